@@ -1,0 +1,215 @@
+/*
+ * mgcfd.h — C ABI of libmgcfd_hip.so: the MI355X (gfx950) implementation of
+ * MG-CFD's edge-flux / multigrid hot path.
+ *
+ * The reference (warwick-hpsc/MG-CFD-app-plain) has no plugin/FFI layer: its
+ * hot path is a set of free functions on caller-owned host arrays
+ * (src/Kernels/{flux_loops,cfd_loops,mg_loops,validation}.h) driven by main()
+ * (src/euler3d_cpu_double.cpp:371-694).  This header exports that same set at
+ * the same granularity behind an opaque handle that keeps the mesh and the
+ * state resident in HBM; every entry point names the reference function it
+ * replaces.  Plain C types only, no exceptions cross the boundary, no exit():
+ * every call returns MGCFD_OK or an error code and mgcfd_last_error() explains.
+ *
+ * Numbering: callers always see the reference's ORIGINAL node and edge
+ * numbering; the library renumbers internally and permutes on the way in/out.
+ * Threading: one host thread per solver handle (as the reference's main()).
+ */
+#ifndef MGCFD_H
+#define MGCFD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGCFD_NVAR 5   /* src/Base/const.h:29  (rho, rho*u, rho*v, rho*w, rho*E) */
+#define MGCFD_RK 3     /* src/Base/const.h:13 */
+
+/* mesh_name codes — src/Base/const.h:40-43 */
+#define MGCFD_MESH_FVCORR 0
+#define MGCFD_MESH_M6_WING 2
+#define MGCFD_MESH_LA_CASCADE 3
+#define MGCFD_MESH_ROTOR_37 4
+
+/* error codes */
+#define MGCFD_OK 0
+#define MGCFD_ERR_ARG 1        /* bad argument / level out of range */
+#define MGCFD_ERR_IO 2         /* file missing or malformed */
+#define MGCFD_ERR_HIP 3        /* HIP runtime failure (no device, OOM, launch error) */
+#define MGCFD_ERR_NAN 4        /* check_for_invalid_variables: NaN/Inf          (validation.cpp:112-121) */
+#define MGCFD_ERR_NEG_DENSITY 5 /* ... negative density                         (validation.cpp:124-128) */
+#define MGCFD_ERR_NEG_ENERGY 6  /* ... negative density*energy                  (validation.cpp:130-134) */
+#define MGCFD_ERR_VALIDATION 7 /* identify_differences found a value out of tolerance (validation.cpp:140-199) */
+
+/* Loop ids: the columns of Times.csv / LoopNumIters.csv in file order
+ * (src/Monitoring/timer.cpp:135-144, src/Base/const.h:31-38 names). */
+enum { MGCFD_LOOP_FLUX = 0, MGCFD_LOOP_UPDATE, MGCFD_LOOP_COMPUTE_STEP, MGCFD_LOOP_TIME_STEP,
+       MGCFD_LOOP_RESTRICT, MGCFD_LOOP_PROLONG, MGCFD_LOOP_INDIRECT_RW, MGCFD_NUM_LOOPS };
+
+/* Per-level arrays a caller can read back / overwrite (reference: the arrays main() owns,
+ * src/euler3d_cpu_double.cpp:138-162). */
+enum { MGCFD_ARR_VARIABLES = 0, MGCFD_ARR_OLD_VARIABLES, MGCFD_ARR_FLUXES, MGCFD_ARR_RESIDUALS,
+       MGCFD_ARR_STEP_FACTORS, MGCFD_ARR_VOLUMES };
+
+/* Solver options (mgcfd_set_option) */
+enum {
+    MGCFD_OPT_EXACT = 0,       /* 1 (default): kernels compiled without FMA contraction and summing in the
+                                  reference's order => bit-identical to the reference built with
+                                  -ffp-contract=off.  0: contraction allowed (faster, ~1e-16 relative). */
+    MGCFD_OPT_TIMING = 1,      /* 1: bracket every loop with hipEvents and accumulate Times.csv columns */
+    MGCFD_OPT_INDIRECT_RW = 2, /* 1: also run the indirect_rw probe each RK stage, as the reference's main() does */
+    MGCFD_OPT_CHECK_INVALID = 3, /* 1 (default): NaN / negativity check every RK stage (validation.cpp:107-138) */
+    MGCFD_OPT_FLUX_VARIANT = 4 /* 0 (default) node-centred gather; other values select experimental kernels */
+};
+
+/* Same 40-byte layout as the reference's edge_neighbour (src/Base/definitions.h:83). */
+typedef struct { int64_t a, b; double x, y, z; } mgcfd_edge;
+
+/* One multigrid level, as read_grid()/read_mg_connectivity() produce it
+ * (src/Base/io.cpp:14-199, src/Base/io_enhanced.cpp:629-650).  All pointers are
+ * caller-owned host memory, copied by mgcfd_create(). */
+typedef struct {
+    int64_t nel;
+    int64_t n_edges;                       /* allocated length of edges[] */
+    int64_t n_internal, n_boundary, n_wall;
+    int64_t internal_start, boundary_start, wall_start;
+    const double *volumes;                 /* [nel] */
+    const double *coords;                  /* [nel*3] x y z; may be NULL for a single-level fvcorr run */
+    const mgcfd_edge *edges;               /* [n_edges]: internal | boundary (a=-1) | wall (a=-2) */
+    const int64_t *mg_map;                 /* [mgc] fine -> coarse map to the next level; NULL on the last */
+    int64_t mgc;
+} mgcfd_level_desc;
+
+typedef struct mgcfd_mesh mgcfd_mesh;      /* host-side multigrid input (files parsed)   */
+typedef struct mgcfd_solver mgcfd_solver;  /* device-resident solver                     */
+
+const char *mgcfd_last_error(void);
+int mgcfd_abi_version(void);
+
+/* ---------------------------------------------------------------------------------
+ * File boundary (host only, no GPU needed)
+ * --------------------------------------------------------------------------------- */
+/* read_input_dat + read_grid + read_mg_connectivity (+ duplicate_mesh when duplicate > 1):
+ * src/Base/io_enhanced.cpp:407-579, src/Base/io.cpp:14-199, io_enhanced.cpp:629-650, :89-201.
+ * `directory` may be NULL/"" (paths then relative to the cwd, as with no -d). */
+int mgcfd_mesh_load(const char *input_dat, const char *directory, int duplicate, mgcfd_mesh **out);
+void mgcfd_mesh_free(mgcfd_mesh *m);
+int mgcfd_mesh_num_levels(const mgcfd_mesh *m);
+int mgcfd_mesh_variant(const mgcfd_mesh *m);
+int mgcfd_mesh_size(const mgcfd_mesh *m);                 /* input.dat "size" x duplicate (euler3d_cpu_double.cpp:259-260) */
+/* Borrowed view of level l (valid until mgcfd_mesh_free). */
+int mgcfd_mesh_level(const mgcfd_mesh *m, int level, mgcfd_level_desc *out);
+
+/* dump(): "%.17e" x5 per node (src/Base/io.cpp:201-233); generic writer for 1- or 5-column arrays. */
+int mgcfd_write_array(const char *path, const double *data, int64_t nel, int ncols);
+/* identify_differences(): returns MGCFD_OK or MGCFD_ERR_VALIDATION; *first_bad = flat index or -1. */
+int mgcfd_identify_differences(const double *test_values, const double *master_values, int64_t nel,
+                               int mesh_variant, int64_t *first_bad);
+
+/* ---------------------------------------------------------------------------------
+ * Solver life cycle
+ * --------------------------------------------------------------------------------- */
+/* Uploads the levels to GPU `device`, applies adjust_ewt/dampen_ewt for the mesh variant
+ * (euler3d_cpu_double.cpp:337-352, validation.cpp:28-75), builds the renumbered gather
+ * structures, and initialises every level to the far-field state
+ * (initialize_far_field_conditions + initialize_variables, cfd_loops.h:44-119;
+ * fluxes/residuals zeroed, euler3d_cpu_double.cpp:321-331). */
+int mgcfd_create(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device,
+                 mgcfd_solver **out);
+int mgcfd_create_from_mesh(const mgcfd_mesh *m, int device, mgcfd_solver **out);
+void mgcfd_destroy(mgcfd_solver *s);
+int mgcfd_set_option(mgcfd_solver *s, int option, int value);
+int mgcfd_get_option(const mgcfd_solver *s, int option, int *value);
+/* Run all subsequent work of this solver on an existing HIP stream (hipStream_t as void*),
+ * e.g. torch.cuda.current_stream().cuda_stream; NULL restores the solver's own stream. */
+int mgcfd_set_stream(mgcfd_solver *s, void *hip_stream);
+int mgcfd_synchronize(mgcfd_solver *s);
+int mgcfd_num_levels(const mgcfd_solver *s);
+int64_t mgcfd_level_nel(const mgcfd_solver *s, int level);
+int64_t mgcfd_level_num_internal_edges(const mgcfd_solver *s, int level);
+/* ff_variable[5] + the four ff_flux_contribution_* vectors (17 doubles), globals.h:11-15. */
+int mgcfd_get_far_field(const mgcfd_solver *s, double *out17);
+
+/* ---------------------------------------------------------------------------------
+ * Kernel-granular operations (asynchronous on the solver's stream)
+ * --------------------------------------------------------------------------------- */
+/* copy<double>(old_variables, variables)                    src/Base/common.h:100-112 */
+int mgcfd_copy_old_variables(mgcfd_solver *s, int level);
+/* compute_step_factor / compute_step_factor_legacy (chosen by mesh variant exactly as
+ * euler3d_cpu_double.cpp:388-395 does)                       src/Kernels/cfd_loops.cpp:13-157 */
+int mgcfd_compute_step_factor(mgcfd_solver *s, int level);
+/* compute_flux_edge over the level's internal edges: fluxes += …   flux_loops.cpp:78-153 */
+int mgcfd_compute_flux_edge(mgcfd_solver *s, int level);
+/* compute_boundary_flux_edge (neighbour code -1)                   flux_loops.cpp:10-42 */
+int mgcfd_compute_boundary_flux_edge(mgcfd_solver *s, int level);
+/* compute_wall_flux_edge (neighbour code -2, far field)            flux_loops.cpp:44-76 */
+int mgcfd_compute_wall_flux_edge(mgcfd_solver *s, int level);
+/* The three above in one launch (same per-node summation order as calling them in sequence). */
+int mgcfd_compute_fluxes(mgcfd_solver *s, int level);
+/* time_step(j, …): variables = old + sf/(RK+1-j)*fluxes; fluxes = 0    cfd_loops.cpp:215-280 */
+int mgcfd_time_step(mgcfd_solver *s, int level, int j);
+/* zero_fluxes                                                       cfd_loops.cpp:282-305 */
+int mgcfd_zero_fluxes(mgcfd_solver *s, int level);
+/* indirect_rw over the internal edges (fluxes += …)                 indirect_rw_loop.cpp:11-78 */
+int mgcfd_indirect_rw(mgcfd_solver *s, int level);
+/* residual(): residuals = variables - old_variables                 validation.cpp:77-89 */
+int mgcfd_residual(mgcfd_solver *s, int level);
+/* calc_rms(): sqrt(sum(r^2)/nel); synchronises                      validation.cpp:91-105 */
+int mgcfd_calc_rms(mgcfd_solver *s, int level, double *rms);
+/* check_for_invalid_variables(); synchronises; returns MGCFD_OK or MGCFD_ERR_NAN/NEG_*;
+ * *bad_cell = first offending cell in original numbering          validation.cpp:107-138 */
+int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_cell);
+/* mg_restrict(variables[fine] -> variables[fine+1])                 mg_loops.cpp:30-202 */
+int mgcfd_restrict(mgcfd_solver *s, int fine_level);
+/* prolong_residuals_interpolate_proper(residuals[fine+1] -> variables[fine])   mg_loops.cpp:678-864 */
+int mgcfd_prolong(mgcfd_solver *s, int fine_level);
+
+/* ---------------------------------------------------------------------------------
+ * Cycle driver — the state machine of src/euler3d_cpu_double.cpp:371-694
+ * --------------------------------------------------------------------------------- */
+/* Runs `cycles` (multigrid) cycles from the solver's current state.  rms_out (may be NULL)
+ * receives, per cycle, the level-0 RMS the reference prints.  Synchronises before returning.
+ * On an invalid state returns MGCFD_ERR_NAN / NEG_* like the reference's exit(). */
+int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out);
+
+/* ---------------------------------------------------------------------------------
+ * State access (synchronous; original numbering)
+ * --------------------------------------------------------------------------------- */
+int mgcfd_get_array(mgcfd_solver *s, int level, int which, double *out);        /* [nel*5] or [nel] */
+int mgcfd_set_array(mgcfd_solver *s, int level, int which, const double *in);
+/* Edge weights after adjust/dampen, original edge order: [n_edges] records. */
+int mgcfd_get_edges(mgcfd_solver *s, int level, mgcfd_edge *out);
+
+/* ---------------------------------------------------------------------------------
+ * Monitoring — LoopNumIters.csv / Times.csv contents
+ * (src/Monitoring/loop_stats.cpp:48-171, src/Monitoring/timer.cpp:58-195)
+ * --------------------------------------------------------------------------------- */
+int mgcfd_get_loop_iters(const mgcfd_solver *s, int level, int64_t out[MGCFD_NUM_LOOPS]);
+int mgcfd_get_loop_times(mgcfd_solver *s, int level, double out_seconds[MGCFD_NUM_LOOPS]);
+int mgcfd_reset_monitoring(mgcfd_solver *s);
+/* Average GPU duration (seconds) of the internal-edge flux launches issued since the last
+ * reset, measured with hipEvents on the launch stream, and how many launches that covers.
+ * Requires MGCFD_OPT_TIMING. */
+int mgcfd_get_flux_kernel_time(mgcfd_solver *s, int level, double *avg_seconds, int64_t *launches);
+
+/* ---------------------------------------------------------------------------------
+ * Multi-GPU hooks (one process per GPU; the collectives themselves are issued by the
+ * host through RCCL — see INTEGRATION.md).  compute_step_factor's global min
+ * (cfd_loops.cpp:137-150) is split so an all-reduce(min) can run between the halves.
+ * --------------------------------------------------------------------------------- */
+/* First half: per-node 0.5*dt and the rank-local minimum, left in a device scalar. */
+int mgcfd_step_factor_local(mgcfd_solver *s, int level);
+/* Device address of that fp64 scalar (for an in-place RCCL all-reduce MIN). */
+int mgcfd_step_factor_min_devptr(mgcfd_solver *s, int level, void **devptr);
+/* Second half: step_factors[i] = min_dt / volumes[i]. */
+int mgcfd_step_factor_apply(mgcfd_solver *s, int level);
+/* Sum of squared residuals of the level, left in a device scalar (all-reduce SUM, then
+ * rms = sqrt(sum / global_nel)). */
+int mgcfd_residual_sumsq(mgcfd_solver *s, int level, void **devptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGCFD_H */

@@ -1,0 +1,42 @@
+// device_plan.hpp — plain structs shared by the host solver and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "preprocess.hpp"
+
+namespace mgcfd {
+
+// Per-node record the flux gather reads: the 5 conserved variables plus the quantities the
+// reference derives from them for every incident edge (cfd_loops.h:121-148).  96 bytes,
+// 16-byte aligned, fetched with six 16-byte loads.
+struct alignas(16) NodeQ {
+    double rho, mx, my, mz, en;
+    double vx, vy, vz, p, speed, c, pad;
+};
+static_assert(sizeof(NodeQ) == 96, "NodeQ must be 96 bytes");
+static_assert(sizeof(EdgeW) == 32, "EdgeW must be 32 bytes");
+static_assert(sizeof(ProlongW) == 24, "ProlongW must be 24 bytes");
+
+// ff_variable + ff_flux_contribution_* (src/Base/globals.h:11-15), passed by value.
+struct FarField {
+    double var[5];
+    double fc_mx[3], fc_my[3], fc_mz[3], fc_de[3];
+};
+
+// Device pointers of one level's gather plan.
+struct DevicePlan {
+    int64_t nel = 0;
+    int32_t n_slices = 0;
+    int32_t *slice_row0 = nullptr, *rows_int = nullptr, *rows_bnd = nullptr, *nbr = nullptr;
+    EdgeW *w = nullptr;
+    int32_t *old_of_new = nullptr;
+    // transfer to/from the next-coarser level
+    int32_t *child_ptr = nullptr, *child = nullptr;
+    ProlongW *pro = nullptr;
+    int32_t *pro_parent = nullptr;
+    double *pro_wsum = nullptr;
+};
+
+} // namespace mgcfd

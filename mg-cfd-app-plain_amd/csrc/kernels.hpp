@@ -1,0 +1,34 @@
+// kernels.hpp — launchers of kernels.hip, declared once per numeric flavour.
+#pragma once
+
+#include "device_plan.hpp"
+
+#define MGCFD_DECLARE_LAUNCHERS(NS)                                                                                  \
+    namespace mgcfd { namespace NS {                                                                                 \
+    void launch_init_variables(hipStream_t, int64_t nel, const FarField &, double *variables, NodeQ *nodeq);         \
+    void launch_derive(hipStream_t, int64_t nel, const double *variables, NodeQ *nodeq);                             \
+    void launch_step_factor_local(hipStream_t, int64_t nel, const double *variables, const double *cbrt_vol,         \
+                                  double *sf, NodeQ *nodeq, unsigned long long *min_bits);                           \
+    void launch_step_factor_apply(hipStream_t, int64_t nel, const unsigned long long *min_bits,                      \
+                                  const double *volumes, double *sf);                                                \
+    void launch_step_factor_legacy(hipStream_t, int64_t nel, const double *variables, const double *volumes,         \
+                                   double *sf, NodeQ *nodeq);                                                        \
+    void launch_flux_gather(hipStream_t, const DevicePlan &, const NodeQ *nodeq, const FarField &, double *fluxes,   \
+                            int classes, int accumulate);                                                            \
+    void launch_indirect_rw(hipStream_t, const DevicePlan &, const NodeQ *nodeq, double *fluxes);                    \
+    void launch_time_step(hipStream_t, int64_t nel, int j, const double *sf, double *fluxes,                         \
+                          const double *old_variables, double *variables, NodeQ *nodeq,                              \
+                          const int32_t *old_of_new, unsigned long long *err, int check);                            \
+    void launch_check_invalid(hipStream_t, int64_t nel, const double *variables, const int32_t *old_of_new,          \
+                              unsigned long long *err);                                                              \
+    void launch_residual(hipStream_t, int64_t nel, const double *old_variables, const double *variables,             \
+                         double *residuals);                                                                         \
+    void launch_sumsq(hipStream_t, int64_t n, const double *x, double *partial, int n_partial, double *out);         \
+    void launch_restrict(hipStream_t, int64_t nel_coarse, const int32_t *child_ptr, const int32_t *child,            \
+                         const double *fine_variables, double *coarse_variables);                                    \
+    void launch_prolong(hipStream_t, const DevicePlan &, const double *coarse_residuals,                             \
+                        const double *fine_residuals, double *fine_variables);                                       \
+    } }
+
+MGCFD_DECLARE_LAUNCHERS(exact)
+MGCFD_DECLARE_LAUNCHERS(fast)

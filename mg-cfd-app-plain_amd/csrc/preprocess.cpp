@@ -1,0 +1,341 @@
+// preprocess.cpp — renumbering and gather-structure construction (host, once per mesh).
+// Compiled with -ffp-contract=off: the static weights computed here (edge length factor,
+// inverse distances, weight sums) must carry the same bits the reference computes at run time.
+#include "preprocess.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <queue>
+#include <stdexcept>
+#include <string>
+
+namespace mgcfd {
+
+namespace {
+
+// src/Base/common.h:24 — a float literal widened to double.
+const double kSmoothing = double(0.2f);
+
+struct Adjacency {
+    std::vector<int32_t> ptr, idx;
+};
+
+Adjacency build_adjacency(int64_t nel, const mgcfd_edge *edges, int64_t first, int64_t count)
+{
+    Adjacency g;
+    g.ptr.assign(static_cast<size_t>(nel) + 1, 0);
+    for (int64_t e = first; e < first + count; e++) {
+        g.ptr[static_cast<size_t>(edges[e].a) + 1]++;
+        g.ptr[static_cast<size_t>(edges[e].b) + 1]++;
+    }
+    std::partial_sum(g.ptr.begin(), g.ptr.end(), g.ptr.begin());
+    g.idx.resize(static_cast<size_t>(g.ptr.back()));
+    std::vector<int32_t> fill(g.ptr.begin(), g.ptr.end() - 1);
+    for (int64_t e = first; e < first + count; e++) {
+        const int32_t a = static_cast<int32_t>(edges[e].a), b = static_cast<int32_t>(edges[e].b);
+        g.idx[static_cast<size_t>(fill[a]++)] = b;
+        g.idx[static_cast<size_t>(fill[b]++)] = a;
+    }
+    return g;
+}
+
+// Breadth-first (Cuthill–McKee) ordering: a wavefront's 64 consecutive nodes then have
+// their r-th neighbours in a narrow, mostly ascending window of the node array, which is
+// what makes the per-row gathers cache friendly.  Handles disconnected meshes (-m copies).
+std::vector<int32_t> cuthill_mckee(const Adjacency &g, int64_t nel)
+{
+    std::vector<int32_t> order;
+    order.reserve(static_cast<size_t>(nel));
+    std::vector<char> seen(static_cast<size_t>(nel), 0);
+    auto degree = [&](int32_t v) { return g.ptr[static_cast<size_t>(v) + 1] - g.ptr[static_cast<size_t>(v)]; };
+    std::vector<int32_t> level_nodes, scratch;
+
+    auto bfs_far_node = [&](int32_t start) {
+        // returns the last node reached from `start` (an approximately peripheral node)
+        std::vector<int32_t> frontier{start}, next;
+        std::vector<int32_t> touched{start};
+        seen[static_cast<size_t>(start)] = 2;
+        int32_t last = start;
+        while (!frontier.empty()) {
+            next.clear();
+            for (int32_t v : frontier)
+                for (int32_t k = g.ptr[static_cast<size_t>(v)]; k < g.ptr[static_cast<size_t>(v) + 1]; k++) {
+                    int32_t u = g.idx[static_cast<size_t>(k)];
+                    if (!seen[static_cast<size_t>(u)]) { seen[static_cast<size_t>(u)] = 2; next.push_back(u); touched.push_back(u); }
+                }
+            if (!next.empty()) {
+                last = *std::min_element(next.begin(), next.end(), [&](int32_t x, int32_t y) { return degree(x) < degree(y); });
+            }
+            frontier.swap(next);
+        }
+        for (int32_t v : touched) seen[static_cast<size_t>(v)] = 0;
+        return last;
+    };
+
+    for (int64_t s0 = 0; s0 < nel; s0++) {
+        if (seen[static_cast<size_t>(s0)]) continue;
+        int32_t start = bfs_far_node(static_cast<int32_t>(s0));
+        start = bfs_far_node(start);
+        size_t head = order.size();
+        order.push_back(start);
+        seen[static_cast<size_t>(start)] = 1;
+        while (head < order.size()) {
+            int32_t v = order[head++];
+            scratch.clear();
+            for (int32_t k = g.ptr[static_cast<size_t>(v)]; k < g.ptr[static_cast<size_t>(v) + 1]; k++) {
+                int32_t u = g.idx[static_cast<size_t>(k)];
+                if (!seen[static_cast<size_t>(u)]) { seen[static_cast<size_t>(u)] = 1; scratch.push_back(u); }
+            }
+            std::sort(scratch.begin(), scratch.end(), [&](int32_t x, int32_t y) {
+                int dx = degree(x), dy = degree(y);
+                return dx != dy ? dx < dy : x < y;
+            });
+            order.insert(order.end(), scratch.begin(), scratch.end());
+        }
+    }
+    return order;   // order[new] = old
+}
+
+inline double inv_distance(const double *p, const double *q)
+{
+    const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+    return 1.0 / std::sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+inline bool coincident(const double *fine, const double *coarse)
+{
+    return (fine[0] - coarse[0]) == 0.0 && (fine[1] - coarse[1]) == 0.0 && (fine[2] - coarse[2]) == 0.0;
+}
+
+} // namespace
+
+void far_field_constants(double *out)
+{
+    // src/Kernels/cfd_loops.h:85-119, src/Base/const.h:9-15
+    const double gamma = 1.4, ff_mach = 1.2, deg_aoa = 0.0;
+    const double angle = double(3.1415926535897931 / 180.0) * double(deg_aoa);
+    double var[5];
+    var[0] = 1.4;
+    const double pressure = 1.0;
+    const double c = std::sqrt(gamma * pressure / var[0]);
+    const double speed = ff_mach * c;
+    const double vx = speed * std::cos(angle), vy = speed * std::sin(angle), vz = 0.0;
+    var[1] = var[0] * vx;
+    var[2] = var[0] * vy;
+    var[3] = var[0] * vz;
+    var[4] = var[0] * (0.5 * (speed * speed)) + (pressure / (gamma - 1.0));
+    for (int v = 0; v < 5; v++) out[v] = var[v];
+    // compute_flux_contribution, cfd_loops.h:57-83
+    double *mx = out + 5, *my = out + 8, *mz = out + 11, *de = out + 14;
+    mx[0] = vx * var[1] + pressure; mx[1] = vx * var[2]; mx[2] = vx * var[3];
+    my[0] = mx[1]; my[1] = vy * var[2] + pressure; my[2] = vy * var[3];
+    mz[0] = mx[2]; mz[1] = my[2]; mz[2] = vz * var[3] + pressure;
+    const double de_p = var[4] + pressure;
+    de[0] = vx * de_p; de[1] = vy * de_p; de[2] = vz * de_p;
+}
+
+void adjust_and_dampen(const mgcfd_level_desc &L, int mesh_variant, std::vector<mgcfd_edge> &edges)
+{
+    double damping = 0.0;
+    if (mesh_variant == MGCFD_MESH_M6_WING) damping = 5e-8;
+    else if (mesh_variant == MGCFD_MESH_LA_CASCADE) damping = 1e-7;
+    else if (mesh_variant == MGCFD_MESH_ROTOR_37) damping = 2e-7;
+    if (damping == 0.0) return;
+    if (!L.coords) throw std::runtime_error("mesh variant needs node coordinates (.coords) for adjust_ewt");
+    for (auto &e : edges) {
+        if (e.a >= 0 && e.b >= 0) {
+            // |w| is a face area; divide by the node distance (validation.cpp:41-55)
+            const double *ca = L.coords + 3 * e.a, *cb = L.coords + 3 * e.b;
+            double dist = 0.0, d;
+            d = cb[0] - ca[0]; dist += d * d;
+            d = cb[1] - ca[1]; dist += d * d;
+            d = cb[2] - ca[2]; dist += d * d;
+            dist = std::sqrt(dist);
+            e.x /= dist; e.y /= dist; e.z /= dist;
+        }
+        e.x *= damping; e.y *= damping; e.z *= damping;       // validation.cpp:70-74
+    }
+}
+
+void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &edges,
+                      const PlanOptions &opt, LevelPlan &P)
+{
+    const int64_t nel = L.nel;
+    if (nel <= 0 || nel >= (int64_t(1) << 30)) throw std::runtime_error("level size out of range for 30-bit node ids");
+    for (int64_t e = L.internal_start; e < L.internal_start + L.n_internal; e++)
+        if (edges[e].a < 0 || edges[e].a >= nel || edges[e].b < 0 || edges[e].b >= nel)
+            throw std::runtime_error("internal edge " + std::to_string(e) + " has an end point outside [0, nel)");
+    for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++)
+        if (edges[e].b < 0 || edges[e].b >= nel) throw std::runtime_error("boundary edge with bad node");
+    for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++)
+        if (edges[e].b < 0 || edges[e].b >= nel) throw std::runtime_error("wall edge with bad node");
+
+    P.nel = nel;
+    const Adjacency g = build_adjacency(nel, edges.data(), L.internal_start, L.n_internal);
+
+    // ---- node order ----
+    std::vector<int32_t> order;
+    if (opt.renumber) order = cuthill_mckee(g, nel);
+    else { order.resize(static_cast<size_t>(nel)); std::iota(order.begin(), order.end(), 0); }
+    std::vector<int32_t> bnd_count(static_cast<size_t>(nel), 0);
+    for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++) bnd_count[static_cast<size_t>(edges[e].b)]++;
+    for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++) bnd_count[static_cast<size_t>(edges[e].b)]++;
+    if (opt.degree_sort_window > kSlice) {
+        // Inside each window sort by (internal degree, boundary faces) so the 64 nodes of a
+        // slice have equal row counts and ELL padding stays small; windows keep locality.
+        const int64_t W = opt.degree_sort_window;
+        for (int64_t s = 0; s < nel; s += W) {
+            auto b = order.begin() + s, e = order.begin() + std::min(nel, s + W);
+            std::stable_sort(b, e, [&](int32_t x, int32_t y) {
+                int dx = g.ptr[static_cast<size_t>(x) + 1] - g.ptr[static_cast<size_t>(x)];
+                int dy = g.ptr[static_cast<size_t>(y) + 1] - g.ptr[static_cast<size_t>(y)];
+                if (dx != dy) return dx > dy;
+                return bnd_count[static_cast<size_t>(x)] > bnd_count[static_cast<size_t>(y)];
+            });
+        }
+    }
+    P.old_of_new = order;
+    P.new_of_old.assign(static_cast<size_t>(nel), 0);
+    for (int64_t n = 0; n < nel; n++) P.new_of_old[static_cast<size_t>(order[static_cast<size_t>(n)])] = static_cast<int32_t>(n);
+
+    // ---- slice geometry ----
+    P.n_slices = static_cast<int32_t>((nel + kSlice - 1) / kSlice);
+    P.rows_int.assign(static_cast<size_t>(P.n_slices), 0);
+    P.rows_bnd.assign(static_cast<size_t>(P.n_slices), 0);
+    for (int64_t n = 0; n < nel; n++) {
+        const int32_t old = order[static_cast<size_t>(n)];
+        const int32_t s = static_cast<int32_t>(n / kSlice);
+        const int32_t d = g.ptr[static_cast<size_t>(old) + 1] - g.ptr[static_cast<size_t>(old)];
+        P.rows_int[static_cast<size_t>(s)] = std::max(P.rows_int[static_cast<size_t>(s)], d);
+        P.rows_bnd[static_cast<size_t>(s)] = std::max(P.rows_bnd[static_cast<size_t>(s)], bnd_count[static_cast<size_t>(old)]);
+    }
+    P.slice_row0.assign(static_cast<size_t>(P.n_slices) + 1, 0);
+    for (int32_t s = 0; s < P.n_slices; s++)
+        P.slice_row0[static_cast<size_t>(s) + 1] = P.slice_row0[static_cast<size_t>(s)] + P.rows_int[static_cast<size_t>(s)] + P.rows_bnd[static_cast<size_t>(s)];
+    const int64_t rows = P.slice_row0.back();
+    if (rows * kSlice >= (int64_t(1) << 31)) throw std::runtime_error("gather structure exceeds 2^31 entries");
+    P.nbr.assign(static_cast<size_t>(rows) * kSlice, kCodePad);
+    P.w.assign(static_cast<size_t>(rows) * kSlice, EdgeW{0.0, 0.0, 0.0, 0.0});
+
+    // ---- fill, in original edge order = the reference's accumulation order ----
+    std::vector<int32_t> fill_int(static_cast<size_t>(nel), 0), fill_bnd(static_cast<size_t>(nel), 0);
+    auto entry_index = [&](int32_t node_new, int32_t row_in_slice) {
+        const int32_t s = node_new / kSlice, lane = node_new % kSlice;
+        return (static_cast<int64_t>(P.slice_row0[static_cast<size_t>(s)]) + row_in_slice) * kSlice + lane;
+    };
+    int64_t useful = 0;
+    for (int64_t e = L.internal_start; e < L.internal_start + L.n_internal; e++) {
+        const mgcfd_edge &E = edges[static_cast<size_t>(e)];
+        const int32_t a = P.new_of_old[static_cast<size_t>(E.a)], b = P.new_of_old[static_cast<size_t>(E.b)];
+        const double ewt = std::sqrt(E.x * E.x + E.y * E.y + E.z * E.z);      // flux_kernel.elemfunc.c:27
+        const double k = -ewt * kSmoothing * 0.5;                              // prefix of :130
+        const double fx = -0.5 * E.x, fy = -0.5 * E.y, fz = -0.5 * E.z;       // :138-140
+        int64_t ia = entry_index(a, fill_int[static_cast<size_t>(a)]++);
+        P.nbr[static_cast<size_t>(ia)] = b;                                    // this node is 'a'
+        P.w[static_cast<size_t>(ia)] = EdgeW{fx, fy, fz, k};
+        int64_t ib = entry_index(b, fill_int[static_cast<size_t>(b)]++);
+        P.nbr[static_cast<size_t>(ib)] = a | kRoleB;                           // this node is 'b'
+        P.w[static_cast<size_t>(ib)] = EdgeW{-fx, -fy, -fz, k};                // x - f*y == x + (-f)*y exactly
+        useful += 2;
+    }
+    auto add_face = [&](const mgcfd_edge &E, int32_t code, double scale) {
+        const int32_t b = P.new_of_old[static_cast<size_t>(E.b)];
+        const int32_t s = b / kSlice;
+        int64_t i = entry_index(b, P.rows_int[static_cast<size_t>(s)] + fill_bnd[static_cast<size_t>(b)]++);
+        P.nbr[static_cast<size_t>(i)] = code;
+        P.w[static_cast<size_t>(i)] = EdgeW{scale * E.x, scale * E.y, scale * E.z, 0.0};
+    };
+    for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++) add_face(edges[static_cast<size_t>(e)], kCodeWall, 1.0);
+    for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++) add_face(edges[static_cast<size_t>(e)], kCodeFar, 0.5);
+
+    P.n_internal_entries = useful;
+    int64_t int_slots = 0;
+    for (int32_t s = 0; s < P.n_slices; s++) int_slots += static_cast<int64_t>(P.rows_int[static_cast<size_t>(s)]) * kSlice;
+    P.pad_fraction = useful > 0 ? double(int_slots - useful) / double(useful) : 0.0;
+}
+
+void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge> &fine_edges,
+                         const double *coarse_coords, int64_t nel_coarse,
+                         const std::vector<int32_t> &coarse_new_of_old, LevelPlan &P)
+{
+    if (!F.mg_map) throw std::runtime_error("level has no multigrid map");
+    const int64_t nel = F.nel, mgc = F.mgc;
+    if (mgc > nel) throw std::runtime_error("multigrid map longer than the fine level");
+    for (int64_t i = 0; i < mgc; i++)
+        if (F.mg_map[i] < 0 || F.mg_map[i] >= nel_coarse) throw std::runtime_error("multigrid map entry out of range");
+
+    // ---- restriction: children of every coarse node, ascending original fine id ----
+    P.child_ptr.assign(static_cast<size_t>(nel_coarse) + 1, 0);
+    for (int64_t i = 0; i < mgc; i++) P.child_ptr[static_cast<size_t>(coarse_new_of_old[static_cast<size_t>(F.mg_map[i])]) + 1]++;
+    std::partial_sum(P.child_ptr.begin(), P.child_ptr.end(), P.child_ptr.begin());
+    P.child.assign(static_cast<size_t>(mgc), 0);
+    {
+        std::vector<int32_t> fill(P.child_ptr.begin(), P.child_ptr.end() - 1);
+        for (int64_t i = 0; i < mgc; i++) {
+            const int32_t c = coarse_new_of_old[static_cast<size_t>(F.mg_map[i])];
+            P.child[static_cast<size_t>(fill[static_cast<size_t>(c)]++)] = P.new_of_old[static_cast<size_t>(i)];
+        }
+    }
+
+    // ---- prolongation weights (mg_loops.cpp:730-812), static because geometry is ----
+    if (mgc < nel) throw std::runtime_error("prolongation needs a parent for every fine node (mgc < nel)");
+    if (!F.coords || !coarse_coords) throw std::runtime_error("prolongation needs node coordinates on both levels");
+    P.pro.assign(P.nbr.size(), ProlongW{0.0, 0.0, 0, 0});
+    P.pro_parent.assign(static_cast<size_t>(nel), 0);
+    P.pro_wsum.assign(static_cast<size_t>(nel), 0.0);
+    std::vector<char> is_coincident(static_cast<size_t>(nel), 0);
+    for (int64_t i = 0; i < nel; i++) {
+        const int64_t p_old = F.mg_map[i];
+        const int32_t p_new = coarse_new_of_old[static_cast<size_t>(p_old)];
+        const bool same = coincident(F.coords + 3 * i, coarse_coords + 3 * p_old);
+        is_coincident[static_cast<size_t>(i)] = same;
+        const int32_t n = P.new_of_old[static_cast<size_t>(i)];
+        P.pro_parent[static_cast<size_t>(n)] = same ? ~p_new : p_new;
+        if (same) P.pro_wsum[static_cast<size_t>(n)] = 1.0;
+    }
+    std::vector<int32_t> fill(static_cast<size_t>(nel), 0);
+    auto entry_index = [&](int32_t node_new, int32_t row_in_slice) {
+        const int32_t s = node_new / kSlice, lane = node_new % kSlice;
+        return (static_cast<int64_t>(P.slice_row0[static_cast<size_t>(s)]) + row_in_slice) * kSlice + lane;
+    };
+    for (int64_t e = F.internal_start; e < F.internal_start + F.n_internal; e++) {
+        const int64_t a2 = fine_edges[static_cast<size_t>(e)].a, b2 = fine_edges[static_cast<size_t>(e)].b;
+        const int64_t a1 = F.mg_map[a2], b1 = F.mg_map[b2];
+        const double *ca1 = coarse_coords + 3 * a1, *cb1 = coarse_coords + 3 * b1;
+        const double *ca2 = F.coords + 3 * a2, *cb2 = F.coords + 3 * b2;
+        const int32_t a1n = coarse_new_of_old[static_cast<size_t>(a1)], b1n = coarse_new_of_old[static_cast<size_t>(b1)];
+        const int32_t an = P.new_of_old[static_cast<size_t>(a2)], bn = P.new_of_old[static_cast<size_t>(b2)];
+        // a2's entry: own parent a1, then b1
+        {
+            ProlongW w{0.0, 0.0, a1n, b1n};
+            if (!is_coincident[static_cast<size_t>(a2)]) {
+                w.w_own = inv_distance(ca2, ca1);      // :754
+                w.w_other = inv_distance(cb1, ca2);    // :768
+                P.pro_wsum[static_cast<size_t>(an)] += w.w_own;
+                P.pro_wsum[static_cast<size_t>(an)] += w.w_other;
+            }
+            P.pro[static_cast<size_t>(entry_index(an, fill[static_cast<size_t>(an)]++))] = w;
+        }
+        // b2's entry: own parent b1, then "a1" — which the reference reads from b1 (:805-809)
+        {
+            ProlongW w{0.0, 0.0, b1n, b1n};
+            if (!is_coincident[static_cast<size_t>(b2)]) {
+                w.w_own = inv_distance(cb2, cb1);      // :792
+                w.w_other = inv_distance(ca1, cb2);    // :806
+                P.pro_wsum[static_cast<size_t>(bn)] += w.w_own;
+                P.pro_wsum[static_cast<size_t>(bn)] += w.w_other;
+            }
+            P.pro[static_cast<size_t>(entry_index(bn, fill[static_cast<size_t>(bn)]++))] = w;
+        }
+    }
+    // A coincident node that no internal edge touches never gets its w_sums/res2_wavg assigned
+    // in the reference (both stay 0 => 0/0); express it as a plain node with no entries.
+    for (int64_t n = 0; n < nel; n++)
+        if (P.pro_parent[static_cast<size_t>(n)] < 0 && fill[static_cast<size_t>(n)] == 0) {
+            P.pro_parent[static_cast<size_t>(n)] = ~P.pro_parent[static_cast<size_t>(n)];
+            P.pro_wsum[static_cast<size_t>(n)] = 0.0;
+        }
+}
+
+} // namespace mgcfd

@@ -1,0 +1,82 @@
+// preprocess.hpp — host-side construction of the device gather structures.
+//
+// The reference walks an edge list and scatter-adds into both end points
+// (src/Kernels/flux_loops.cpp:133-136).  On the GPU every node instead GATHERS
+// its incident edges: nodes are renumbered for locality, grouped into slices of
+// 64 consecutive nodes (one wavefront) and each slice stores its incidence lists
+// as a sliced-ELLPACK block, row r holding the r-th incident edge of all 64
+// nodes contiguously.  The r-th entries are ordered by ORIGINAL edge index
+// (internal, then boundary, then wall), which is exactly the order in which the
+// reference's serial loops add into fluxes[node] — so a per-node sequential sum
+// reproduces the reference's floating-point result bit for bit, with no atomics.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "mgcfd.h"
+
+namespace mgcfd {
+
+constexpr int kSlice = 64;   // wavefront width
+
+// neighbour codes in Sell::nbr
+constexpr int32_t kRoleB = 1 << 30;     // set when THIS node is the edge's 'b' end (else it is 'a')
+constexpr int32_t kIdMask = kRoleB - 1;
+constexpr int32_t kCodeWall = -1;       // reference neighbour code -1: solid wall   ("boundary" edges)
+constexpr int32_t kCodeFar = -2;        // reference neighbour code -2: far field    ("wall" edges)
+constexpr int32_t kCodePad = -3;
+
+struct EdgeW { double x, y, z, k; };    // 32 B, one per (node, incident edge)
+struct ProlongW { double w_own, w_other; int32_t p_own, p_other; };   // 24 B
+
+struct LevelPlan {
+    int64_t nel = 0;
+    int32_t n_slices = 0;
+    std::vector<int32_t> new_of_old, old_of_new;   // node permutation
+
+    // ---- flux gather (sliced ELL) ----
+    std::vector<int32_t> slice_row0;   // [n_slices+1] first row of each slice; entry index = row*64 + lane
+    std::vector<int32_t> rows_int;     // [n_slices] rows holding internal edges
+    std::vector<int32_t> rows_bnd;     // [n_slices] rows holding boundary/far-field faces (after the internal rows)
+    std::vector<int32_t> nbr;          // [rows*64] neighbour (new id | role bit) or a kCode*
+    std::vector<EdgeW> w;              // [rows*64]
+    //   internal, this node = a:  (x,y,z) = -0.5*e   k = -|e|*smoothing*0.5   (flux_kernel.elemfunc.c:130-140)
+    //   internal, this node = b:  (x,y,z) = +0.5*e   k = same
+    //   wall (-1):                (x,y,z) = e                                  (flux_boundary_kernel.elemfunc.c:37-45)
+    //   far field (-2):           (x,y,z) = 0.5*e                              (flux_wall_kernel.elemfunc.c:51-53)
+    int64_t n_internal_entries = 0;    // = 2 * internal edges
+    double pad_fraction = 0.0;         // padding / useful entries in the internal rows
+
+    // ---- restriction to the next-coarser level: coarse-centred CSR of children ----
+    std::vector<int32_t> child_ptr;    // [nel_coarse+1]
+    std::vector<int32_t> child;        // fine NEW ids, ascending ORIGINAL fine id (mg_loops.cpp:119-142 order)
+
+    // ---- prolongation from the next-coarser level (shares slice_row0/rows_int) ----
+    std::vector<ProlongW> pro;         // [rows*64] only the internal rows are meaningful
+    std::vector<int32_t> pro_parent;   // [nel] coarse NEW id of the node's parent; ~id when the node coincides with it
+    std::vector<double> pro_wsum;      // [nel] sum of weights in reference order (1.0 when coincident)
+};
+
+struct PlanOptions {
+    int degree_sort_window = 1024;     // nodes per window inside which nodes are sorted by degree (0 = off)
+    bool renumber = true;
+};
+
+// `edges` are the level's final edge weights (after adjust/dampen).  coarse_new_of_old is
+// the permutation of the next-coarser level (needed to express parents in new ids), empty
+// on the last level.
+void build_level_plan(const mgcfd_level_desc &lvl, const std::vector<mgcfd_edge> &edges,
+                      const PlanOptions &opt, LevelPlan &plan);
+void build_transfer_plan(const mgcfd_level_desc &fine, const std::vector<mgcfd_edge> &fine_edges,
+                         const double *coarse_coords, int64_t nel_coarse,
+                         const std::vector<int32_t> &coarse_new_of_old, LevelPlan &fine_plan);
+
+// Edge-weight preconditioning exactly as the reference does before its loop
+// (src/Kernels/validation.cpp:28-75, src/euler3d_cpu_double.cpp:337-352).
+void adjust_and_dampen(const mgcfd_level_desc &lvl, int mesh_variant, std::vector<mgcfd_edge> &edges);
+
+// ff_variable + ff_flux_contribution_* (src/Kernels/cfd_loops.h:85-119); out[17].
+void far_field_constants(double *out17);
+
+} // namespace mgcfd

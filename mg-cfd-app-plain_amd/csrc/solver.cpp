@@ -1,0 +1,729 @@
+// solver.cpp — device-resident solver behind the C ABI of include/mgcfd.h.
+//
+// Owns, per multigrid level, the state arrays the reference's main() owns
+// (src/euler3d_cpu_double.cpp:138-162) in HBM, in the renumbered node order of the
+// level's gather plan, and exposes the reference's kernel set one call per loop plus the
+// V-cycle state machine (src/euler3d_cpu_double.cpp:371-694).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "mesh.hpp"
+#include "mgcfd.h"
+#include "preprocess.hpp"
+
+namespace mgcfd {
+
+static thread_local std::string g_last_error;
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string &m) : std::runtime_error(m) {}
+};
+
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            throw HipError(std::string(#expr) + " failed: " + hipGetErrorString(_e));                \
+    } while (0)
+
+template <typename T> static T *dev_alloc(size_t n)
+{
+    void *p = nullptr;
+    HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+    return static_cast<T *>(p);
+}
+
+template <typename T> static T *dev_upload(const std::vector<T> &v)
+{
+    T *p = dev_alloc<T>(v.size());
+    if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return p;
+}
+
+struct EventPair { hipEvent_t start, stop; int level, loop; bool is_flux_internal; };
+
+struct DeviceLevel {
+    mgcfd_level_desc info{};             // sizes only (pointers nulled)
+    std::vector<mgcfd_edge> edges;       // final edge weights, original order
+    LevelPlan plan;                      // host copy (permutations for get/set)
+    DevicePlan dp;
+    double *variables = nullptr, *old_variables = nullptr, *fluxes = nullptr, *residuals = nullptr;
+    double *step_factors = nullptr, *volumes = nullptr, *cbrt_vol = nullptr;
+    NodeQ *nodeq = nullptr;
+    unsigned long long *min_bits = nullptr;
+    double *sumsq = nullptr, *partials = nullptr;
+    int n_partials = 0;
+    bool nodeq_stale = false;
+    bool has_transfer = false;           // plan to the next-coarser level present
+    int64_t iters[MGCFD_NUM_LOOPS] = {0};
+    double times[MGCFD_NUM_LOOPS] = {0};
+    double flux_time = 0.0;
+    int64_t flux_launches = 0;
+};
+
+} // namespace mgcfd
+
+using namespace mgcfd;
+
+struct mgcfd_mesh { HostMesh mesh; };
+
+struct mgcfd_solver {
+    int device = 0;
+    int mesh_variant = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<DeviceLevel> L;
+    FarField ff{};
+    double ff17[17] = {0};
+    unsigned long long *err = nullptr;       // device: packed (cell << 8 | code), ~0 = clean
+    int opt_exact = 1, opt_timing = 0, opt_indirect_rw = 0, opt_check = 1, opt_variant = 0;
+    std::vector<EventPair> pending;
+    std::vector<hipEvent_t> free_events;
+
+    ~mgcfd_solver();
+    void use_device() const { HIP_CHECK(hipSetDevice(device)); }
+    DeviceLevel &level(int l)
+    {
+        if (l < 0 || l >= static_cast<int>(L.size())) throw std::invalid_argument("level out of range");
+        return L[static_cast<size_t>(l)];
+    }
+
+    // ---- timing --------------------------------------------------------------------------
+    hipEvent_t get_event()
+    {
+        if (pending.size() >= 8192) fold_events();
+        if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+    void fold_events()
+    {
+        if (pending.empty()) return;
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (auto &p : pending) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, p.start, p.stop));
+            DeviceLevel &lv = L[static_cast<size_t>(p.level)];
+            lv.times[p.loop] += double(ms) * 1e-3;
+            if (p.is_flux_internal) { lv.flux_time += double(ms) * 1e-3; lv.flux_launches++; }
+            free_events.push_back(p.start);
+            free_events.push_back(p.stop);
+        }
+        pending.clear();
+    }
+    struct Timed {
+        mgcfd_solver *s; EventPair p; bool on;
+        Timed(mgcfd_solver *s_, int level, int loop, bool flux_internal = false) : s(s_), on(s_->opt_timing != 0)
+        {
+            if (!on) return;
+            p = EventPair{s->get_event(), s->get_event(), level, loop, flux_internal};
+            HIP_CHECK(hipEventRecord(p.start, s->stream));
+        }
+        ~Timed()
+        {
+            if (!on) return;
+            (void)hipEventRecord(p.stop, s->stream);
+            s->pending.push_back(p);
+        }
+    };
+
+    // ---- operations ----------------------------------------------------------------------
+    void ensure_nodeq(DeviceLevel &lv)
+    {
+        if (!lv.nodeq_stale) return;
+        if (opt_exact) exact::launch_derive(stream, lv.info.nel, lv.variables, lv.nodeq);
+        else fast::launch_derive(stream, lv.info.nel, lv.variables, lv.nodeq);
+        lv.nodeq_stale = false;
+    }
+    void op_copy_old(int l)
+    {
+        DeviceLevel &lv = level(l);
+        HIP_CHECK(hipMemcpyAsync(lv.old_variables, lv.variables, sizeof(double) * 5 * lv.info.nel, hipMemcpyDeviceToDevice, stream));
+    }
+    void op_step_factor_local(int l)
+    {
+        DeviceLevel &lv = level(l);
+        HIP_CHECK(hipMemsetAsync(lv.min_bits, 0x7F, sizeof(unsigned long long), stream));
+        if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.variables, lv.cbrt_vol, lv.step_factors, lv.nodeq, lv.min_bits);
+        else fast::launch_step_factor_local(stream, lv.info.nel, lv.variables, lv.cbrt_vol, lv.step_factors, lv.nodeq, lv.min_bits);
+        lv.nodeq_stale = false;
+    }
+    void op_step_factor_apply(int l)
+    {
+        DeviceLevel &lv = level(l);
+        if (opt_exact) exact::launch_step_factor_apply(stream, lv.info.nel, lv.min_bits, lv.volumes, lv.step_factors);
+        else fast::launch_step_factor_apply(stream, lv.info.nel, lv.min_bits, lv.volumes, lv.step_factors);
+    }
+    void op_step_factor(int l)
+    {
+        DeviceLevel &lv = level(l);
+        Timed t(this, l, MGCFD_LOOP_COMPUTE_STEP);
+        if (mesh_variant == MGCFD_MESH_FVCORR) {
+            if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.variables, lv.volumes, lv.step_factors, lv.nodeq);
+            else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.variables, lv.volumes, lv.step_factors, lv.nodeq);
+            lv.nodeq_stale = false;
+        } else {
+            op_step_factor_local(l);
+            op_step_factor_apply(l);
+        }
+        lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;
+    }
+    // classes: bit0 internal, bit1 solid wall (-1), bit2 far field (-2)
+    void op_flux(int l, int classes)
+    {
+        DeviceLevel &lv = level(l);
+        ensure_nodeq(lv);
+        Timed t(this, l, MGCFD_LOOP_FLUX, (classes & 1) != 0);
+        if (opt_exact) exact::launch_flux_gather(stream, lv.dp, lv.nodeq, ff, lv.fluxes, classes, 1);
+        else fast::launch_flux_gather(stream, lv.dp, lv.nodeq, ff, lv.fluxes, classes, 1);
+        if (classes & 1) lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
+    }
+    void op_indirect_rw(int l)
+    {
+        DeviceLevel &lv = level(l);
+        ensure_nodeq(lv);
+        Timed t(this, l, MGCFD_LOOP_INDIRECT_RW);
+        if (opt_exact) exact::launch_indirect_rw(stream, lv.dp, lv.nodeq, lv.fluxes);
+        else fast::launch_indirect_rw(stream, lv.dp, lv.nodeq, lv.fluxes);
+        lv.iters[MGCFD_LOOP_INDIRECT_RW] += lv.info.n_internal;
+    }
+    void op_zero_fluxes(int l)
+    {
+        DeviceLevel &lv = level(l);
+        HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * lv.info.nel, stream));
+    }
+    void op_time_step(int l, int j)
+    {
+        if (j < 0 || j >= MGCFD_RK) throw std::invalid_argument("RK stage out of range");
+        DeviceLevel &lv = level(l);
+        Timed t(this, l, MGCFD_LOOP_TIME_STEP);
+        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.variables, lv.nodeq, lv.dp.old_of_new, err, opt_check);
+        else fast::launch_time_step(stream, lv.info.nel, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.variables, lv.nodeq, lv.dp.old_of_new, err, opt_check);
+        lv.nodeq_stale = false;
+        lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
+    }
+    void op_residual(int l)
+    {
+        DeviceLevel &lv = level(l);
+        if (opt_exact) exact::launch_residual(stream, lv.info.nel, lv.old_variables, lv.variables, lv.residuals);
+        else fast::launch_residual(stream, lv.info.nel, lv.old_variables, lv.variables, lv.residuals);
+    }
+    void op_sumsq(int l)
+    {
+        DeviceLevel &lv = level(l);
+        if (opt_exact) exact::launch_sumsq(stream, lv.info.nel * 5, lv.residuals, lv.partials, lv.n_partials, lv.sumsq);
+        else fast::launch_sumsq(stream, lv.info.nel * 5, lv.residuals, lv.partials, lv.n_partials, lv.sumsq);
+    }
+    void op_restrict(int fine)
+    {
+        DeviceLevel &F = level(fine);
+        DeviceLevel &C = level(fine + 1);
+        if (!F.has_transfer) throw std::invalid_argument("level has no multigrid map");
+        // Timer / iteration attribution quirk: the reference bumps `level` before the call,
+        // so restriction is booked to the COARSE level.
+        Timed t(this, fine + 1, MGCFD_LOOP_RESTRICT);
+        if (opt_exact) exact::launch_restrict(stream, C.info.nel, F.dp.child_ptr, F.dp.child, F.variables, C.variables);
+        else fast::launch_restrict(stream, C.info.nel, F.dp.child_ptr, F.dp.child, F.variables, C.variables);
+        C.nodeq_stale = true;
+        C.iters[MGCFD_LOOP_RESTRICT] += 2 * F.info.mgc + C.info.nel;   // mg_loops.cpp:61,117,172
+    }
+    void op_prolong(int fine)
+    {
+        DeviceLevel &F = level(fine);
+        DeviceLevel &C = level(fine + 1);
+        if (!F.has_transfer) throw std::invalid_argument("level has no multigrid map");
+        Timed t(this, fine, MGCFD_LOOP_PROLONG);
+        if (opt_exact) exact::launch_prolong(stream, F.dp, C.residuals, F.residuals, F.variables);
+        else fast::launch_prolong(stream, F.dp, C.residuals, F.residuals, F.variables);
+        F.nodeq_stale = true;
+        F.iters[MGCFD_LOOP_PROLONG] += F.info.n_internal + F.info.nel;  // mg_loops.cpp:728,842
+    }
+    int read_error(int64_t *bad_cell)
+    {
+        unsigned long long h = 0;
+        HIP_CHECK(hipMemcpyAsync(&h, err, sizeof(h), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (h == ~0ULL) return MGCFD_OK;
+        if (bad_cell) *bad_cell = static_cast<int64_t>(h >> 8);
+        HIP_CHECK(hipMemsetAsync(err, 0xFF, sizeof(unsigned long long), stream));
+        switch (h & 0xFF) {
+            case 1: return MGCFD_ERR_NAN;
+            case 2: return MGCFD_ERR_NEG_DENSITY;
+            default: return MGCFD_ERR_NEG_ENERGY;
+        }
+    }
+};
+
+mgcfd_solver::~mgcfd_solver()
+{
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto &p : pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+    for (auto e : free_events) (void)hipEventDestroy(e);
+    for (auto &lv : L) {
+        void *ptrs[] = {lv.variables, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
+                        lv.cbrt_vol, lv.nodeq, lv.min_bits, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
+                        lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.pro,
+                        lv.dp.pro_parent, lv.dp.pro_wsum};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+    }
+    if (err) (void)hipFree(err);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// construction
+// ------------------------------------------------------------------------------------------
+static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device)
+{
+    if (!levels || nlevels <= 0) throw std::invalid_argument("no levels given");
+    if (mesh_variant != MGCFD_MESH_FVCORR && mesh_variant != MGCFD_MESH_M6_WING &&
+        mesh_variant != MGCFD_MESH_LA_CASCADE && mesh_variant != MGCFD_MESH_ROTOR_37)
+        throw std::invalid_argument("unknown mesh variant");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        throw HipError("no HIP device available: libmgcfd_hip.so has no CPU fallback");
+    if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+
+    auto s = std::make_unique<mgcfd_solver>();
+    s->device = device;
+    s->mesh_variant = mesh_variant;
+    s->use_device();
+    HIP_CHECK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    s->stream = s->own_stream;
+    far_field_constants(s->ff17);
+    std::memcpy(s->ff.var, s->ff17, sizeof(double) * 5);
+    std::memcpy(s->ff.fc_mx, s->ff17 + 5, sizeof(double) * 3);
+    std::memcpy(s->ff.fc_my, s->ff17 + 8, sizeof(double) * 3);
+    std::memcpy(s->ff.fc_mz, s->ff17 + 11, sizeof(double) * 3);
+    std::memcpy(s->ff.fc_de, s->ff17 + 14, sizeof(double) * 3);
+    s->err = dev_alloc<unsigned long long>(1);
+    HIP_CHECK(hipMemset(s->err, 0xFF, sizeof(unsigned long long)));
+
+    s->L.resize(static_cast<size_t>(nlevels));
+    PlanOptions popt;
+    // host-side plans first (coarse permutations are needed by the fine level's transfer plan)
+    for (int l = 0; l < nlevels; l++) {
+        const mgcfd_level_desc &d = levels[l];
+        DeviceLevel &lv = s->L[static_cast<size_t>(l)];
+        if (!d.volumes || !d.edges) throw std::invalid_argument("level is missing volumes/edges");
+        if (d.internal_start < 0 || d.internal_start + d.n_internal > d.n_edges || d.boundary_start < 0 ||
+            d.boundary_start + d.n_boundary > d.n_edges || d.wall_start < 0 || d.wall_start + d.n_wall > d.n_edges)
+            throw std::invalid_argument("edge class ranges exceed n_edges");
+        lv.edges.assign(d.edges, d.edges + d.n_edges);
+        adjust_and_dampen(d, mesh_variant, lv.edges);
+        build_level_plan(d, lv.edges, popt, lv.plan);
+    }
+    for (int l = 0; l + 1 < nlevels; l++) {
+        const mgcfd_level_desc &d = levels[l];
+        if (!d.mg_map) throw std::invalid_argument("multigrid map missing between levels");
+        build_transfer_plan(d, s->L[static_cast<size_t>(l)].edges, levels[l + 1].coords, levels[l + 1].nel,
+                            s->L[static_cast<size_t>(l) + 1].plan.new_of_old, s->L[static_cast<size_t>(l)].plan);
+        s->L[static_cast<size_t>(l)].has_transfer = true;
+    }
+    // device upload
+    for (int l = 0; l < nlevels; l++) {
+        const mgcfd_level_desc &d = levels[l];
+        DeviceLevel &lv = s->L[static_cast<size_t>(l)];
+        lv.info = d;
+        lv.info.volumes = nullptr; lv.info.coords = nullptr; lv.info.edges = nullptr; lv.info.mg_map = nullptr;
+        const int64_t nel = d.nel;
+        const LevelPlan &P = lv.plan;
+        std::vector<double> vol(static_cast<size_t>(nel)), cb(static_cast<size_t>(nel));
+        for (int64_t n = 0; n < nel; n++) {
+            const double v = d.volumes[P.old_of_new[static_cast<size_t>(n)]];
+            vol[static_cast<size_t>(n)] = v;
+            cb[static_cast<size_t>(n)] = std::cbrt(v);        // cfd_loops.cpp:116, static => host libm once
+        }
+        lv.volumes = dev_upload(vol);
+        lv.cbrt_vol = dev_upload(cb);
+        lv.variables = dev_alloc<double>(static_cast<size_t>(nel) * 5);
+        lv.old_variables = dev_alloc<double>(static_cast<size_t>(nel) * 5);
+        lv.fluxes = dev_alloc<double>(static_cast<size_t>(nel) * 5);
+        lv.residuals = dev_alloc<double>(static_cast<size_t>(nel) * 5);
+        lv.step_factors = dev_alloc<double>(static_cast<size_t>(nel));
+        lv.nodeq = dev_alloc<NodeQ>(static_cast<size_t>(nel));
+        lv.min_bits = dev_alloc<unsigned long long>(1);
+        lv.sumsq = dev_alloc<double>(1);
+        lv.n_partials = static_cast<int>(std::min<int64_t>(1024, (nel * 5 + 255) / 256));
+        lv.partials = dev_alloc<double>(static_cast<size_t>(lv.n_partials));
+        lv.dp.nel = nel;
+        lv.dp.n_slices = P.n_slices;
+        lv.dp.slice_row0 = dev_upload(P.slice_row0);
+        lv.dp.rows_int = dev_upload(P.rows_int);
+        lv.dp.rows_bnd = dev_upload(P.rows_bnd);
+        lv.dp.nbr = dev_upload(P.nbr);
+        lv.dp.w = dev_upload(P.w);
+        lv.dp.old_of_new = dev_upload(P.old_of_new);
+        if (lv.has_transfer) {
+            lv.dp.child_ptr = dev_upload(P.child_ptr);
+            lv.dp.child = dev_upload(P.child);
+            lv.dp.pro = dev_upload(P.pro);
+            lv.dp.pro_parent = dev_upload(P.pro_parent);
+            lv.dp.pro_wsum = dev_upload(P.pro_wsum);
+            // the per-entry host copies are not needed again
+            lv.plan.pro.clear(); lv.plan.pro.shrink_to_fit();
+        }
+        lv.plan.nbr.clear(); lv.plan.nbr.shrink_to_fit();
+        lv.plan.w.clear(); lv.plan.w.shrink_to_fit();
+        // initial state: far field everywhere, fluxes/residuals/old/step factors zero
+        HIP_CHECK(hipMemsetAsync(lv.old_variables, 0, sizeof(double) * 5 * nel, s->stream));
+        HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * nel, s->stream));
+        HIP_CHECK(hipMemsetAsync(lv.residuals, 0, sizeof(double) * 5 * nel, s->stream));
+        HIP_CHECK(hipMemsetAsync(lv.step_factors, 0, sizeof(double) * nel, s->stream));
+        exact::launch_init_variables(s->stream, nel, s->ff, lv.variables, lv.nodeq);
+    }
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    HIP_CHECK(hipGetLastError());
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+template <typename F> static int guarded(F &&f)
+{
+    try {
+        f();
+        return MGCFD_OK;
+    } catch (const HipError &e) {
+        g_last_error = e.what();
+        return MGCFD_ERR_HIP;
+    } catch (const std::invalid_argument &e) {
+        g_last_error = e.what();
+        return MGCFD_ERR_ARG;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return MGCFD_ERR_IO;
+    }
+}
+
+#define REQUIRE(p) do { if (!(p)) { g_last_error = "null argument: " #p; return MGCFD_ERR_ARG; } } while (0)
+
+extern "C" {
+
+const char *mgcfd_last_error(void) { return g_last_error.c_str(); }
+int mgcfd_abi_version(void) { return 1; }
+
+// ---- file boundary ----
+int mgcfd_mesh_load(const char *input_dat, const char *directory, int duplicate, mgcfd_mesh **out)
+{
+    REQUIRE(input_dat); REQUIRE(out);
+    return guarded([&] {
+        auto m = std::make_unique<mgcfd_mesh>();
+        m->mesh = load_mesh(input_dat, directory ? directory : "", duplicate);
+        *out = m.release();
+    });
+}
+void mgcfd_mesh_free(mgcfd_mesh *m) { delete m; }
+int mgcfd_mesh_num_levels(const mgcfd_mesh *m) { return m ? static_cast<int>(m->mesh.levels.size()) : 0; }
+int mgcfd_mesh_variant(const mgcfd_mesh *m) { return m ? m->mesh.mesh_variant : -1; }
+int mgcfd_mesh_size(const mgcfd_mesh *m) { return m ? m->mesh.size : 0; }
+int mgcfd_mesh_level(const mgcfd_mesh *m, int level, mgcfd_level_desc *out)
+{
+    REQUIRE(m); REQUIRE(out);
+    if (level < 0 || level >= static_cast<int>(m->mesh.levels.size())) { g_last_error = "level out of range"; return MGCFD_ERR_ARG; }
+    *out = m->mesh.levels[static_cast<size_t>(level)].desc();
+    return MGCFD_OK;
+}
+int mgcfd_write_array(const char *path, const double *data, int64_t nel, int ncols)
+{
+    REQUIRE(path); REQUIRE(data);
+    return guarded([&] { write_array(path, data, nel, ncols); });
+}
+int mgcfd_identify_differences(const double *t, const double *m, int64_t nel, int mesh_variant, int64_t *first_bad)
+{
+    REQUIRE(t); REQUIRE(m);
+    const int64_t k = identify_differences(t, m, nel, mesh_variant);
+    if (first_bad) *first_bad = k;
+    if (k >= 0) { g_last_error = "Unacceptable error detected at flat index " + std::to_string(k); return MGCFD_ERR_VALIDATION; }
+    return MGCFD_OK;
+}
+
+// ---- life cycle ----
+int mgcfd_create(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device, mgcfd_solver **out)
+{
+    REQUIRE(out);
+    return guarded([&] { *out = build_solver(levels, nlevels, mesh_variant, device).release(); });
+}
+int mgcfd_create_from_mesh(const mgcfd_mesh *m, int device, mgcfd_solver **out)
+{
+    REQUIRE(m); REQUIRE(out);
+    return guarded([&] {
+        std::vector<mgcfd_level_desc> d;
+        for (auto &l : m->mesh.levels) d.push_back(l.desc());
+        *out = build_solver(d.data(), static_cast<int>(d.size()), m->mesh.mesh_variant, device).release();
+    });
+}
+void mgcfd_destroy(mgcfd_solver *s) { delete s; }
+
+int mgcfd_set_option(mgcfd_solver *s, int option, int value)
+{
+    REQUIRE(s);
+    return guarded([&] {
+        switch (option) {
+            case MGCFD_OPT_EXACT: s->opt_exact = value != 0; break;
+            case MGCFD_OPT_TIMING: s->use_device(); s->fold_events(); s->opt_timing = value != 0; break;
+            case MGCFD_OPT_INDIRECT_RW: s->opt_indirect_rw = value != 0; break;
+            case MGCFD_OPT_CHECK_INVALID: s->opt_check = value != 0; break;
+            case MGCFD_OPT_FLUX_VARIANT: s->opt_variant = value; break;
+            default: throw std::invalid_argument("unknown option");
+        }
+    });
+}
+int mgcfd_get_option(const mgcfd_solver *s, int option, int *value)
+{
+    REQUIRE(s); REQUIRE(value);
+    switch (option) {
+        case MGCFD_OPT_EXACT: *value = s->opt_exact; break;
+        case MGCFD_OPT_TIMING: *value = s->opt_timing; break;
+        case MGCFD_OPT_INDIRECT_RW: *value = s->opt_indirect_rw; break;
+        case MGCFD_OPT_CHECK_INVALID: *value = s->opt_check; break;
+        case MGCFD_OPT_FLUX_VARIANT: *value = s->opt_variant; break;
+        default: g_last_error = "unknown option"; return MGCFD_ERR_ARG;
+    }
+    return MGCFD_OK;
+}
+int mgcfd_set_stream(mgcfd_solver *s, void *hip_stream)
+{
+    REQUIRE(s);
+    return guarded([&] {
+        s->use_device();
+        s->fold_events();
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        s->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->own_stream;
+    });
+}
+int mgcfd_synchronize(mgcfd_solver *s)
+{
+    REQUIRE(s);
+    return guarded([&] { s->use_device(); HIP_CHECK(hipStreamSynchronize(s->stream)); HIP_CHECK(hipGetLastError()); });
+}
+int mgcfd_num_levels(const mgcfd_solver *s) { return s ? static_cast<int>(s->L.size()) : 0; }
+int64_t mgcfd_level_nel(const mgcfd_solver *s, int l)
+{ return (s && l >= 0 && l < static_cast<int>(s->L.size())) ? s->L[static_cast<size_t>(l)].info.nel : -1; }
+int64_t mgcfd_level_num_internal_edges(const mgcfd_solver *s, int l)
+{ return (s && l >= 0 && l < static_cast<int>(s->L.size())) ? s->L[static_cast<size_t>(l)].info.n_internal : -1; }
+int mgcfd_get_far_field(const mgcfd_solver *s, double *out17)
+{
+    REQUIRE(s); REQUIRE(out17);
+    std::memcpy(out17, s->ff17, sizeof(double) * 17);
+    return MGCFD_OK;
+}
+
+// ---- kernel-granular operations ----
+#define OP(body) REQUIRE(s); return guarded([&] { s->use_device(); body; })
+int mgcfd_copy_old_variables(mgcfd_solver *s, int level) { OP(s->op_copy_old(level)); }
+int mgcfd_compute_step_factor(mgcfd_solver *s, int level) { OP(s->op_step_factor(level)); }
+int mgcfd_compute_flux_edge(mgcfd_solver *s, int level) { OP(s->op_flux(level, 1)); }
+int mgcfd_compute_boundary_flux_edge(mgcfd_solver *s, int level) { OP(s->op_flux(level, 2)); }
+int mgcfd_compute_wall_flux_edge(mgcfd_solver *s, int level) { OP(s->op_flux(level, 4)); }
+int mgcfd_compute_fluxes(mgcfd_solver *s, int level) { OP(s->op_flux(level, 7)); }
+int mgcfd_time_step(mgcfd_solver *s, int level, int j) { OP(s->op_time_step(level, j)); }
+int mgcfd_zero_fluxes(mgcfd_solver *s, int level) { OP(s->op_zero_fluxes(level)); }
+int mgcfd_indirect_rw(mgcfd_solver *s, int level) { OP(s->op_indirect_rw(level)); }
+int mgcfd_residual(mgcfd_solver *s, int level) { OP(s->op_residual(level)); }
+int mgcfd_restrict(mgcfd_solver *s, int fine_level) { OP(s->op_restrict(fine_level)); }
+int mgcfd_prolong(mgcfd_solver *s, int fine_level) { OP(s->op_prolong(fine_level)); }
+int mgcfd_step_factor_local(mgcfd_solver *s, int level)
+{
+    OP({
+        if (s->mesh_variant == MGCFD_MESH_FVCORR) throw std::invalid_argument("fvcorr uses a local time step: nothing to reduce");
+        s->op_step_factor_local(level);
+        s->level(level).iters[MGCFD_LOOP_COMPUTE_STEP] += s->level(level).info.nel;
+    });
+}
+int mgcfd_step_factor_min_devptr(mgcfd_solver *s, int level, void **devptr)
+{ REQUIRE(devptr); OP(*devptr = s->level(level).min_bits); }
+int mgcfd_step_factor_apply(mgcfd_solver *s, int level) { OP(s->op_step_factor_apply(level)); }
+int mgcfd_residual_sumsq(mgcfd_solver *s, int level, void **devptr)
+{ REQUIRE(devptr); OP({ s->op_sumsq(level); *devptr = s->level(level).sumsq; }); }
+
+int mgcfd_calc_rms(mgcfd_solver *s, int level, double *rms)
+{
+    REQUIRE(s); REQUIRE(rms);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        s->op_sumsq(level);
+        double sum = 0.0;
+        HIP_CHECK(hipMemcpyAsync(&sum, lv.sumsq, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        *rms = std::sqrt(sum / double(lv.info.nel));
+    });
+}
+int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_cell)
+{
+    REQUIRE(s);
+    int code = MGCFD_OK;
+    int rc = guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        exact::launch_check_invalid(s->stream, lv.info.nel, lv.variables, lv.dp.old_of_new, s->err);
+        code = s->read_error(bad_cell);
+    });
+    if (rc != MGCFD_OK) return rc;
+    if (code != MGCFD_OK) g_last_error = "invalid variables detected";
+    return code;
+}
+
+// ---- cycle driver: src/euler3d_cpu_double.cpp:371-694 ----
+int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
+{
+    REQUIRE(s);
+    int code = MGCFD_OK;
+    int rc = guarded([&] {
+        s->use_device();
+        const int nlevels = static_cast<int>(s->L.size());
+        double *rms_dev = cycles > 0 ? dev_alloc<double>(static_cast<size_t>(cycles)) : nullptr;
+        int level = 0;
+        bool going_up = true;
+        for (int cyc = 0; cyc < cycles;) {
+            s->op_copy_old(level);                                         // :383
+            s->op_step_factor(level);                                      // :388-395
+            for (int j = 0; j < MGCFD_RK; j++) {                           // :397-506
+                s->op_flux(level, 1);
+                s->op_flux(level, 2);
+                s->op_flux(level, 4);
+                s->op_time_step(level, j);
+                if (s->opt_indirect_rw) { s->op_indirect_rw(level); s->op_zero_fluxes(level); }
+            }
+            s->op_residual(level);                                         // :508
+            if (level == 0) {                                              // :509-512
+                s->op_sumsq(0);
+                HIP_CHECK(hipMemcpyAsync(rms_dev + cyc, s->L[0].sumsq, sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+            }
+            if (nlevels <= 1) { cyc++; continue; }
+            if (going_up) {                                                // :527-559
+                level++;
+                s->op_restrict(level - 1);
+                if (level == nlevels - 1) going_up = false;
+            } else {                                                       // :560-688
+                level--;
+                s->op_prolong(level);
+                if (level == 0) { going_up = true; cyc++; }
+            }
+        }
+        std::vector<double> sums(static_cast<size_t>(cycles > 0 ? cycles : 0));
+        if (cycles > 0) HIP_CHECK(hipMemcpyAsync(sums.data(), rms_dev, sizeof(double) * cycles, hipMemcpyDeviceToHost, s->stream));
+        code = s->read_error(nullptr);                                     // synchronises
+        if (rms_dev) HIP_CHECK(hipFree(rms_dev));
+        if (rms_out)
+            for (int c = 0; c < cycles; c++) rms_out[c] = std::sqrt(sums[static_cast<size_t>(c)] / double(s->L[0].info.nel));
+        HIP_CHECK(hipGetLastError());
+    });
+    if (rc != MGCFD_OK) return rc;
+    if (code != MGCFD_OK) g_last_error = "check_for_invalid_variables: invalid state during the cycles";
+    return code;
+}
+
+// ---- state access ----
+static double *array_ptr(DeviceLevel &lv, int which, int *ncols)
+{
+    *ncols = 5;
+    switch (which) {
+        case MGCFD_ARR_VARIABLES: return lv.variables;
+        case MGCFD_ARR_OLD_VARIABLES: return lv.old_variables;
+        case MGCFD_ARR_FLUXES: return lv.fluxes;
+        case MGCFD_ARR_RESIDUALS: return lv.residuals;
+        case MGCFD_ARR_STEP_FACTORS: *ncols = 1; return lv.step_factors;
+        case MGCFD_ARR_VOLUMES: *ncols = 1; return lv.volumes;
+        default: throw std::invalid_argument("unknown array id");
+    }
+}
+int mgcfd_get_array(mgcfd_solver *s, int level, int which, double *out)
+{
+    REQUIRE(s); REQUIRE(out);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        int nc = 0;
+        double *src = array_ptr(lv, which, &nc);
+        std::vector<double> tmp(static_cast<size_t>(lv.info.nel) * nc);
+        HIP_CHECK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        for (int64_t n = 0; n < lv.info.nel; n++) {
+            const int64_t o = lv.plan.old_of_new[static_cast<size_t>(n)];
+            for (int c = 0; c < nc; c++) out[o * nc + c] = tmp[static_cast<size_t>(n * nc + c)];
+        }
+    });
+}
+int mgcfd_set_array(mgcfd_solver *s, int level, int which, const double *in)
+{
+    REQUIRE(s); REQUIRE(in);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        int nc = 0;
+        double *dst = array_ptr(lv, which, &nc);
+        if (which == MGCFD_ARR_VOLUMES) throw std::invalid_argument("volumes are fixed at creation");
+        std::vector<double> tmp(static_cast<size_t>(lv.info.nel) * nc);
+        for (int64_t n = 0; n < lv.info.nel; n++) {
+            const int64_t o = lv.plan.old_of_new[static_cast<size_t>(n)];
+            for (int c = 0; c < nc; c++) tmp[static_cast<size_t>(n * nc + c)] = in[o * nc + c];
+        }
+        HIP_CHECK(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        if (which == MGCFD_ARR_VARIABLES) lv.nodeq_stale = true;
+    });
+}
+int mgcfd_get_edges(mgcfd_solver *s, int level, mgcfd_edge *out)
+{
+    REQUIRE(s); REQUIRE(out);
+    return guarded([&] {
+        DeviceLevel &lv = s->level(level);
+        std::memcpy(out, lv.edges.data(), lv.edges.size() * sizeof(mgcfd_edge));
+    });
+}
+
+// ---- monitoring ----
+int mgcfd_get_loop_iters(const mgcfd_solver *s, int level, int64_t out[MGCFD_NUM_LOOPS])
+{
+    REQUIRE(s); REQUIRE(out);
+    if (level < 0 || level >= static_cast<int>(s->L.size())) { g_last_error = "level out of range"; return MGCFD_ERR_ARG; }
+    std::memcpy(out, s->L[static_cast<size_t>(level)].iters, sizeof(int64_t) * MGCFD_NUM_LOOPS);
+    return MGCFD_OK;
+}
+int mgcfd_get_loop_times(mgcfd_solver *s, int level, double out[MGCFD_NUM_LOOPS])
+{
+    REQUIRE(s); REQUIRE(out);
+    return guarded([&] {
+        s->use_device();
+        s->fold_events();
+        std::memcpy(out, s->level(level).times, sizeof(double) * MGCFD_NUM_LOOPS);
+    });
+}
+int mgcfd_reset_monitoring(mgcfd_solver *s)
+{
+    REQUIRE(s);
+    return guarded([&] {
+        s->use_device();
+        s->fold_events();
+        for (auto &lv : s->L) {
+            std::memset(lv.iters, 0, sizeof(lv.iters));
+            std::memset(lv.times, 0, sizeof(lv.times));
+            lv.flux_time = 0.0;
+            lv.flux_launches = 0;
+        }
+    });
+}
+int mgcfd_get_flux_kernel_time(mgcfd_solver *s, int level, double *avg_seconds, int64_t *launches)
+{
+    REQUIRE(s); REQUIRE(avg_seconds); REQUIRE(launches);
+    return guarded([&] {
+        s->use_device();
+        s->fold_events();
+        DeviceLevel &lv = s->level(level);
+        *launches = lv.flux_launches;
+        *avg_seconds = lv.flux_launches ? lv.flux_time / double(lv.flux_launches) : 0.0;
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,361 @@
+"""ctypes binding of libmgcfd_hip.so (include/mgcfd.h).
+
+The Python layer is plumbing for tests, bench.py and torch.distributed — the product is
+the HIP library.  There is no CPU fallback: if the shared object is missing or no GPU is
+present, construction of a :class:`Solver` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .meshgen import EDGE_DTYPE, LevelMesh, MultigridMesh, to_edge_arrays
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.normpath(os.path.join(PKG_DIR, "..", "csrc"))
+LIB_PATH = os.path.join(CSRC_DIR, "libmgcfd_hip.so")
+
+NVAR = 5
+RK = 3
+LOOPS = ("flux", "update", "compute_step", "time_step", "restrict", "prolong", "indirect_rw")
+ARR = {"variables": 0, "old_variables": 1, "fluxes": 2, "residuals": 3, "step_factors": 4, "volumes": 5}
+OPT = {"exact": 0, "timing": 1, "indirect_rw": 2, "check_invalid": 3, "flux_variant": 4}
+ERR_NAMES = {0: "OK", 1: "ERR_ARG", 2: "ERR_IO", 3: "ERR_HIP", 4: "ERR_NAN", 5: "ERR_NEG_DENSITY",
+             6: "ERR_NEG_ENERGY", 7: "ERR_VALIDATION"}
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+
+class LevelDesc(C.Structure):
+    _fields_ = [("nel", _i64), ("n_edges", _i64), ("n_internal", _i64), ("n_boundary", _i64),
+                ("n_wall", _i64), ("internal_start", _i64), ("boundary_start", _i64), ("wall_start", _i64),
+                ("volumes", _vp), ("coords", _vp), ("edges", _vp), ("mg_map", _vp), ("mgc", _i64)]
+
+
+class MgcfdError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+# Every symbol include/mgcfd.h declares: (name, restype, argtypes)
+_SIGNATURES = [
+    ("mgcfd_last_error", C.c_char_p, []),
+    ("mgcfd_abi_version", C.c_int, []),
+    ("mgcfd_mesh_load", C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    ("mgcfd_mesh_free", None, [_vp]),
+    ("mgcfd_mesh_num_levels", C.c_int, [_vp]),
+    ("mgcfd_mesh_variant", C.c_int, [_vp]),
+    ("mgcfd_mesh_size", C.c_int, [_vp]),
+    ("mgcfd_mesh_level", C.c_int, [_vp, C.c_int, C.POINTER(LevelDesc)]),
+    ("mgcfd_write_array", C.c_int, [C.c_char_p, _vp, _i64, C.c_int]),
+    ("mgcfd_identify_differences", C.c_int, [_vp, _vp, _i64, C.c_int, C.POINTER(_i64)]),
+    ("mgcfd_create", C.c_int, [C.POINTER(LevelDesc), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("mgcfd_create_from_mesh", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    ("mgcfd_destroy", None, [_vp]),
+    ("mgcfd_set_option", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("mgcfd_get_option", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    ("mgcfd_set_stream", C.c_int, [_vp, _vp]),
+    ("mgcfd_synchronize", C.c_int, [_vp]),
+    ("mgcfd_num_levels", C.c_int, [_vp]),
+    ("mgcfd_level_nel", _i64, [_vp, C.c_int]),
+    ("mgcfd_level_num_internal_edges", _i64, [_vp, C.c_int]),
+    ("mgcfd_get_far_field", C.c_int, [_vp, _vp]),
+    ("mgcfd_copy_old_variables", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_compute_step_factor", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_compute_flux_edge", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_compute_boundary_flux_edge", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_compute_wall_flux_edge", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_compute_fluxes", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_time_step", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("mgcfd_zero_fluxes", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_indirect_rw", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_residual", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_calc_rms", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
+    ("mgcfd_check_for_invalid_variables", C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
+    ("mgcfd_restrict", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_prolong", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_run_cycles", C.c_int, [_vp, C.c_int, _vp]),
+    ("mgcfd_get_array", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    ("mgcfd_set_array", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    ("mgcfd_get_edges", C.c_int, [_vp, C.c_int, _vp]),
+    ("mgcfd_get_loop_iters", C.c_int, [_vp, C.c_int, _vp]),
+    ("mgcfd_get_loop_times", C.c_int, [_vp, C.c_int, _vp]),
+    ("mgcfd_reset_monitoring", C.c_int, [_vp]),
+    ("mgcfd_get_flux_kernel_time", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    ("mgcfd_step_factor_local", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_step_factor_min_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    ("mgcfd_step_factor_apply", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_residual_sumsq", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+]
+EXPORTED_SYMBOLS = tuple(name for name, _, _ in _SIGNATURES)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load libmgcfd_hip.so and type every entry point.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} not found: build it with `make -C {CSRC_DIR}` "
+                                f"(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(p)
+    for name, res, args in _SIGNATURES:
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc: int):
+    if rc != 0:
+        raise MgcfdError(rc, (lib.mgcfd_last_error() or b"").decode(errors="replace"))
+
+
+def _ptr(a: np.ndarray):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_vp)
+
+
+class Mesh:
+    """Multigrid input parsed by the library's own readers (the reference's file formats)."""
+
+    def __init__(self, input_dat: str, directory: str = "", duplicate: int = 1):
+        self.lib = load_library()
+        h = _vp()
+        _check(self.lib, self.lib.mgcfd_mesh_load(input_dat.encode(), directory.encode(), duplicate, C.byref(h)))
+        self.handle = h
+
+    @property
+    def num_levels(self) -> int:
+        return self.lib.mgcfd_mesh_num_levels(self.handle)
+
+    @property
+    def variant(self) -> int:
+        return self.lib.mgcfd_mesh_variant(self.handle)
+
+    @property
+    def size(self) -> int:
+        return self.lib.mgcfd_mesh_size(self.handle)
+
+    def level(self, l: int) -> dict:
+        d = LevelDesc()
+        _check(self.lib, self.lib.mgcfd_mesh_level(self.handle, l, C.byref(d)))
+
+        def view(addr, n, dt):
+            if not addr or n == 0:
+                return np.zeros(0, dtype=dt)
+            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(addr)
+            return np.frombuffer(buf, dtype=dt, count=n).copy()
+
+        return {"nel": d.nel, "n_edges": d.n_edges, "n_internal": d.n_internal, "n_boundary": d.n_boundary,
+                "n_wall": d.n_wall, "internal_start": d.internal_start, "boundary_start": d.boundary_start,
+                "wall_start": d.wall_start, "volumes": view(d.volumes, d.nel, np.float64),
+                "coords": view(d.coords, d.nel * 3, np.float64).reshape(-1, 3),
+                "edges": view(d.edges, d.n_edges, EDGE_DTYPE), "mg_map": view(d.mg_map, d.mgc, np.int64)}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mgcfd_mesh_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Solver:
+    """Device-resident solver.  Construct from a :class:`Mesh`, from a generated
+    :class:`~mgcfd.meshgen.MultigridMesh`, or from raw per-level arrays."""
+
+    def __init__(self, handle, lib):
+        self.handle = handle
+        self.lib = lib
+        self._keep = None
+
+    # ---- constructors ----
+    @classmethod
+    def from_mesh(cls, mesh: Mesh, device: int = 0) -> "Solver":
+        lib = load_library()
+        h = _vp()
+        _check(lib, lib.mgcfd_create_from_mesh(mesh.handle, device, C.byref(h)))
+        return cls(h, lib)
+
+    @classmethod
+    def from_arrays(cls, levels: Sequence[dict], mesh_variant: int, device: int = 0) -> "Solver":
+        """levels[l] = dict(nel, volumes, coords|None, edges[EDGE_DTYPE], n_internal, n_boundary, n_wall,
+        mg_map|None) — the reference's read_grid()/read_mg_connectivity() outputs."""
+        lib = load_library()
+        descs = (LevelDesc * len(levels))()
+        keep = []
+        for l, L in enumerate(levels):
+            vol = np.ascontiguousarray(L["volumes"], dtype=np.float64)
+            edges = np.ascontiguousarray(L["edges"], dtype=EDGE_DTYPE)
+            crd = None if L.get("coords") is None else np.ascontiguousarray(L["coords"], dtype=np.float64)
+            mp = None if L.get("mg_map") is None else np.ascontiguousarray(L["mg_map"], dtype=np.int64)
+            keep += [vol, edges, crd, mp]
+            d = descs[l]
+            d.nel = int(L["nel"])
+            d.n_edges = len(edges)
+            d.n_internal, d.n_boundary, d.n_wall = int(L["n_internal"]), int(L["n_boundary"]), int(L["n_wall"])
+            d.internal_start = int(L.get("internal_start", 0))
+            d.boundary_start = int(L.get("boundary_start", d.n_internal))
+            d.wall_start = int(L.get("wall_start", d.n_internal + d.n_boundary))
+            d.volumes = _ptr(vol)
+            d.coords = _ptr(crd) if crd is not None else None
+            d.edges = _ptr(edges)
+            d.mg_map = _ptr(mp) if mp is not None else None
+            d.mgc = len(mp) if mp is not None else 0
+        h = _vp()
+        _check(lib, lib.mgcfd_create(descs, len(levels), mesh_variant, device, C.byref(h)))
+        return cls(h, lib)
+
+    @classmethod
+    def from_generated(cls, mg: MultigridMesh, device: int = 0) -> "Solver":
+        return cls.from_arrays(generated_to_levels(mg), mg.mesh_variant, device)
+
+    # ---- plumbing ----
+    def _c(self, rc):
+        _check(self.lib, rc)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mgcfd_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name: str, value: int):
+        self._c(self.lib.mgcfd_set_option(self.handle, OPT[name], int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        self._c(self.lib.mgcfd_get_option(self.handle, OPT[name], C.byref(v)))
+        return v.value
+
+    def set_stream(self, stream_handle: Optional[int]):
+        self._c(self.lib.mgcfd_set_stream(self.handle, _vp(stream_handle) if stream_handle else None))
+
+    def synchronize(self):
+        self._c(self.lib.mgcfd_synchronize(self.handle))
+
+    @property
+    def num_levels(self) -> int:
+        return self.lib.mgcfd_num_levels(self.handle)
+
+    def nel(self, l: int) -> int:
+        return self.lib.mgcfd_level_nel(self.handle, l)
+
+    def num_internal_edges(self, l: int) -> int:
+        return self.lib.mgcfd_level_num_internal_edges(self.handle, l)
+
+    def far_field(self) -> np.ndarray:
+        out = np.zeros(17)
+        self._c(self.lib.mgcfd_get_far_field(self.handle, _ptr(out)))
+        return out
+
+    # ---- the reference's kernel set ----
+    def copy_old_variables(self, l): self._c(self.lib.mgcfd_copy_old_variables(self.handle, l))
+    def compute_step_factor(self, l): self._c(self.lib.mgcfd_compute_step_factor(self.handle, l))
+    def compute_flux_edge(self, l): self._c(self.lib.mgcfd_compute_flux_edge(self.handle, l))
+    def compute_boundary_flux_edge(self, l): self._c(self.lib.mgcfd_compute_boundary_flux_edge(self.handle, l))
+    def compute_wall_flux_edge(self, l): self._c(self.lib.mgcfd_compute_wall_flux_edge(self.handle, l))
+    def compute_fluxes(self, l): self._c(self.lib.mgcfd_compute_fluxes(self.handle, l))
+    def time_step(self, l, j): self._c(self.lib.mgcfd_time_step(self.handle, l, j))
+    def zero_fluxes(self, l): self._c(self.lib.mgcfd_zero_fluxes(self.handle, l))
+    def indirect_rw(self, l): self._c(self.lib.mgcfd_indirect_rw(self.handle, l))
+    def residual(self, l): self._c(self.lib.mgcfd_residual(self.handle, l))
+    def restrict(self, fine): self._c(self.lib.mgcfd_restrict(self.handle, fine))
+    def prolong(self, fine): self._c(self.lib.mgcfd_prolong(self.handle, fine))
+
+    def calc_rms(self, l) -> float:
+        v = C.c_double()
+        self._c(self.lib.mgcfd_calc_rms(self.handle, l, C.byref(v)))
+        return v.value
+
+    def check_for_invalid_variables(self, l):
+        bad = _i64(-1)
+        rc = self.lib.mgcfd_check_for_invalid_variables(self.handle, l, C.byref(bad))
+        return rc, bad.value
+
+    def run_cycles(self, cycles: int) -> np.ndarray:
+        rms = np.zeros(max(cycles, 1))
+        self._c(self.lib.mgcfd_run_cycles(self.handle, cycles, _ptr(rms)))
+        return rms[:cycles]
+
+    # ---- state ----
+    def get(self, l: int, name: str) -> np.ndarray:
+        ncols = 1 if name in ("step_factors", "volumes") else NVAR
+        out = np.zeros(self.nel(l) * ncols)
+        self._c(self.lib.mgcfd_get_array(self.handle, l, ARR[name], _ptr(out)))
+        return out.reshape(-1, ncols) if ncols > 1 else out
+
+    def set(self, l: int, name: str, values: np.ndarray):
+        a = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        ncols = 1 if name in ("step_factors", "volumes") else NVAR
+        assert a.size == self.nel(l) * ncols
+        self._c(self.lib.mgcfd_set_array(self.handle, l, ARR[name], _ptr(a)))
+
+    def get_edges(self, l: int, n_edges: int) -> np.ndarray:
+        out = np.zeros(n_edges, dtype=EDGE_DTYPE)
+        self._c(self.lib.mgcfd_get_edges(self.handle, l, _ptr(out)))
+        return out
+
+    # ---- monitoring ----
+    def loop_iters(self, l: int) -> dict:
+        out = np.zeros(len(LOOPS), dtype=np.int64)
+        self._c(self.lib.mgcfd_get_loop_iters(self.handle, l, _ptr(out)))
+        return dict(zip(LOOPS, out.tolist()))
+
+    def loop_times(self, l: int) -> dict:
+        out = np.zeros(len(LOOPS))
+        self._c(self.lib.mgcfd_get_loop_times(self.handle, l, _ptr(out)))
+        return dict(zip(LOOPS, out.tolist()))
+
+    def reset_monitoring(self):
+        self._c(self.lib.mgcfd_reset_monitoring(self.handle))
+
+    def flux_kernel_time(self, l: int):
+        t = C.c_double()
+        n = _i64()
+        self._c(self.lib.mgcfd_get_flux_kernel_time(self.handle, l, C.byref(t), C.byref(n)))
+        return t.value, n.value
+
+    # ---- multi-GPU hooks ----
+    def step_factor_local(self, l): self._c(self.lib.mgcfd_step_factor_local(self.handle, l))
+    def step_factor_apply(self, l): self._c(self.lib.mgcfd_step_factor_apply(self.handle, l))
+
+    def step_factor_min_devptr(self, l) -> int:
+        p = _vp()
+        self._c(self.lib.mgcfd_step_factor_min_devptr(self.handle, l, C.byref(p)))
+        return p.value
+
+    def residual_sumsq_devptr(self, l) -> int:
+        p = _vp()
+        self._c(self.lib.mgcfd_residual_sumsq(self.handle, l, C.byref(p)))
+        return p.value
+
+
+def generated_to_levels(mg: MultigridMesh) -> List[dict]:
+    """Turn a generated mesh into read_grid()-shaped per-level dicts without touching disk."""
+    out = []
+    for lvl in mg.levels:
+        edges, ni, nb, nw = to_edge_arrays(lvl, mg.mesh_variant)
+        out.append({"nel": lvl.nel, "volumes": lvl.volumes, "coords": lvl.coords, "edges": edges,
+                    "n_internal": ni, "n_boundary": nb, "n_wall": nw, "mg_map": lvl.mg_map})
+    return out

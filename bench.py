@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py — MG-CFD hot path on MI355X: Medges/s of the edge-flux sweep.
+
+Contract (one JSON line on rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): "Onera-M6 L0 only, flux+update kernels only, no MG".
+The dataset release is not available, so the M6-L0-like synthetic mesh of SURVEY.md §8d cfg2
+is used: a 67^3 jittered lattice (300,763 nodes / 888,822 internal edges) with randomly
+permuted node ids, mesh_name = m6wing (adjust + dampen 5e-8), state = far field with +-1 %
+uniform noise (seed 1234).  One STEP = one smoothing sweep on that level, exactly the
+per-level body of the reference's cycle loop (src/euler3d_cpu_double.cpp:383-508):
+  copy old <- variables; compute_step_factor; 3 x [compute_flux_edge + boundary + wall fluxes,
+  time_step]; residual.
+value = internal edges pushed through compute_flux_edge (3 per step per rank) / wall time of
+the K timed steps, max over ranks, summed over ranks (weak scaling: every rank owns one mesh
+copy, coupled through the global-min time step exactly like the reference's -m duplication:
+one all-reduce(MIN) of one fp64 per sweep over RCCL).
+
+roofline: the flux gather kernel, ALGORITHMIC bytes 40*E + 80*N per launch
+over its mean duration measured with hipEvents on the launch stream, against 8 TB/s.
+cpu_baseline: the reference's own compute_flux_edge (oracle/_ref, built from the reference
+sources) — or the C oracle port when that build is absent — timed on one host core on the
+same mesh for a bounded number of passes.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+LATTICE = 67                 # 67^3 = 300,763 nodes, 888,822 internal edges
+
+
+def build_workload(lattice: int, seed: int = 0):
+    from mgcfd import meshgen, generated_to_levels
+    mg = meshgen.make_multigrid((lattice,), "m6wing", seed=seed, jitter=0.2, area_noise=0.02,
+                                volume_noise=0.02, permute=True)
+    return mg, generated_to_levels(mg)
+
+
+def perturbed_state(nel, ff_var, seed=1234, amplitude=0.01):
+    rng = np.random.default_rng(seed)
+    base = np.tile(np.asarray(ff_var, dtype=np.float64), (nel, 1))
+    return base * (1.0 + amplitude * rng.uniform(-1.0, 1.0, base.shape))
+
+
+class _DevScalar:
+    """Zero-copy view of an fp64 device scalar owned by the library, for torch/RCCL."""
+
+    def __init__(self, ptr):
+        self.__cuda_array_interface__ = {"shape": (1,), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def cpu_baseline(levels, sample_seconds: float):
+    """Time compute_flux_edge on ONE host core for a bounded number of passes."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    L = levels[0]
+    edges = np.ascontiguousarray(L["edges"]).copy()
+    # same edge-weight preconditioning the solver applies (validation.cpp:28-75)
+    lib = O.load(native=True)
+    coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+    lib.ora_adjust_ewt(O.ptr(coords), len(edges), O.ptr(edges))
+    lib.ora_dampen_ewt(len(edges), O.ptr(edges), 5e-8)
+    ff = O.farfield()
+    q = perturbed_state(L["nel"], ff.var)
+    f = np.zeros_like(q)
+    n_int = int(L["n_internal"])
+    if O.have_reference():
+        ref = O.load_reference()
+        ref.ref_init(1, 2)
+        fn = lambda: ref.ref_compute_flux_edge(0, n_int, O.ptr(edges), O.ptr(q), O.ptr(f))
+        kind = "reference"
+        how = "reference compute_flux_edge (src/Kernels/flux_loops.cpp:78-153) built by oracle/build_ref.sh, g++ -O3 -fno-fast-math -ffp-contract=off"
+    else:
+        fn = lambda: lib.ora_compute_flux_edge(0, n_int, O.ptr(edges), O.ptr(q), O.ptr(f))
+        kind = "port"
+        how = "oracle/mgcfd_oracle.c ora_compute_flux_edge, gcc -O3 -fno-fast-math -march=native"
+    fn()
+    t0 = time.perf_counter()
+    fn()
+    one = time.perf_counter() - t0
+    passes = max(3, int(sample_seconds / max(one, 1e-6)))
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        fn()
+    dt = time.perf_counter() - t0
+    return {"value": round(n_int * passes / dt / 1e6, 3), "unit": "Medges/s", "cores": 1, "kind": kind,
+            "sample": f"{passes} passes of compute_flux_edge over the same {n_int}-edge level ({dt:.1f} s), {how}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--lattice", type=int, default=LATTICE, help="nodes per side of the synthetic M6-L0-like level")
+    ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (0 disables)")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MG-CFD HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    import mgcfd
+    mg, levels = build_workload(args.lattice)
+    solver = mgcfd.Solver.from_arrays(levels, mg.mesh_variant, device=local_rank)
+    stream = torch.cuda.current_stream()
+    solver.set_stream(stream.cuda_stream)
+    solver.set_option("exact", 0 if args.fast else 1)
+    nel, n_int = solver.nel(0), solver.num_internal_edges(0)
+    solver.set(0, "variables", perturbed_state(nel, solver.far_field()[:5]))
+
+    min_view = None
+    if world > 1:
+        min_view = torch.as_tensor(_DevScalar(solver.step_factor_min_devptr(0)), device=torch.device("cuda", local_rank))
+
+    def step():
+        if world == 1:
+            solver.smooth(0, 1)
+            return
+        # same sweep, with the global-min time step reduced over all ranks' mesh copies
+        solver.copy_old_variables(0)
+        solver.step_factor_local(0)
+        dist.all_reduce(min_view, op=dist.ReduceOp.MIN)
+        solver.step_factor_apply(0)
+        for j in range(3):
+            solver.compute_fluxes(0)
+            solver.time_step(0, j)
+        solver.residual(0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    solver.reset_monitoring()
+    solver.set_option("timing", 2)            # hipEvent pairs around the flux launches only
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    flux_avg, flux_launches = solver.flux_kernel_time(0)
+    solver.set_option("timing", 0)
+    rc, bad = solver.check_for_invalid_variables(0)
+    if rc != 0:
+        raise SystemExit(f"state became invalid during the bench (code {rc}, cell {bad})")
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        edges_total = 3 * n_int * args.steps * world
+        algo_bytes = 40 * n_int + 80 * nel
+        achieved = algo_bytes / flux_avg / 1e9 if flux_avg > 0 else 0.0
+        out = {
+            "metric": "Medges/s (compute_flux_edge)",
+            "value": round(edges_total / elapsed / 1e6, 3),
+            "unit": "Medges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"M6-L0-like synthetic level ({args.lattice}^3 jittered lattice, permuted ids): "
+                                   f"{nel} nodes / {n_int} internal edges per GPU, flux + update sweep, no MG",
+                       "step": "copy, compute_step_factor, 3 x (fluxes, time_step), residual",
+                       "numerics": "fast (FMA contraction)" if args.fast else "exact (bit-identical to the reference)",
+                       "parallelism": f"{world} mesh copies, all-reduce(min dt) per sweep" if world > 1 else "1 GPU"},
+            "flux_kernel_medges_per_s": round(n_int / flux_avg / 1e6, 1) if flux_avg > 0 else None,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_flux_gather", "launches": flux_launches,
+                         "avg_kernel_us": round(flux_avg * 1e6, 3), "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(levels, args.cpu_seconds)
+        print(json.dumps(out))
+    solver.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,7 @@ enum {
     MGCFD_OPT_EXACT = 0,       /* 1 (default): kernels compiled without FMA contraction and summing in the
                                   reference's order => bit-identical to the reference built with
                                   -ffp-contract=off.  0: contraction allowed (faster, ~1e-16 relative). */
-    MGCFD_OPT_TIMING = 1,      /* 1: bracket every loop with hipEvents and accumulate Times.csv columns */
+    MGCFD_OPT_TIMING = 1,      /* 1: bracket every loop with hipEvents (Times.csv columns); 2: only the flux launches */
     MGCFD_OPT_INDIRECT_RW = 2, /* 1: also run the indirect_rw probe each RK stage, as the reference's main() does */
     MGCFD_OPT_CHECK_INVALID = 3, /* 1 (default): NaN / negativity check every RK stage (validation.cpp:107-138) */
     MGCFD_OPT_FLUX_VARIANT = 4 /* 0 (default) node-centred gather; other values select experimental kernels */
@@ -169,6 +169,9 @@ int mgcfd_prolong(mgcfd_solver *s, int fine_level);
 /* ---------------------------------------------------------------------------------
  * Cycle driver — the state machine of src/euler3d_cpu_double.cpp:371-694
  * --------------------------------------------------------------------------------- */
+/* `sweeps` smoothing sweeps on one level, no multigrid transfer: the per-level body of the cycle
+ * loop (copy, step factor, RK x [fluxes, time_step], residual; euler3d_cpu_double.cpp:383-508). */
+int mgcfd_smooth(mgcfd_solver *s, int level, int sweeps);
 /* Runs `cycles` (multigrid) cycles from the solver's current state.  rms_out (may be NULL)
  * receives, per cycle, the level-0 RMS the reference prints.  Synchronises before returning.
  * On an invalid state returns MGCFD_ERR_NAN / NEG_* like the reference's exit(). */

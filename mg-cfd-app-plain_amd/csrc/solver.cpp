@@ -61,6 +61,7 @@ struct DeviceLevel {
     double *sumsq = nullptr, *partials = nullptr;
     int n_partials = 0;
     bool nodeq_stale = false;
+    bool fluxes_zero = true;             // fluxes[] is known to hold zeros (skip the read in flux_gather)
     bool has_transfer = false;           // plan to the next-coarser level present
     int64_t iters[MGCFD_NUM_LOOPS] = {0};
     double times[MGCFD_NUM_LOOPS] = {0};
@@ -120,7 +121,8 @@ struct mgcfd_solver {
     }
     struct Timed {
         mgcfd_solver *s; EventPair p; bool on;
-        Timed(mgcfd_solver *s_, int level, int loop, bool flux_internal = false) : s(s_), on(s_->opt_timing != 0)
+        Timed(mgcfd_solver *s_, int level, int loop, bool flux_internal = false)
+            : s(s_), on(s_->opt_timing == 1 || (s_->opt_timing == 2 && flux_internal))
         {
             if (!on) return;
             p = EventPair{s->get_event(), s->get_event(), level, loop, flux_internal};
@@ -181,8 +183,10 @@ struct mgcfd_solver {
         DeviceLevel &lv = level(l);
         ensure_nodeq(lv);
         Timed t(this, l, MGCFD_LOOP_FLUX, (classes & 1) != 0);
-        if (opt_exact) exact::launch_flux_gather(stream, lv.dp, lv.nodeq, ff, lv.fluxes, classes, 1);
-        else fast::launch_flux_gather(stream, lv.dp, lv.nodeq, ff, lv.fluxes, classes, 1);
+        const int accumulate = lv.fluxes_zero ? 0 : 1;     // 0.0 + x: same bits either way
+        if (opt_exact) exact::launch_flux_gather(stream, lv.dp, lv.nodeq, ff, lv.fluxes, classes, accumulate);
+        else fast::launch_flux_gather(stream, lv.dp, lv.nodeq, ff, lv.fluxes, classes, accumulate);
+        lv.fluxes_zero = false;
         if (classes & 1) lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
     }
     void op_indirect_rw(int l)
@@ -192,12 +196,14 @@ struct mgcfd_solver {
         Timed t(this, l, MGCFD_LOOP_INDIRECT_RW);
         if (opt_exact) exact::launch_indirect_rw(stream, lv.dp, lv.nodeq, lv.fluxes);
         else fast::launch_indirect_rw(stream, lv.dp, lv.nodeq, lv.fluxes);
+        lv.fluxes_zero = false;
         lv.iters[MGCFD_LOOP_INDIRECT_RW] += lv.info.n_internal;
     }
     void op_zero_fluxes(int l)
     {
         DeviceLevel &lv = level(l);
         HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * lv.info.nel, stream));
+        lv.fluxes_zero = true;
     }
     void op_time_step(int l, int j)
     {
@@ -207,6 +213,7 @@ struct mgcfd_solver {
         if (opt_exact) exact::launch_time_step(stream, lv.info.nel, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.variables, lv.nodeq, lv.dp.old_of_new, err, opt_check);
         else fast::launch_time_step(stream, lv.info.nel, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.variables, lv.nodeq, lv.dp.old_of_new, err, opt_check);
         lv.nodeq_stale = false;
+        lv.fluxes_zero = true;
         lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
     }
     void op_residual(int l)
@@ -470,7 +477,7 @@ int mgcfd_set_option(mgcfd_solver *s, int option, int value)
     return guarded([&] {
         switch (option) {
             case MGCFD_OPT_EXACT: s->opt_exact = value != 0; break;
-            case MGCFD_OPT_TIMING: s->use_device(); s->fold_events(); s->opt_timing = value != 0; break;
+            case MGCFD_OPT_TIMING: s->use_device(); s->fold_events(); s->opt_timing = value; break;
             case MGCFD_OPT_INDIRECT_RW: s->opt_indirect_rw = value != 0; break;
             case MGCFD_OPT_CHECK_INVALID: s->opt_check = value != 0; break;
             case MGCFD_OPT_FLUX_VARIANT: s->opt_variant = value; break;
@@ -574,6 +581,29 @@ int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_c
     return code;
 }
 
+// One smoothing sweep = the per-level body of the reference's cycle loop
+// (src/euler3d_cpu_double.cpp:383-508): copy, step factor, RK x (fluxes, time_step), residual.
+static void smooth_once(mgcfd_solver *s, int level, bool split_flux_classes)
+{
+    s->op_copy_old(level);                                         // :383
+    s->op_step_factor(level);                                      // :388-395
+    for (int j = 0; j < MGCFD_RK; j++) {                           // :397-506
+        if (split_flux_classes) { s->op_flux(level, 1); s->op_flux(level, 2); s->op_flux(level, 4); }
+        else s->op_flux(level, 7);
+        s->op_time_step(level, j);
+        if (s->opt_indirect_rw) { s->op_indirect_rw(level); s->op_zero_fluxes(level); }
+    }
+    s->op_residual(level);                                         // :508
+}
+
+int mgcfd_smooth(mgcfd_solver *s, int level, int sweeps)
+{
+    OP({
+        s->level(level);
+        for (int k = 0; k < sweeps; k++) smooth_once(s, level, false);
+    });
+}
+
 // ---- cycle driver: src/euler3d_cpu_double.cpp:371-694 ----
 int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
 {
@@ -586,16 +616,7 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
         int level = 0;
         bool going_up = true;
         for (int cyc = 0; cyc < cycles;) {
-            s->op_copy_old(level);                                         // :383
-            s->op_step_factor(level);                                      // :388-395
-            for (int j = 0; j < MGCFD_RK; j++) {                           // :397-506
-                s->op_flux(level, 1);
-                s->op_flux(level, 2);
-                s->op_flux(level, 4);
-                s->op_time_step(level, j);
-                if (s->opt_indirect_rw) { s->op_indirect_rw(level); s->op_zero_fluxes(level); }
-            }
-            s->op_residual(level);                                         // :508
+            smooth_once(s, level, false);                                  // :383-508
             if (level == 0) {                                              // :509-512
                 s->op_sumsq(0);
                 HIP_CHECK(hipMemcpyAsync(rms_dev + cyc, s->L[0].sumsq, sizeof(double), hipMemcpyDeviceToDevice, s->stream));
@@ -672,6 +693,7 @@ int mgcfd_set_array(mgcfd_solver *s, int level, int which, const double *in)
         HIP_CHECK(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
         HIP_CHECK(hipStreamSynchronize(s->stream));
         if (which == MGCFD_ARR_VARIABLES) lv.nodeq_stale = true;
+        if (which == MGCFD_ARR_FLUXES) lv.fluxes_zero = false;
     });
 }
 int mgcfd_get_edges(mgcfd_solver *s, int level, mgcfd_edge *out)

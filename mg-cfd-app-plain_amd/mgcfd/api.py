@@ -79,6 +79,7 @@ _SIGNATURES = [
     ("mgcfd_check_for_invalid_variables", C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
     ("mgcfd_restrict", C.c_int, [_vp, C.c_int]),
     ("mgcfd_prolong", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_smooth", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mgcfd_run_cycles", C.c_int, [_vp, C.c_int, _vp]),
     ("mgcfd_get_array", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     ("mgcfd_set_array", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
@@ -292,6 +293,9 @@ class Solver:
         bad = _i64(-1)
         rc = self.lib.mgcfd_check_for_invalid_variables(self.handle, l, C.byref(bad))
         return rc, bad.value
+
+    def smooth(self, l: int, sweeps: int = 1):
+        self._c(self.lib.mgcfd_smooth(self.handle, l, sweeps))
 
     def run_cycles(self, cycles: int) -> np.ndarray:
         rms = np.zeros(max(cycles, 1))

@@ -8,14 +8,11 @@
 
 namespace mgcfd {
 
-// Per-node record the flux gather reads: the 5 conserved variables plus the quantities the
-// reference derives from them for every incident edge (cfd_loops.h:121-148).  96 bytes,
-// 16-byte aligned, fetched with six 16-byte loads.
-struct alignas(16) NodeQ {
-    double rho, mx, my, mz, en;
-    double vx, vy, vz, p, speed, c, pad;
-};
-static_assert(sizeof(NodeQ) == 96, "NodeQ must be 96 bytes");
+// Node-state fields per level, stored structure-of-arrays with a common padded stride
+// (stride = 64 * n_slices): q[f*stride + i], f = 0..4 conserved variables (the reference's
+// `variables`), f = 5..10 the quantities the reference derives from them for every incident
+// edge (velocity, pressure, |v|, speed of sound; cfd_loops.h:121-148).
+constexpr int kNumStateFields = 11;
 static_assert(sizeof(EdgeW) == 32, "EdgeW must be 32 bytes");
 static_assert(sizeof(ProlongW) == 24, "ProlongW must be 24 bytes");
 
@@ -28,9 +25,10 @@ struct FarField {
 // Device pointers of one level's gather plan.
 struct DevicePlan {
     int64_t nel = 0;
+    int64_t stride = 0;                 // 64 * n_slices
     int32_t n_slices = 0;
     int32_t *slice_row0 = nullptr, *rows_int = nullptr, *rows_bnd = nullptr, *nbr = nullptr;
-    EdgeW *w = nullptr;
+    double *w = nullptr;                // [row][4 components][64 lanes]
     int32_t *old_of_new = nullptr;
     // transfer to/from the next-coarser level
     int32_t *child_ptr = nullptr, *child = nullptr;

@@ -11,8 +11,8 @@
 //   * flux_gather   replaces the reference's edge loop + scatter-add
 //                   (src/Kernels/flux_loops.cpp:133-136, flux_kernel.elemfunc.c) by a per-node
 //                   gather over a sliced-ELLPACK incidence list: coalesced 36 B/entry streams,
-//                   96-byte neighbour records fetched with 16-byte loads, a sequential per-node
-//                   sum in the reference's order, no atomics, no colouring, deterministic.
+//                   structure-of-arrays node state gathered field by field, a sequential
+//                   per-node sum in the reference's order, no atomics, no colouring, deterministic.
 //   * The division / square-root work (8 div + 5 sqrt per edge in the reference) is hoisted to
 //     one per-node "derive" (3 div + 2 sqrt per node) that is fused into the kernels that
 //     produce `variables` (step factor, time step); values are identical because the
@@ -51,25 +51,47 @@ __device__ __forceinline__ Derived derive(double rho, double mx, double my, doub
     return d;
 }
 
-__device__ __forceinline__ void store_nodeq(NodeQ *q, int64_t i, double rho, double mx, double my,
-                                            double mz, double en, const Derived &d)
+// Node state is stored structure-of-arrays: field f of node i lives at q[f*stride + i]
+// (fields: 0 rho, 1 mx, 2 my, 3 mz, 4 en | 5 vx, 6 vy, 7 vz, 8 p, 9 |v|, 10 c).  A wavefront's
+// own-node accesses are then perfectly coalesced, and — because the plan numbers nodes
+// breadth-first — the r-th neighbours of 64 consecutive nodes are nearly consecutive too, so
+// each 8-byte gather instruction touches a handful of cache lines instead of 64.
+struct NodeQ { double rho, mx, my, mz, en, vx, vy, vz, p, speed, c; };
+
+__device__ __forceinline__ void store_derived(double *__restrict__ q, int64_t stride, int64_t i, const Derived &d)
 {
-    double2 *dst = reinterpret_cast<double2 *>(q + i);
-    dst[0] = make_double2(rho, mx);
-    dst[1] = make_double2(my, mz);
-    dst[2] = make_double2(en, d.vx);
-    dst[3] = make_double2(d.vy, d.vz);
-    dst[4] = make_double2(d.p, d.speed);
-    dst[5] = make_double2(d.c, 0.0);
+    q[5 * stride + i] = d.vx;
+    q[6 * stride + i] = d.vy;
+    q[7 * stride + i] = d.vz;
+    q[8 * stride + i] = d.p;
+    q[9 * stride + i] = d.speed;
+    q[10 * stride + i] = d.c;
 }
 
-__device__ __forceinline__ NodeQ load_nodeq(const NodeQ *q, int64_t i)
+__device__ __forceinline__ void store_conserved(double *__restrict__ q, int64_t stride, int64_t i, double rho,
+                                                double mx, double my, double mz, double en)
 {
-    const double2 *src = reinterpret_cast<const double2 *>(q + i);
-    const double2 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4], f = src[5];
+    q[i] = rho;
+    q[stride + i] = mx;
+    q[2 * stride + i] = my;
+    q[3 * stride + i] = mz;
+    q[4 * stride + i] = en;
+}
+
+__device__ __forceinline__ NodeQ load_nodeq(const double *__restrict__ q, int64_t stride, int64_t i)
+{
     NodeQ r;
-    r.rho = a.x; r.mx = a.y; r.my = b.x; r.mz = b.y; r.en = c.x; r.vx = c.y;
-    r.vy = d.x; r.vz = d.y; r.p = e.x; r.speed = e.y; r.c = f.x; r.pad = 0.0;
+    r.rho = q[i];
+    r.mx = q[stride + i];
+    r.my = q[2 * stride + i];
+    r.mz = q[3 * stride + i];
+    r.en = q[4 * stride + i];
+    r.vx = q[5 * stride + i];
+    r.vy = q[6 * stride + i];
+    r.vz = q[7 * stride + i];
+    r.p = q[8 * stride + i];
+    r.speed = q[9 * stride + i];
+    r.c = q[10 * stride + i];
     return r;
 }
 
@@ -107,49 +129,53 @@ __device__ __forceinline__ double wave_sum(double v)
 
 } // namespace
 
-// ------------------------------------------------------------------------------------------
-// initialize_variables (cfd_loops.h:44-55) + first derive
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-k_init_variables(int64_t nel, FarField ff, double *__restrict__ variables, NodeQ *__restrict__ nodeq)
+// XCD-aware block order: hardware deals consecutive workgroups round-robin over the 8 XCDs
+// (each with a private L2).  Give every XCD one CONTIGUOUS range of slices instead, so the
+// neighbour windows of the blocks sharing an L2 overlap and node state is fetched from the
+// Infinity Cache / HBM about once, not eight times.  Pure speed: any placement is correct.
+__device__ __forceinline__ unsigned xcd_contiguous_block(unsigned b, unsigned nb)
 {
-    const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
-    if (i >= nel) return;
-    double *v = variables + i * 5;
-    v[0] = ff.var[0]; v[1] = ff.var[1]; v[2] = ff.var[2]; v[3] = ff.var[3]; v[4] = ff.var[4];
-    const Derived d = derive(ff.var[0], ff.var[1], ff.var[2], ff.var[3], ff.var[4]);
-    store_nodeq(nodeq, i, ff.var[0], ff.var[1], ff.var[2], ff.var[3], ff.var[4], d);
+    const unsigned q = nb >> 3, r = nb & 7u, x = b & 7u, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
-// variables -> nodeq (after restrict / prolong / set_array changed variables)
+// ------------------------------------------------------------------------------------------
+// initialize_variables (cfd_loops.h:44-55) + first derive.  Runs over the padded length so
+// the tail of every field holds valid numbers.
+// ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_derive(int64_t nel, const double *__restrict__ variables, NodeQ *__restrict__ nodeq)
+k_init_variables(int64_t stride, FarField ff, double *__restrict__ q)
+{
+    const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    if (i >= stride) return;
+    store_conserved(q, stride, i, ff.var[0], ff.var[1], ff.var[2], ff.var[3], ff.var[4]);
+    store_derived(q, stride, i, derive(ff.var[0], ff.var[1], ff.var[2], ff.var[3], ff.var[4]));
+}
+
+// conserved -> derived fields (after restrict / prolong / set_array changed variables)
+__global__ void __launch_bounds__(kBlock)
+k_derive(int64_t nel, int64_t stride, double *__restrict__ q)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
-    const double *v = variables + i * 5;
-    const double rho = v[0], mx = v[1], my = v[2], mz = v[3], en = v[4];
-    store_nodeq(nodeq, i, rho, mx, my, mz, en, derive(rho, mx, my, mz, en));
+    store_derived(q, stride, i, derive(q[i], q[stride + i], q[2 * stride + i], q[3 * stride + i], q[4 * stride + i]));
 }
 
 // ------------------------------------------------------------------------------------------
 // compute_step_factor, first half (cfd_loops.cpp:98-125): sf = 0.5 * cbrt(vol) / (|v| + c) and
 // the minimum over the level.  cbrt(vol) is static and precomputed on the host with the same
-// libm the reference would call.  Also refreshes nodeq (same derive).
+// libm the reference would call.  Also refreshes the derived fields (same expressions).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_step_factor_local(int64_t nel, const double *__restrict__ variables, const double *__restrict__ cbrt_vol,
-                    double *__restrict__ step_factors, NodeQ *__restrict__ nodeq,
-                    unsigned long long *__restrict__ min_bits)
+k_step_factor_local(int64_t nel, int64_t stride, double *__restrict__ q, const double *__restrict__ cbrt_vol,
+                    double *__restrict__ step_factors, unsigned long long *__restrict__ min_bits)
 {
     __shared__ double s_min[kBlock / 64];
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     double sf = __longlong_as_double(0x7F7F7F7F7F7F7F7FLL);
     if (i < nel) {
-        const double *v = variables + i * 5;
-        const double rho = v[0], mx = v[1], my = v[2], mz = v[3], en = v[4];
-        const Derived d = derive(rho, mx, my, mz, en);
-        store_nodeq(nodeq, i, rho, mx, my, mz, en, d);
+        const Derived d = derive(q[i], q[stride + i], q[2 * stride + i], q[3 * stride + i], q[4 * stride + i]);
+        store_derived(q, stride, i, d);
         const double dt = cbrt_vol[i] / (d.speed + d.c);
         sf = 0.5 * dt;
         step_factors[i] = sf;
@@ -178,15 +204,13 @@ k_step_factor_apply(int64_t nel, const unsigned long long *__restrict__ min_bits
 
 // compute_step_factor_legacy (cfd_loops.cpp:37-61), mesh_name = fvcorr only
 __global__ void __launch_bounds__(kBlock)
-k_step_factor_legacy(int64_t nel, const double *__restrict__ variables, const double *__restrict__ volumes,
-                     double *__restrict__ step_factors, NodeQ *__restrict__ nodeq)
+k_step_factor_legacy(int64_t nel, int64_t stride, double *__restrict__ q, const double *__restrict__ volumes,
+                     double *__restrict__ step_factors)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
-    const double *v = variables + i * 5;
-    const double rho = v[0], mx = v[1], my = v[2], mz = v[3], en = v[4];
-    const Derived d = derive(rho, mx, my, mz, en);
-    store_nodeq(nodeq, i, rho, mx, my, mz, en, d);
+    const Derived d = derive(q[i], q[stride + i], q[2 * stride + i], q[3 * stride + i], q[4 * stride + i]);
+    store_derived(q, stride, i, d);
     step_factors[i] = 0.5 / (sqrt(volumes[i]) * (d.speed + d.c));
 }
 
@@ -196,41 +220,42 @@ k_step_factor_legacy(int64_t nel, const double *__restrict__ variables, const do
 // slice of the sliced-ELL plan.  `classes` selects which edge classes take part
 // (bit0 internal, bit1 solid wall "-1", bit2 far field "-2"); `accumulate` != 0 starts from the
 // value already in `fluxes` (the reference's "+=" when the array is not known to be zero).
+// Entry e = row*64 + lane; edge weights are stored [row][component][lane].
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_flux_gather(int64_t nel, const NodeQ *__restrict__ nodeq, const int32_t *__restrict__ slice_row0,
+k_flux_gather(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
               const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
-              const int32_t *__restrict__ nbr, const EdgeW *__restrict__ w, FarField ff,
+              const int32_t *__restrict__ nbr, const double *__restrict__ w, FarField ff,
               double *__restrict__ fluxes, int classes, int accumulate)
 {
-    const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int64_t i = blk * int64_t(kBlock) + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
     if ((int64_t(slice) << 6) >= nel) return;          // whole wave past the end
-    const bool active = i < nel;
-    const int64_t ii = active ? i : nel - 1;           // keep addresses valid for idle lanes
+    const bool active = i < nel;                        // padded tail lanes compute on valid padding
 
     const int32_t row0 = slice_row0[slice];
     const int32_t n_int = rows_int[slice];
     const int32_t n_bnd = rows_bnd[slice];
 
-    const NodeQ me = load_nodeq(nodeq, ii);
+    const NodeQ me = load_nodeq(q, stride, i);
     const FluxC fm = flux_contribution(me);
 
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
     if (accumulate) {
-        const double *f = fluxes + ii * 5;
-        a0 = f[0]; a1 = f[1]; a2 = f[2]; a3 = f[3]; a4 = f[4];
+        a0 = fluxes[i]; a1 = fluxes[stride + i]; a2 = fluxes[2 * stride + i];
+        a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
     }
 
     if (classes & 1) {
-        int64_t e = (int64_t(row0) << 6) + lane;
-        for (int32_t r = 0; r < n_int; r++, e += 64) {
-            const int32_t code = nbr[e];
+        for (int32_t r = 0; r < n_int; r++) {
+            const int64_t row = int64_t(row0) + r;
+            const int32_t code = nbr[(row << 6) + lane];
             if (code < 0) continue;                                   // ELL padding
-            const double2 w01 = reinterpret_cast<const double2 *>(w + e)[0];
-            const double2 w23 = reinterpret_cast<const double2 *>(w + e)[1];
-            const NodeQ ot = load_nodeq(nodeq, code & kIdMask);
+            const double *wr = w + (row << 8) + lane;
+            const double fx = wr[0], fy = wr[64], fz = wr[128], k = wr[192];
+            const NodeQ ot = load_nodeq(q, stride, code & kIdMask);
             const FluxC fo = flux_contribution(ot);
             const bool me_is_b = (code & kRoleB) != 0;
             // factor = -|e|*0.2f*0.5 * (speed_a + speed_b + c_a + c_b), left-associated
@@ -238,8 +263,7 @@ k_flux_gather(int64_t nel, const NodeQ *__restrict__ nodeq, const int32_t *__res
             // on which end this node is.
             const double c_a = me_is_b ? ot.c : me.c;
             const double c_b = me_is_b ? me.c : ot.c;
-            const double factor = w23.y * (((me.speed + ot.speed) + c_a) + c_b);
-            const double fx = w01.x, fy = w01.y, fz = w23.x;
+            const double factor = k * (((me.speed + ot.speed) + c_a) + c_b);
             // flux_kernel.elemfunc.c:142-189 seen from this node ("me" - "other"; the b-side
             // sign is folded into fx,fy,fz by the plan)
             a0 += factor * (me.rho - ot.rho) + fx * (me.mx + ot.mx) + fy * (me.my + ot.my) + fz * (me.mz + ot.mz);
@@ -256,12 +280,11 @@ k_flux_gather(int64_t nel, const NodeQ *__restrict__ nodeq, const int32_t *__res
         for (int pass = 0; pass < 2; pass++) {
             const int32_t want = pass == 0 ? kCodeWall : kCodeFar;
             if (!(classes & (pass == 0 ? 2 : 4))) continue;
-            int64_t e = ((int64_t(row0) + n_int) << 6) + lane;
-            for (int32_t r = 0; r < n_bnd; r++, e += 64) {
-                if (nbr[e] != want) continue;
-                const double2 w01 = reinterpret_cast<const double2 *>(w + e)[0];
-                const double wz = reinterpret_cast<const double *>(w + e)[2];
-                const double fx = w01.x, fy = w01.y, fz = wz;
+            for (int32_t r = 0; r < n_bnd; r++) {
+                const int64_t row = int64_t(row0) + n_int + r;
+                if (nbr[(row << 6) + lane] != want) continue;
+                const double *wr = w + (row << 8) + lane;
+                const double fx = wr[0], fy = wr[64], fz = wr[128];
                 if (pass == 0) {
                     // flux_boundary_kernel.elemfunc.c:37-64: pressure force only
                     a0 += 0.0;
@@ -282,8 +305,8 @@ k_flux_gather(int64_t nel, const NodeQ *__restrict__ nodeq, const int32_t *__res
     }
 
     if (active) {
-        double *f = fluxes + i * 5;
-        f[0] = a0; f[1] = a1; f[2] = a2; f[3] = a3; f[4] = a4;
+        fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
+        fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
     }
 }
 
@@ -293,67 +316,66 @@ k_flux_gather(int64_t nel, const NodeQ *__restrict__ nodeq, const int32_t *__res
 // The plan stores -0.5*e (a side), so e = -2*w exactly.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_indirect_rw(int64_t nel, const NodeQ *__restrict__ nodeq, const int32_t *__restrict__ slice_row0,
+k_indirect_rw(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
               const int32_t *__restrict__ rows_int, const int32_t *__restrict__ nbr,
-              const EdgeW *__restrict__ w, double *__restrict__ fluxes)
+              const double *__restrict__ w, double *__restrict__ fluxes)
 {
-    const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int64_t i = blk * int64_t(kBlock) + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
     if ((int64_t(slice) << 6) >= nel) return;
     const bool active = i < nel;
-    const int64_t ii = active ? i : nel - 1;
     const int32_t row0 = slice_row0[slice];
     const int32_t n_int = rows_int[slice];
-    const double *f = fluxes + ii * 5;
-    double a0 = f[0], a1 = f[1], a2 = f[2], a3 = f[3], a4 = f[4];
-    int64_t e = (int64_t(row0) << 6) + lane;
-    for (int32_t r = 0; r < n_int; r++, e += 64) {
-        const int32_t code = nbr[e];
+    double a0 = fluxes[i], a1 = fluxes[stride + i], a2 = fluxes[2 * stride + i],
+           a3 = fluxes[3 * stride + i], a4 = fluxes[4 * stride + i];
+    for (int32_t r = 0; r < n_int; r++) {
+        const int64_t row = int64_t(row0) + r;
+        const int32_t code = nbr[(row << 6) + lane];
         if (code < 0) continue;
-        const NodeQ ot = load_nodeq(nodeq, code & kIdMask);
+        const int64_t j = code & kIdMask;
+        const double o0 = q[j], o1 = q[stride + j], o2 = q[2 * stride + j], o3 = q[3 * stride + j], o4 = q[4 * stride + j];
         if (code & kRoleB) {
-            a0 += ot.rho; a1 += ot.mx; a2 += ot.my; a3 += ot.mz; a4 += ot.en;
+            a0 += o0; a1 += o1; a2 += o2; a3 += o3; a4 += o4;
         } else {
-            const EdgeW we = w[e];
-            a0 += ot.rho + (-2.0 * we.x);
-            a1 += ot.mx + (-2.0 * we.z);
-            a2 += ot.my;
-            a3 += ot.mz;
-            a4 += ot.en + (-2.0 * we.y);
+            const double *wr = w + (row << 8) + lane;
+            a0 += o0 + (-2.0 * wr[0]);
+            a1 += o1 + (-2.0 * wr[128]);
+            a2 += o2;
+            a3 += o3;
+            a4 += o4 + (-2.0 * wr[64]);
         }
     }
     if (active) {
-        double *g = fluxes + i * 5;
-        g[0] = a0; g[1] = a1; g[2] = a2; g[3] = a3; g[4] = a4;
+        fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
+        fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // time_step (cfd_loops.cpp:241-268): variables = old + sf/(RK+1-j) * fluxes ; fluxes = 0.
-// Fused: refresh nodeq for the next flux pass and raise the check_for_invalid_variables flag
-// (validation.cpp:107-138) — err[0] = code, err[1] = smallest offending ORIGINAL cell id.
+// Fused: refresh the derived fields for the next flux pass and raise the
+// check_for_invalid_variables flag (validation.cpp:107-138) — err = (smallest offending
+// ORIGINAL cell id << 8) | code.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_time_step(int64_t nel, double rk_div, const double *__restrict__ step_factors, double *__restrict__ fluxes,
-            const double *__restrict__ old_variables, double *__restrict__ variables,
-            NodeQ *__restrict__ nodeq, const int32_t *__restrict__ old_of_new,
-            unsigned long long *__restrict__ err, int check)
+k_time_step(int64_t nel, int64_t stride, double rk_div, const double *__restrict__ step_factors,
+            double *__restrict__ fluxes, const double *__restrict__ old_variables, double *__restrict__ q,
+            const int32_t *__restrict__ old_of_new, unsigned long long *__restrict__ err, int check)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
     const double factor = step_factors[i] / rk_div;
-    const double *o = old_variables + i * 5;
-    double *f = fluxes + i * 5;
-    double *v = variables + i * 5;
-    const double rho = o[0] + factor * f[0];
-    const double mx = o[1] + factor * f[1];
-    const double my = o[2] + factor * f[2];
-    const double mz = o[3] + factor * f[3];
-    const double en = o[4] + factor * f[4];
-    v[0] = rho; v[1] = mx; v[2] = my; v[3] = mz; v[4] = en;
-    f[0] = 0.0; f[1] = 0.0; f[2] = 0.0; f[3] = 0.0; f[4] = 0.0;
-    store_nodeq(nodeq, i, rho, mx, my, mz, en, derive(rho, mx, my, mz, en));
+    const double rho = old_variables[i] + factor * fluxes[i];
+    const double mx = old_variables[stride + i] + factor * fluxes[stride + i];
+    const double my = old_variables[2 * stride + i] + factor * fluxes[2 * stride + i];
+    const double mz = old_variables[3 * stride + i] + factor * fluxes[3 * stride + i];
+    const double en = old_variables[4 * stride + i] + factor * fluxes[4 * stride + i];
+    store_conserved(q, stride, i, rho, mx, my, mz, en);
+    fluxes[i] = 0.0; fluxes[stride + i] = 0.0; fluxes[2 * stride + i] = 0.0;
+    fluxes[3 * stride + i] = 0.0; fluxes[4 * stride + i] = 0.0;
+    store_derived(q, stride, i, derive(rho, mx, my, mz, en));
     if (check) {
         const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
         int code = 0;
@@ -371,21 +393,21 @@ k_time_step(int64_t nel, double rk_div, const double *__restrict__ step_factors,
 
 // check_for_invalid_variables as a standalone sweep
 __global__ void __launch_bounds__(kBlock)
-k_check_invalid(int64_t nel, const double *__restrict__ variables, const int32_t *__restrict__ old_of_new,
+k_check_invalid(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ old_of_new,
                 unsigned long long *__restrict__ err)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
-    const double *v = variables + i * 5;
-    const bool finite = isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]) && isfinite(v[4]);
+    const double v0 = q[i], v1 = q[stride + i], v2 = q[2 * stride + i], v3 = q[3 * stride + i], v4 = q[4 * stride + i];
+    const bool finite = isfinite(v0) && isfinite(v1) && isfinite(v2) && isfinite(v3) && isfinite(v4);
     int code = 0;
     if (!finite) code = 1;
-    else if (v[0] < 0.0) code = 2;
-    else if (v[4] < 0.0) code = 3;
+    else if (v0 < 0.0) code = 2;
+    else if (v4 < 0.0) code = 3;
     if (code) atomicMin(err, (static_cast<unsigned long long>(old_of_new[i]) << 8) | unsigned(code));
 }
 
-// residual (validation.cpp:77-89), flat over nel*5 values
+// residual (validation.cpp:77-89), flat over the 5 padded fields
 __global__ void __launch_bounds__(kBlock)
 k_residual(int64_t n, const double *__restrict__ old_variables, const double *__restrict__ variables,
            double *__restrict__ residuals)
@@ -394,15 +416,15 @@ k_residual(int64_t n, const double *__restrict__ old_variables, const double *__
     if (k < n) residuals[k] = variables[k] - old_variables[k];
 }
 
-// sum of squares for calc_rms (validation.cpp:91-105).  Tree order differs from the
-// reference's serial sum; the value is only ever printed with %.3e.
+// sum of squares for calc_rms (validation.cpp:91-105) over the nel real entries of 5 fields.
+// Tree order differs from the reference's serial sum; the value is only ever printed with %.3e.
 __global__ void __launch_bounds__(kBlock)
-k_sumsq(int64_t n, const double *__restrict__ x, double *__restrict__ partial)
+k_sumsq(int64_t nel, int64_t stride, const double *__restrict__ x, double *__restrict__ partial)
 {
     __shared__ double s[kBlock / 64];
     double acc = 0.0;
-    for (int64_t k = blockIdx.x * int64_t(kBlock) + threadIdx.x; k < n; k += int64_t(gridDim.x) * kBlock)
-        acc += x[k] * x[k];
+    for (int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x; i < nel; i += int64_t(gridDim.x) * kBlock)
+        for (int f = 0; f < 5; f++) { const double v = x[f * stride + i]; acc += v * v; }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -434,8 +456,8 @@ k_sum_partials(int n, const double *__restrict__ partial, double *__restrict__ o
 // ascending fine id) * (1/count); coarse nodes without children keep their value.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_restrict(int64_t nel_coarse, const int32_t *__restrict__ child_ptr, const int32_t *__restrict__ child,
-           const double *__restrict__ fine_variables, double *__restrict__ coarse_variables)
+k_restrict(int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine, const int32_t *__restrict__ child_ptr,
+           const int32_t *__restrict__ child, const double *__restrict__ fine_q, double *__restrict__ coarse_q)
 {
     const int64_t c = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (c >= nel_coarse) return;
@@ -443,12 +465,12 @@ k_restrict(int64_t nel_coarse, const int32_t *__restrict__ child_ptr, const int3
     if (b == e) return;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
     for (int32_t k = b; k < e; k++) {
-        const double *v = fine_variables + int64_t(child[k]) * 5;
-        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3]; s4 += v[4];
+        const int64_t j = child[k];
+        s0 += fine_q[j]; s1 += fine_q[stride_fine + j]; s2 += fine_q[2 * stride_fine + j];
+        s3 += fine_q[3 * stride_fine + j]; s4 += fine_q[4 * stride_fine + j];
     }
     const double average = 1.0 / double(e - b);
-    double *o = coarse_variables + c * 5;
-    o[0] = s0 * average; o[1] = s1 * average; o[2] = s2 * average; o[3] = s3 * average; o[4] = s4 * average;
+    store_conserved(coarse_q, stride_coarse, c, s0 * average, s1 * average, s2 * average, s3 * average, s4 * average);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -458,10 +480,11 @@ k_restrict(int64_t nel_coarse, const int32_t *__restrict__ child_ptr, const int3
 //   variables += residuals - wavg
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_prolong(int64_t nel, const int32_t *__restrict__ slice_row0, const int32_t *__restrict__ rows_int,
-          const ProlongW *__restrict__ pro, const int32_t *__restrict__ pro_parent,
-          const double *__restrict__ pro_wsum, const double *__restrict__ coarse_residuals,
-          const double *__restrict__ fine_residuals, double *__restrict__ fine_variables)
+k_prolong(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t *__restrict__ slice_row0,
+          const int32_t *__restrict__ rows_int, const ProlongW *__restrict__ pro,
+          const int32_t *__restrict__ pro_parent, const double *__restrict__ pro_wsum,
+          const double *__restrict__ coarse_residuals, const double *__restrict__ fine_residuals,
+          double *__restrict__ fine_q)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -472,33 +495,34 @@ k_prolong(int64_t nel, const int32_t *__restrict__ slice_row0, const int32_t *__
     const int32_t row0 = slice_row0[slice];
     const int32_t n_int = rows_int[slice];
     const int32_t parent = pro_parent[ii];
+    const int64_t sc = stride_coarse;
     double r0, r1, r2, r3, r4;
     if (parent < 0) {
-        const double *R = coarse_residuals + int64_t(~parent) * 5;
-        r0 = R[0]; r1 = R[1]; r2 = R[2]; r3 = R[3]; r4 = R[4];
+        const int64_t p = ~parent;
+        r0 = coarse_residuals[p]; r1 = coarse_residuals[sc + p]; r2 = coarse_residuals[2 * sc + p];
+        r3 = coarse_residuals[3 * sc + p]; r4 = coarse_residuals[4 * sc + p];
     } else {
         r0 = r1 = r2 = r3 = r4 = 0.0;
         int64_t e = (int64_t(row0) << 6) + lane;
         for (int32_t r = 0; r < n_int; r++, e += 64) {
             const ProlongW pw = pro[e];
             if (pw.w_own == 0.0 && pw.w_other == 0.0) continue;      // ELL padding
-            const double *Ro = coarse_residuals + int64_t(pw.p_own) * 5;
-            const double *Rx = coarse_residuals + int64_t(pw.p_other) * 5;
-            r0 += pw.w_own * Ro[0]; r1 += pw.w_own * Ro[1]; r2 += pw.w_own * Ro[2];
-            r3 += pw.w_own * Ro[3]; r4 += pw.w_own * Ro[4];
-            r0 += pw.w_other * Rx[0]; r1 += pw.w_other * Rx[1]; r2 += pw.w_other * Rx[2];
-            r3 += pw.w_other * Rx[3]; r4 += pw.w_other * Rx[4];
+            const int64_t po = pw.p_own, px = pw.p_other;
+            r0 += pw.w_own * coarse_residuals[po]; r1 += pw.w_own * coarse_residuals[sc + po];
+            r2 += pw.w_own * coarse_residuals[2 * sc + po]; r3 += pw.w_own * coarse_residuals[3 * sc + po];
+            r4 += pw.w_own * coarse_residuals[4 * sc + po];
+            r0 += pw.w_other * coarse_residuals[px]; r1 += pw.w_other * coarse_residuals[sc + px];
+            r2 += pw.w_other * coarse_residuals[2 * sc + px]; r3 += pw.w_other * coarse_residuals[3 * sc + px];
+            r4 += pw.w_other * coarse_residuals[4 * sc + px];
         }
     }
     if (!active) return;
     const double ws = pro_wsum[i];
-    const double *q = fine_residuals + i * 5;
-    double *v = fine_variables + i * 5;
-    v[0] += q[0] - r0 / ws;
-    v[1] += q[1] - r1 / ws;
-    v[2] += q[2] - r2 / ws;
-    v[3] += q[3] - r3 / ws;
-    v[4] += q[4] - r4 / ws;
+    fine_q[i] += fine_residuals[i] - r0 / ws;
+    fine_q[stride + i] += fine_residuals[stride + i] - r1 / ws;
+    fine_q[2 * stride + i] += fine_residuals[2 * stride + i] - r2 / ws;
+    fine_q[3 * stride + i] += fine_residuals[3 * stride + i] - r3 / ws;
+    fine_q[4 * stride + i] += fine_residuals[4 * stride + i] - r4 / ws;
 }
 
 // ==========================================================================================
@@ -506,67 +530,69 @@ k_prolong(int64_t nel, const int32_t *__restrict__ slice_row0, const int32_t *__
 // ==========================================================================================
 static inline unsigned grid_for(int64_t n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); }
 
-void launch_init_variables(hipStream_t st, int64_t nel, const FarField &ff, double *variables, NodeQ *nodeq)
-{ hipLaunchKernelGGL(k_init_variables, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, ff, variables, nodeq); }
+void launch_init_variables(hipStream_t st, int64_t stride, const FarField &ff, double *q)
+{ hipLaunchKernelGGL(k_init_variables, dim3(grid_for(stride)), dim3(kBlock), 0, st, stride, ff, q); }
 
-void launch_derive(hipStream_t st, int64_t nel, const double *variables, NodeQ *nodeq)
-{ hipLaunchKernelGGL(k_derive, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, variables, nodeq); }
+void launch_derive(hipStream_t st, int64_t nel, int64_t stride, double *q)
+{ hipLaunchKernelGGL(k_derive, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q); }
 
-void launch_step_factor_local(hipStream_t st, int64_t nel, const double *variables, const double *cbrt_vol,
-                              double *sf, NodeQ *nodeq, unsigned long long *min_bits)
-{ hipLaunchKernelGGL(k_step_factor_local, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, variables, cbrt_vol, sf, nodeq, min_bits); }
+void launch_step_factor_local(hipStream_t st, int64_t nel, int64_t stride, double *q, const double *cbrt_vol,
+                              double *sf, unsigned long long *min_bits)
+{ hipLaunchKernelGGL(k_step_factor_local, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, cbrt_vol, sf, min_bits); }
 
 void launch_step_factor_apply(hipStream_t st, int64_t nel, const unsigned long long *min_bits,
                               const double *volumes, double *sf)
 { hipLaunchKernelGGL(k_step_factor_apply, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, min_bits, volumes, sf); }
 
-void launch_step_factor_legacy(hipStream_t st, int64_t nel, const double *variables, const double *volumes,
-                               double *sf, NodeQ *nodeq)
-{ hipLaunchKernelGGL(k_step_factor_legacy, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, variables, volumes, sf, nodeq); }
+void launch_step_factor_legacy(hipStream_t st, int64_t nel, int64_t stride, double *q, const double *volumes, double *sf)
+{ hipLaunchKernelGGL(k_step_factor_legacy, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, volumes, sf); }
 
-void launch_flux_gather(hipStream_t st, const DevicePlan &p, const NodeQ *nodeq, const FarField &ff,
+void launch_flux_gather(hipStream_t st, const DevicePlan &p, const double *q, const FarField &ff,
                         double *fluxes, int classes, int accumulate)
 {
-    hipLaunchKernelGGL(k_flux_gather, dim3(grid_for(int64_t(p.n_slices) * 64)), dim3(kBlock), 0, st, p.nel, nodeq,
+    hipLaunchKernelGGL(k_flux_gather, dim3(grid_for(p.stride)), dim3(kBlock), 0, st, p.nel, p.stride, q,
                        p.slice_row0, p.rows_int, p.rows_bnd, p.nbr, p.w, ff, fluxes, classes, accumulate);
 }
 
-void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const NodeQ *nodeq, double *fluxes)
+void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, double *fluxes)
 {
-    hipLaunchKernelGGL(k_indirect_rw, dim3(grid_for(int64_t(p.n_slices) * 64)), dim3(kBlock), 0, st, p.nel, nodeq,
+    hipLaunchKernelGGL(k_indirect_rw, dim3(grid_for(p.stride)), dim3(kBlock), 0, st, p.nel, p.stride, q,
                        p.slice_row0, p.rows_int, p.nbr, p.w, fluxes);
 }
 
-void launch_time_step(hipStream_t st, int64_t nel, int j, const double *sf, double *fluxes, const double *old_variables,
-                      double *variables, NodeQ *nodeq, const int32_t *old_of_new, unsigned long long *err, int check)
+void launch_time_step(hipStream_t st, int64_t nel, int64_t stride, int j, const double *sf, double *fluxes,
+                      const double *old_variables, double *q, const int32_t *old_of_new, unsigned long long *err, int check)
 {
     const double rk_div = double(3 + 1 - j);    // double(RK+1-j), cfd_loops.cpp:243
-    hipLaunchKernelGGL(k_time_step, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, rk_div, sf, fluxes, old_variables,
-                       variables, nodeq, old_of_new, err, check);
+    hipLaunchKernelGGL(k_time_step, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, rk_div, sf, fluxes,
+                       old_variables, q, old_of_new, err, check);
 }
 
-void launch_check_invalid(hipStream_t st, int64_t nel, const double *variables, const int32_t *old_of_new,
+void launch_check_invalid(hipStream_t st, int64_t nel, int64_t stride, const double *q, const int32_t *old_of_new,
                           unsigned long long *err)
-{ hipLaunchKernelGGL(k_check_invalid, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, variables, old_of_new, err); }
+{ hipLaunchKernelGGL(k_check_invalid, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, old_of_new, err); }
 
-void launch_residual(hipStream_t st, int64_t nel, const double *old_variables, const double *variables, double *residuals)
-{ hipLaunchKernelGGL(k_residual, dim3(grid_for(nel * 5)), dim3(kBlock), 0, st, nel * 5, old_variables, variables, residuals); }
+void launch_residual(hipStream_t st, int64_t stride, const double *old_variables, const double *q, double *residuals)
+{ hipLaunchKernelGGL(k_residual, dim3(grid_for(stride * 5)), dim3(kBlock), 0, st, stride * 5, old_variables, q, residuals); }
 
-void launch_sumsq(hipStream_t st, int64_t n, const double *x, double *partial, int n_partial, double *out)
+void launch_sumsq(hipStream_t st, int64_t nel, int64_t stride, const double *x, double *partial, int n_partial, double *out)
 {
-    hipLaunchKernelGGL(k_sumsq, dim3(n_partial), dim3(kBlock), 0, st, n, x, partial);
+    hipLaunchKernelGGL(k_sumsq, dim3(n_partial), dim3(kBlock), 0, st, nel, stride, x, partial);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, n_partial, partial, out);
 }
 
-void launch_restrict(hipStream_t st, int64_t nel_coarse, const int32_t *child_ptr, const int32_t *child,
-                     const double *fine_variables, double *coarse_variables)
-{ hipLaunchKernelGGL(k_restrict, dim3(grid_for(nel_coarse)), dim3(kBlock), 0, st, nel_coarse, child_ptr, child, fine_variables, coarse_variables); }
-
-void launch_prolong(hipStream_t st, const DevicePlan &p, const double *coarse_residuals, const double *fine_residuals,
-                    double *fine_variables)
+void launch_restrict(hipStream_t st, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,
+                     const int32_t *child_ptr, const int32_t *child, const double *fine_q, double *coarse_q)
 {
-    hipLaunchKernelGGL(k_prolong, dim3(grid_for(int64_t(p.n_slices) * 64)), dim3(kBlock), 0, st, p.nel, p.slice_row0,
-                       p.rows_int, p.pro, p.pro_parent, p.pro_wsum, coarse_residuals, fine_residuals, fine_variables);
+    hipLaunchKernelGGL(k_restrict, dim3(grid_for(nel_coarse)), dim3(kBlock), 0, st, nel_coarse, stride_coarse,
+                       stride_fine, child_ptr, child, fine_q, coarse_q);
+}
+
+void launch_prolong(hipStream_t st, const DevicePlan &p, int64_t stride_coarse, const double *coarse_residuals,
+                    const double *fine_residuals, double *fine_q)
+{
+    hipLaunchKernelGGL(k_prolong, dim3(grid_for(p.stride)), dim3(kBlock), 0, st, p.nel, p.stride, stride_coarse,
+                       p.slice_row0, p.rows_int, p.pro, p.pro_parent, p.pro_wsum, coarse_residuals, fine_residuals, fine_q);
 }
 
 } // namespace MGCFD_KERNEL_NS

@@ -5,29 +5,30 @@
 
 #define MGCFD_DECLARE_LAUNCHERS(NS)                                                                                  \
     namespace mgcfd { namespace NS {                                                                                 \
-    void launch_init_variables(hipStream_t, int64_t nel, const FarField &, double *variables, NodeQ *nodeq);         \
-    void launch_derive(hipStream_t, int64_t nel, const double *variables, NodeQ *nodeq);                             \
-    void launch_step_factor_local(hipStream_t, int64_t nel, const double *variables, const double *cbrt_vol,         \
-                                  double *sf, NodeQ *nodeq, unsigned long long *min_bits);                           \
+    void launch_init_variables(hipStream_t, int64_t stride, const FarField &, double *q);                            \
+    void launch_derive(hipStream_t, int64_t nel, int64_t stride, double *q);                                         \
+    void launch_step_factor_local(hipStream_t, int64_t nel, int64_t stride, double *q, const double *cbrt_vol,       \
+                                  double *sf, unsigned long long *min_bits);                                         \
     void launch_step_factor_apply(hipStream_t, int64_t nel, const unsigned long long *min_bits,                      \
                                   const double *volumes, double *sf);                                                \
-    void launch_step_factor_legacy(hipStream_t, int64_t nel, const double *variables, const double *volumes,         \
-                                   double *sf, NodeQ *nodeq);                                                        \
-    void launch_flux_gather(hipStream_t, const DevicePlan &, const NodeQ *nodeq, const FarField &, double *fluxes,   \
+    void launch_step_factor_legacy(hipStream_t, int64_t nel, int64_t stride, double *q, const double *volumes,       \
+                                   double *sf);                                                                      \
+    void launch_flux_gather(hipStream_t, const DevicePlan &, const double *q, const FarField &, double *fluxes,      \
                             int classes, int accumulate);                                                            \
-    void launch_indirect_rw(hipStream_t, const DevicePlan &, const NodeQ *nodeq, double *fluxes);                    \
-    void launch_time_step(hipStream_t, int64_t nel, int j, const double *sf, double *fluxes,                         \
-                          const double *old_variables, double *variables, NodeQ *nodeq,                              \
-                          const int32_t *old_of_new, unsigned long long *err, int check);                            \
-    void launch_check_invalid(hipStream_t, int64_t nel, const double *variables, const int32_t *old_of_new,          \
-                              unsigned long long *err);                                                              \
-    void launch_residual(hipStream_t, int64_t nel, const double *old_variables, const double *variables,             \
+    void launch_indirect_rw(hipStream_t, const DevicePlan &, const double *q, double *fluxes);                       \
+    void launch_time_step(hipStream_t, int64_t nel, int64_t stride, int j, const double *sf, double *fluxes,         \
+                          const double *old_variables, double *q, const int32_t *old_of_new,                         \
+                          unsigned long long *err, int check);                                                       \
+    void launch_check_invalid(hipStream_t, int64_t nel, int64_t stride, const double *q,                             \
+                              const int32_t *old_of_new, unsigned long long *err);                                   \
+    void launch_residual(hipStream_t, int64_t stride, const double *old_variables, const double *q,                  \
                          double *residuals);                                                                         \
-    void launch_sumsq(hipStream_t, int64_t n, const double *x, double *partial, int n_partial, double *out);         \
-    void launch_restrict(hipStream_t, int64_t nel_coarse, const int32_t *child_ptr, const int32_t *child,            \
-                         const double *fine_variables, double *coarse_variables);                                    \
-    void launch_prolong(hipStream_t, const DevicePlan &, const double *coarse_residuals,                             \
-                        const double *fine_residuals, double *fine_variables);                                       \
+    void launch_sumsq(hipStream_t, int64_t nel, int64_t stride, const double *x, double *partial, int n_partial,     \
+                      double *out);                                                                                  \
+    void launch_restrict(hipStream_t, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,                \
+                         const int32_t *child_ptr, const int32_t *child, const double *fine_q, double *coarse_q);    \
+    void launch_prolong(hipStream_t, const DevicePlan &, int64_t stride_coarse, const double *coarse_residuals,      \
+                        const double *fine_residuals, double *fine_q);                                               \
     } }
 
 MGCFD_DECLARE_LAUNCHERS(exact)

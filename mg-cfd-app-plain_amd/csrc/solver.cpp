@@ -54,9 +54,9 @@ struct DeviceLevel {
     std::vector<mgcfd_edge> edges;       // final edge weights, original order
     LevelPlan plan;                      // host copy (permutations for get/set)
     DevicePlan dp;
-    double *variables = nullptr, *old_variables = nullptr, *fluxes = nullptr, *residuals = nullptr;
-    double *step_factors = nullptr, *volumes = nullptr, *cbrt_vol = nullptr;
-    NodeQ *nodeq = nullptr;
+    // SoA state, stride = dp.stride: q = 11 fields (0-4 = the reference's `variables`, 5-10 derived)
+    double *q = nullptr, *old_variables = nullptr, *fluxes = nullptr, *residuals = nullptr;   // [5|11][stride]
+    double *step_factors = nullptr, *volumes = nullptr, *cbrt_vol = nullptr;                  // [stride]
     unsigned long long *min_bits = nullptr;
     double *sumsq = nullptr, *partials = nullptr;
     int n_partials = 0;
@@ -140,21 +140,21 @@ struct mgcfd_solver {
     void ensure_nodeq(DeviceLevel &lv)
     {
         if (!lv.nodeq_stale) return;
-        if (opt_exact) exact::launch_derive(stream, lv.info.nel, lv.variables, lv.nodeq);
-        else fast::launch_derive(stream, lv.info.nel, lv.variables, lv.nodeq);
+        if (opt_exact) exact::launch_derive(stream, lv.info.nel, lv.dp.stride, lv.q);
+        else fast::launch_derive(stream, lv.info.nel, lv.dp.stride, lv.q);
         lv.nodeq_stale = false;
     }
     void op_copy_old(int l)
     {
         DeviceLevel &lv = level(l);
-        HIP_CHECK(hipMemcpyAsync(lv.old_variables, lv.variables, sizeof(double) * 5 * lv.info.nel, hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(lv.old_variables, lv.q, sizeof(double) * 5 * lv.dp.stride, hipMemcpyDeviceToDevice, stream));
     }
     void op_step_factor_local(int l)
     {
         DeviceLevel &lv = level(l);
         HIP_CHECK(hipMemsetAsync(lv.min_bits, 0x7F, sizeof(unsigned long long), stream));
-        if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.variables, lv.cbrt_vol, lv.step_factors, lv.nodeq, lv.min_bits);
-        else fast::launch_step_factor_local(stream, lv.info.nel, lv.variables, lv.cbrt_vol, lv.step_factors, lv.nodeq, lv.min_bits);
+        if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits);
+        else fast::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits);
         lv.nodeq_stale = false;
     }
     void op_step_factor_apply(int l)
@@ -168,8 +168,8 @@ struct mgcfd_solver {
         DeviceLevel &lv = level(l);
         Timed t(this, l, MGCFD_LOOP_COMPUTE_STEP);
         if (mesh_variant == MGCFD_MESH_FVCORR) {
-            if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.variables, lv.volumes, lv.step_factors, lv.nodeq);
-            else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.variables, lv.volumes, lv.step_factors, lv.nodeq);
+            if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors);
+            else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors);
             lv.nodeq_stale = false;
         } else {
             op_step_factor_local(l);
@@ -184,8 +184,8 @@ struct mgcfd_solver {
         ensure_nodeq(lv);
         Timed t(this, l, MGCFD_LOOP_FLUX, (classes & 1) != 0);
         const int accumulate = lv.fluxes_zero ? 0 : 1;     // 0.0 + x: same bits either way
-        if (opt_exact) exact::launch_flux_gather(stream, lv.dp, lv.nodeq, ff, lv.fluxes, classes, accumulate);
-        else fast::launch_flux_gather(stream, lv.dp, lv.nodeq, ff, lv.fluxes, classes, accumulate);
+        if (opt_exact) exact::launch_flux_gather(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate);
+        else fast::launch_flux_gather(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate);
         lv.fluxes_zero = false;
         if (classes & 1) lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
     }
@@ -194,15 +194,15 @@ struct mgcfd_solver {
         DeviceLevel &lv = level(l);
         ensure_nodeq(lv);
         Timed t(this, l, MGCFD_LOOP_INDIRECT_RW);
-        if (opt_exact) exact::launch_indirect_rw(stream, lv.dp, lv.nodeq, lv.fluxes);
-        else fast::launch_indirect_rw(stream, lv.dp, lv.nodeq, lv.fluxes);
+        if (opt_exact) exact::launch_indirect_rw(stream, lv.dp, lv.q, lv.fluxes);
+        else fast::launch_indirect_rw(stream, lv.dp, lv.q, lv.fluxes);
         lv.fluxes_zero = false;
         lv.iters[MGCFD_LOOP_INDIRECT_RW] += lv.info.n_internal;
     }
     void op_zero_fluxes(int l)
     {
         DeviceLevel &lv = level(l);
-        HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * lv.info.nel, stream));
+        HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * lv.dp.stride, stream));
         lv.fluxes_zero = true;
     }
     void op_time_step(int l, int j)
@@ -210,8 +210,8 @@ struct mgcfd_solver {
         if (j < 0 || j >= MGCFD_RK) throw std::invalid_argument("RK stage out of range");
         DeviceLevel &lv = level(l);
         Timed t(this, l, MGCFD_LOOP_TIME_STEP);
-        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.variables, lv.nodeq, lv.dp.old_of_new, err, opt_check);
-        else fast::launch_time_step(stream, lv.info.nel, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.variables, lv.nodeq, lv.dp.old_of_new, err, opt_check);
+        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check);
+        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check);
         lv.nodeq_stale = false;
         lv.fluxes_zero = true;
         lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
@@ -219,14 +219,14 @@ struct mgcfd_solver {
     void op_residual(int l)
     {
         DeviceLevel &lv = level(l);
-        if (opt_exact) exact::launch_residual(stream, lv.info.nel, lv.old_variables, lv.variables, lv.residuals);
-        else fast::launch_residual(stream, lv.info.nel, lv.old_variables, lv.variables, lv.residuals);
+        if (opt_exact) exact::launch_residual(stream, lv.dp.stride, lv.old_variables, lv.q, lv.residuals);
+        else fast::launch_residual(stream, lv.dp.stride, lv.old_variables, lv.q, lv.residuals);
     }
     void op_sumsq(int l)
     {
         DeviceLevel &lv = level(l);
-        if (opt_exact) exact::launch_sumsq(stream, lv.info.nel * 5, lv.residuals, lv.partials, lv.n_partials, lv.sumsq);
-        else fast::launch_sumsq(stream, lv.info.nel * 5, lv.residuals, lv.partials, lv.n_partials, lv.sumsq);
+        if (opt_exact) exact::launch_sumsq(stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq);
+        else fast::launch_sumsq(stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq);
     }
     void op_restrict(int fine)
     {
@@ -236,8 +236,8 @@ struct mgcfd_solver {
         // Timer / iteration attribution quirk: the reference bumps `level` before the call,
         // so restriction is booked to the COARSE level.
         Timed t(this, fine + 1, MGCFD_LOOP_RESTRICT);
-        if (opt_exact) exact::launch_restrict(stream, C.info.nel, F.dp.child_ptr, F.dp.child, F.variables, C.variables);
-        else fast::launch_restrict(stream, C.info.nel, F.dp.child_ptr, F.dp.child, F.variables, C.variables);
+        if (opt_exact) exact::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q);
+        else fast::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q);
         C.nodeq_stale = true;
         C.iters[MGCFD_LOOP_RESTRICT] += 2 * F.info.mgc + C.info.nel;   // mg_loops.cpp:61,117,172
     }
@@ -247,8 +247,8 @@ struct mgcfd_solver {
         DeviceLevel &C = level(fine + 1);
         if (!F.has_transfer) throw std::invalid_argument("level has no multigrid map");
         Timed t(this, fine, MGCFD_LOOP_PROLONG);
-        if (opt_exact) exact::launch_prolong(stream, F.dp, C.residuals, F.residuals, F.variables);
-        else fast::launch_prolong(stream, F.dp, C.residuals, F.residuals, F.variables);
+        if (opt_exact) exact::launch_prolong(stream, F.dp, C.dp.stride, C.residuals, F.residuals, F.q);
+        else fast::launch_prolong(stream, F.dp, C.dp.stride, C.residuals, F.residuals, F.q);
         F.nodeq_stale = true;
         F.iters[MGCFD_LOOP_PROLONG] += F.info.n_internal + F.info.nel;  // mg_loops.cpp:728,842
     }
@@ -275,8 +275,8 @@ mgcfd_solver::~mgcfd_solver()
     for (auto &p : pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto e : free_events) (void)hipEventDestroy(e);
     for (auto &lv : L) {
-        void *ptrs[] = {lv.variables, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
-                        lv.cbrt_vol, lv.nodeq, lv.min_bits, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
+        void *ptrs[] = {lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
+                        lv.cbrt_vol, lv.min_bits, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.pro,
                         lv.dp.pro_parent, lv.dp.pro_wsum};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -343,7 +343,8 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.info.volumes = nullptr; lv.info.coords = nullptr; lv.info.edges = nullptr; lv.info.mg_map = nullptr;
         const int64_t nel = d.nel;
         const LevelPlan &P = lv.plan;
-        std::vector<double> vol(static_cast<size_t>(nel)), cb(static_cast<size_t>(nel));
+        const int64_t stride = int64_t(P.n_slices) * kSlice;
+        std::vector<double> vol(static_cast<size_t>(stride), 1.0), cb(static_cast<size_t>(stride), 1.0);
         for (int64_t n = 0; n < nel; n++) {
             const double v = d.volumes[P.old_of_new[static_cast<size_t>(n)]];
             vol[static_cast<size_t>(n)] = v;
@@ -351,23 +352,35 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         }
         lv.volumes = dev_upload(vol);
         lv.cbrt_vol = dev_upload(cb);
-        lv.variables = dev_alloc<double>(static_cast<size_t>(nel) * 5);
-        lv.old_variables = dev_alloc<double>(static_cast<size_t>(nel) * 5);
-        lv.fluxes = dev_alloc<double>(static_cast<size_t>(nel) * 5);
-        lv.residuals = dev_alloc<double>(static_cast<size_t>(nel) * 5);
-        lv.step_factors = dev_alloc<double>(static_cast<size_t>(nel));
-        lv.nodeq = dev_alloc<NodeQ>(static_cast<size_t>(nel));
+        lv.q = dev_alloc<double>(static_cast<size_t>(stride) * kNumStateFields);
+        lv.old_variables = dev_alloc<double>(static_cast<size_t>(stride) * 5);
+        lv.fluxes = dev_alloc<double>(static_cast<size_t>(stride) * 5);
+        lv.residuals = dev_alloc<double>(static_cast<size_t>(stride) * 5);
+        lv.step_factors = dev_alloc<double>(static_cast<size_t>(stride));
         lv.min_bits = dev_alloc<unsigned long long>(1);
         lv.sumsq = dev_alloc<double>(1);
         lv.n_partials = static_cast<int>(std::min<int64_t>(1024, (nel * 5 + 255) / 256));
         lv.partials = dev_alloc<double>(static_cast<size_t>(lv.n_partials));
         lv.dp.nel = nel;
+        lv.dp.stride = stride;
         lv.dp.n_slices = P.n_slices;
         lv.dp.slice_row0 = dev_upload(P.slice_row0);
         lv.dp.rows_int = dev_upload(P.rows_int);
         lv.dp.rows_bnd = dev_upload(P.rows_bnd);
         lv.dp.nbr = dev_upload(P.nbr);
-        lv.dp.w = dev_upload(P.w);
+        {
+            // edge weights as [row][component][lane] so each component load of a wave is one
+            // contiguous 512-byte run
+            std::vector<double> ws(P.w.size() * 4);
+            for (size_t e = 0; e < P.w.size(); e++) {
+                const size_t row = e / kSlice, lane = e % kSlice;
+                ws[(row * 4 + 0) * kSlice + lane] = P.w[e].x;
+                ws[(row * 4 + 1) * kSlice + lane] = P.w[e].y;
+                ws[(row * 4 + 2) * kSlice + lane] = P.w[e].z;
+                ws[(row * 4 + 3) * kSlice + lane] = P.w[e].k;
+            }
+            lv.dp.w = dev_upload(ws);
+        }
         lv.dp.old_of_new = dev_upload(P.old_of_new);
         if (lv.has_transfer) {
             lv.dp.child_ptr = dev_upload(P.child_ptr);
@@ -381,11 +394,11 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.plan.nbr.clear(); lv.plan.nbr.shrink_to_fit();
         lv.plan.w.clear(); lv.plan.w.shrink_to_fit();
         // initial state: far field everywhere, fluxes/residuals/old/step factors zero
-        HIP_CHECK(hipMemsetAsync(lv.old_variables, 0, sizeof(double) * 5 * nel, s->stream));
-        HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * nel, s->stream));
-        HIP_CHECK(hipMemsetAsync(lv.residuals, 0, sizeof(double) * 5 * nel, s->stream));
-        HIP_CHECK(hipMemsetAsync(lv.step_factors, 0, sizeof(double) * nel, s->stream));
-        exact::launch_init_variables(s->stream, nel, s->ff, lv.variables, lv.nodeq);
+        HIP_CHECK(hipMemsetAsync(lv.old_variables, 0, sizeof(double) * 5 * stride, s->stream));
+        HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * stride, s->stream));
+        HIP_CHECK(hipMemsetAsync(lv.residuals, 0, sizeof(double) * 5 * stride, s->stream));
+        HIP_CHECK(hipMemsetAsync(lv.step_factors, 0, sizeof(double) * stride, s->stream));
+        exact::launch_init_variables(s->stream, stride, s->ff, lv.q);
     }
     HIP_CHECK(hipStreamSynchronize(s->stream));
     HIP_CHECK(hipGetLastError());
@@ -573,7 +586,7 @@ int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_c
     int rc = guarded([&] {
         s->use_device();
         DeviceLevel &lv = s->level(level);
-        exact::launch_check_invalid(s->stream, lv.info.nel, lv.variables, lv.dp.old_of_new, s->err);
+        exact::launch_check_invalid(s->stream, lv.info.nel, lv.dp.stride, lv.q, lv.dp.old_of_new, s->err);
         code = s->read_error(bad_cell);
     });
     if (rc != MGCFD_OK) return rc;
@@ -650,7 +663,7 @@ static double *array_ptr(DeviceLevel &lv, int which, int *ncols)
 {
     *ncols = 5;
     switch (which) {
-        case MGCFD_ARR_VARIABLES: return lv.variables;
+        case MGCFD_ARR_VARIABLES: return lv.q;
         case MGCFD_ARR_OLD_VARIABLES: return lv.old_variables;
         case MGCFD_ARR_FLUXES: return lv.fluxes;
         case MGCFD_ARR_RESIDUALS: return lv.residuals;
@@ -667,12 +680,13 @@ int mgcfd_get_array(mgcfd_solver *s, int level, int which, double *out)
         DeviceLevel &lv = s->level(level);
         int nc = 0;
         double *src = array_ptr(lv, which, &nc);
-        std::vector<double> tmp(static_cast<size_t>(lv.info.nel) * nc);
+        const int64_t stride = lv.dp.stride;
+        std::vector<double> tmp(static_cast<size_t>(stride) * nc);
         HIP_CHECK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         HIP_CHECK(hipStreamSynchronize(s->stream));
-        for (int64_t n = 0; n < lv.info.nel; n++) {
+        for (int64_t n = 0; n < lv.info.nel; n++) {          // device: [field][new id]  ->  caller: [old id][field]
             const int64_t o = lv.plan.old_of_new[static_cast<size_t>(n)];
-            for (int c = 0; c < nc; c++) out[o * nc + c] = tmp[static_cast<size_t>(n * nc + c)];
+            for (int c = 0; c < nc; c++) out[o * nc + c] = tmp[static_cast<size_t>(c * stride + n)];
         }
     });
 }
@@ -685,10 +699,14 @@ int mgcfd_set_array(mgcfd_solver *s, int level, int which, const double *in)
         int nc = 0;
         double *dst = array_ptr(lv, which, &nc);
         if (which == MGCFD_ARR_VOLUMES) throw std::invalid_argument("volumes are fixed at creation");
-        std::vector<double> tmp(static_cast<size_t>(lv.info.nel) * nc);
+        const int64_t stride = lv.dp.stride;
+        // keep the padded tail of every field as it is on the device (valid numbers)
+        std::vector<double> tmp(static_cast<size_t>(stride) * nc);
+        HIP_CHECK(hipMemcpyAsync(tmp.data(), dst, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
         for (int64_t n = 0; n < lv.info.nel; n++) {
             const int64_t o = lv.plan.old_of_new[static_cast<size_t>(n)];
-            for (int c = 0; c < nc; c++) tmp[static_cast<size_t>(n * nc + c)] = in[o * nc + c];
+            for (int c = 0; c < nc; c++) tmp[static_cast<size_t>(c * stride + n)] = in[o * nc + c];
         }
         HIP_CHECK(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
         HIP_CHECK(hipStreamSynchronize(s->stream));

@@ -197,6 +197,10 @@ int mgcfd_reset_monitoring(mgcfd_solver *s);
  * Requires MGCFD_OPT_TIMING. */
 int mgcfd_get_flux_kernel_time(mgcfd_solver *s, int level, double *avg_seconds, int64_t *launches);
 
+/* Diagnostic: mean GPU time of `launches` back-to-back flux launches (internal + boundary +
+ * far field, starting from zero fluxes), hipEvents around the batch on the solver's stream. */
+int mgcfd_bench_flux(mgcfd_solver *s, int level, int launches, double *avg_seconds);
+
 /* ---------------------------------------------------------------------------------
  * Multi-GPU hooks (one process per GPU; the collectives themselves are issued by the
  * host through RCCL — see INTEGRATION.md).  compute_step_factor's global min

@@ -29,6 +29,8 @@ struct DevicePlan {
     int32_t n_slices = 0;
     int32_t *slice_row0 = nullptr, *rows_int = nullptr, *rows_bnd = nullptr, *nbr = nullptr;
     double *w = nullptr;                // [row][4 components][64 lanes]
+    int32_t n_tiles = 0;
+    int32_t *nbr_tile = nullptr, *tile_halo_ptr = nullptr, *tile_halo = nullptr;
     int32_t *old_of_new = nullptr;
     // transfer to/from the next-coarser level
     int32_t *child_ptr = nullptr, *child = nullptr;

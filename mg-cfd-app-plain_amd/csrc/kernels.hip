@@ -95,6 +95,35 @@ __device__ __forceinline__ NodeQ load_nodeq(const double *__restrict__ q, int64_
     return r;
 }
 
+// The flux kernels read node state as array-of-structures RECORDS instead: one 128-byte,
+// line-aligned record per node (11 doubles + padding), so that staging a halo node into LDS
+// costs exactly one cache-line access.
+constexpr int kRecDoubles = 16;            // 128 B in global memory
+constexpr int kLdsRecDoubles = 12;         // 96 B in LDS (padding dropped)
+
+__device__ __forceinline__ void store_record(double *__restrict__ rec, int64_t i, double rho, double mx, double my,
+                                             double mz, double en, const Derived &d)
+{
+    double2 *dst = reinterpret_cast<double2 *>(rec + i * kRecDoubles);
+    dst[0] = make_double2(rho, mx);
+    dst[1] = make_double2(my, mz);
+    dst[2] = make_double2(en, d.vx);
+    dst[3] = make_double2(d.vy, d.vz);
+    dst[4] = make_double2(d.p, d.speed);
+    dst[5] = make_double2(d.c, 0.0);
+}
+
+template <typename P> __device__ __forceinline__ NodeQ load_record(P base)
+{
+    // base points at 6 x double2 (global or LDS)
+    const double2 a = base[0], b = base[1], c = base[2], d = base[3], e = base[4];
+    const double f = reinterpret_cast<const double *>(base)[10];
+    NodeQ r;
+    r.rho = a.x; r.mx = a.y; r.my = b.x; r.mz = b.y; r.en = c.x; r.vx = c.y;
+    r.vy = d.x; r.vz = d.y; r.p = e.x; r.speed = e.y; r.c = f;
+    return r;
+}
+
 // The nine distinct flux-contribution components (cfd_loops.h:57-83); the momentum tensor is
 // symmetric in storage: fmy.x = fmx.y, fmz.x = fmx.z, fmz.y = fmy.z.
 struct FluxC { double xx, xy, xz, yy, yz, zz, ex, ey, ez; };
@@ -144,21 +173,26 @@ __device__ __forceinline__ unsigned xcd_contiguous_block(unsigned b, unsigned nb
 // the tail of every field holds valid numbers.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_init_variables(int64_t stride, FarField ff, double *__restrict__ q)
+k_init_variables(int64_t stride, FarField ff, double *__restrict__ q, double *__restrict__ rec)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= stride) return;
     store_conserved(q, stride, i, ff.var[0], ff.var[1], ff.var[2], ff.var[3], ff.var[4]);
-    store_derived(q, stride, i, derive(ff.var[0], ff.var[1], ff.var[2], ff.var[3], ff.var[4]));
+    const Derived d = derive(ff.var[0], ff.var[1], ff.var[2], ff.var[3], ff.var[4]);
+    store_derived(q, stride, i, d);
+    store_record(rec, i, ff.var[0], ff.var[1], ff.var[2], ff.var[3], ff.var[4], d);
 }
 
 // conserved -> derived fields (after restrict / prolong / set_array changed variables)
 __global__ void __launch_bounds__(kBlock)
-k_derive(int64_t nel, int64_t stride, double *__restrict__ q)
+k_derive(int64_t nel, int64_t stride, double *__restrict__ q, double *__restrict__ rec)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
-    store_derived(q, stride, i, derive(q[i], q[stride + i], q[2 * stride + i], q[3 * stride + i], q[4 * stride + i]));
+    const double rho = q[i], mx = q[stride + i], my = q[2 * stride + i], mz = q[3 * stride + i], en = q[4 * stride + i];
+    const Derived d = derive(rho, mx, my, mz, en);
+    store_derived(q, stride, i, d);
+    store_record(rec, i, rho, mx, my, mz, en, d);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -167,15 +201,18 @@ k_derive(int64_t nel, int64_t stride, double *__restrict__ q)
 // libm the reference would call.  Also refreshes the derived fields (same expressions).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_step_factor_local(int64_t nel, int64_t stride, double *__restrict__ q, const double *__restrict__ cbrt_vol,
-                    double *__restrict__ step_factors, unsigned long long *__restrict__ min_bits)
+k_step_factor_local(int64_t nel, int64_t stride, double *__restrict__ q, double *__restrict__ rec,
+                    const double *__restrict__ cbrt_vol, double *__restrict__ step_factors,
+                    unsigned long long *__restrict__ min_bits)
 {
     __shared__ double s_min[kBlock / 64];
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     double sf = __longlong_as_double(0x7F7F7F7F7F7F7F7FLL);
     if (i < nel) {
-        const Derived d = derive(q[i], q[stride + i], q[2 * stride + i], q[3 * stride + i], q[4 * stride + i]);
+        const double rho = q[i], mx = q[stride + i], my = q[2 * stride + i], mz = q[3 * stride + i], en = q[4 * stride + i];
+        const Derived d = derive(rho, mx, my, mz, en);
         store_derived(q, stride, i, d);
+        store_record(rec, i, rho, mx, my, mz, en, d);
         const double dt = cbrt_vol[i] / (d.speed + d.c);
         sf = 0.5 * dt;
         step_factors[i] = sf;
@@ -204,13 +241,15 @@ k_step_factor_apply(int64_t nel, const unsigned long long *__restrict__ min_bits
 
 // compute_step_factor_legacy (cfd_loops.cpp:37-61), mesh_name = fvcorr only
 __global__ void __launch_bounds__(kBlock)
-k_step_factor_legacy(int64_t nel, int64_t stride, double *__restrict__ q, const double *__restrict__ volumes,
-                     double *__restrict__ step_factors)
+k_step_factor_legacy(int64_t nel, int64_t stride, double *__restrict__ q, double *__restrict__ rec,
+                     const double *__restrict__ volumes, double *__restrict__ step_factors)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
-    const Derived d = derive(q[i], q[stride + i], q[2 * stride + i], q[3 * stride + i], q[4 * stride + i]);
+    const double rho = q[i], mx = q[stride + i], my = q[2 * stride + i], mz = q[3 * stride + i], en = q[4 * stride + i];
+    const Derived d = derive(rho, mx, my, mz, en);
     store_derived(q, stride, i, d);
+    store_record(rec, i, rho, mx, my, mz, en, d);
     step_factors[i] = 0.5 / (sqrt(volumes[i]) * (d.speed + d.c));
 }
 
@@ -221,8 +260,62 @@ k_step_factor_legacy(int64_t nel, int64_t stride, double *__restrict__ q, const 
 // (bit0 internal, bit1 solid wall "-1", bit2 far field "-2"); `accumulate` != 0 starts from the
 // value already in `fluxes` (the reference's "+=" when the array is not known to be zero).
 // Entry e = row*64 + lane; edge weights are stored [row][component][lane].
+//
+// The level has only ~4.6 waves per SIMD of work (300K nodes / 64 / 1024 SIMDs), so latency
+// cannot be hidden by occupancy alone: the PIPE form software-pipelines the row loop —
+// neighbour ids and weights are fetched two rows ahead, the neighbour's state one row ahead —
+// and rows are still accumulated strictly in order (bit-exactness needs the reference's
+// summation order, not its instruction order).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
+struct EdgeRow { int32_t code; double fx, fy, fz, k; };
+
+__device__ __forceinline__ EdgeRow load_row(const int32_t *__restrict__ nbr, const double *__restrict__ w,
+                                            int64_t row, int lane)
+{
+    EdgeRow e;
+    e.code = nbr[(row << 6) + lane];
+    const double *wr = w + (row << 8) + lane;
+    e.fx = wr[0]; e.fy = wr[64]; e.fz = wr[128]; e.k = wr[192];
+    return e;
+}
+
+__device__ __forceinline__ EdgeRow pad_row()
+{
+    EdgeRow e;
+    e.code = kCodePad; e.fx = 0.0; e.fy = 0.0; e.fz = 0.0; e.k = 0.0;
+    return e;
+}
+
+// padding rows read this lane's own (valid, cached) state and are skipped by add_edge
+__device__ __forceinline__ NodeQ gather_other(const double *__restrict__ q, int64_t stride, int32_t code, int64_t self)
+{
+    return load_nodeq(q, stride, code < 0 ? self : int64_t(code & kIdMask));
+}
+
+__device__ __forceinline__ void add_edge(const NodeQ &me, const FluxC &fm, const NodeQ &ot, const EdgeRow &e,
+                                         double &a0, double &a1, double &a2, double &a3, double &a4)
+{
+    if (e.code < 0) return;                                       // ELL padding
+    const FluxC fo = flux_contribution(ot);
+    const bool me_is_b = (e.code & kRoleB) != 0;
+    // factor = -|e|*0.2f*0.5 * (speed_a + speed_b + c_a + c_b), left-associated
+    // (flux_kernel.elemfunc.c:130-131); only the order of the two sound speeds depends on
+    // which end this node is.
+    const double c_a = me_is_b ? ot.c : me.c;
+    const double c_b = me_is_b ? me.c : ot.c;
+    const double factor = e.k * (((me.speed + ot.speed) + c_a) + c_b);
+    const double fx = e.fx, fy = e.fy, fz = e.fz;
+    // flux_kernel.elemfunc.c:142-189 seen from this node ("me" - "other"; the b-side sign is
+    // folded into fx,fy,fz by the plan)
+    a0 += factor * (me.rho - ot.rho) + fx * (me.mx + ot.mx) + fy * (me.my + ot.my) + fz * (me.mz + ot.mz);
+    a4 += factor * (me.en - ot.en) + fx * (fm.ex + fo.ex) + fy * (fm.ey + fo.ey) + fz * (fm.ez + fo.ez);
+    a1 += factor * (me.mx - ot.mx) + fx * (fm.xx + fo.xx) + fy * (fm.xy + fo.xy) + fz * (fm.xz + fo.xz);
+    a2 += factor * (me.my - ot.my) + fx * (fm.xy + fo.xy) + fy * (fm.yy + fo.yy) + fz * (fm.yz + fo.yz);
+    a3 += factor * (me.mz - ot.mz) + fx * (fm.xz + fo.xz) + fy * (fm.yz + fo.yz) + fz * (fm.zz + fo.zz);
+}
+
+template <int MINW, bool PIPE>
+__global__ void __launch_bounds__(kBlock, MINW)
 k_flux_gather(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
               const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
               const int32_t *__restrict__ nbr, const double *__restrict__ w, FarField ff,
@@ -236,8 +329,15 @@ k_flux_gather(int64_t nel, int64_t stride, const double *__restrict__ q, const i
     const bool active = i < nel;                        // padded tail lanes compute on valid padding
 
     const int32_t row0 = slice_row0[slice];
-    const int32_t n_int = rows_int[slice];
+    const int32_t n_int = (classes & 1) ? rows_int[slice] : 0;
     const int32_t n_bnd = rows_bnd[slice];
+
+    // issue the first rows' loads before anything else so they overlap the own-state loads
+    EdgeRow e0 = pad_row(), e1 = pad_row();
+    if (PIPE) {
+        if (n_int > 0) e0 = load_row(nbr, w, row0, lane);
+        if (n_int > 1) e1 = load_row(nbr, w, int64_t(row0) + 1, lane);
+    }
 
     const NodeQ me = load_nodeq(q, stride, i);
     const FluxC fm = flux_contribution(me);
@@ -248,40 +348,41 @@ k_flux_gather(int64_t nel, int64_t stride, const double *__restrict__ q, const i
         a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
     }
 
-    if (classes & 1) {
+    if (PIPE) {
+        if (n_int > 0) {
+            NodeQ o0 = gather_other(q, stride, e0.code, i);
+            for (int32_t r = 0; r < n_int; r += 2) {
+                // row r+1's neighbour state and row r+2's ids/weights go in flight ...
+                const NodeQ o1 = gather_other(q, stride, e1.code, i);
+                EdgeRow e2 = pad_row();
+                if (r + 2 < n_int) e2 = load_row(nbr, w, int64_t(row0) + r + 2, lane);
+                // ... while row r is computed
+                add_edge(me, fm, o0, e0, a0, a1, a2, a3, a4);
+                const NodeQ o2 = gather_other(q, stride, e2.code, i);
+                EdgeRow e3 = pad_row();
+                if (r + 3 < n_int) e3 = load_row(nbr, w, int64_t(row0) + r + 3, lane);
+                add_edge(me, fm, o1, e1, a0, a1, a2, a3, a4);
+                e0 = e2; o0 = o2; e1 = e3;
+            }
+        }
+    } else {
         for (int32_t r = 0; r < n_int; r++) {
-            const int64_t row = int64_t(row0) + r;
-            const int32_t code = nbr[(row << 6) + lane];
-            if (code < 0) continue;                                   // ELL padding
-            const double *wr = w + (row << 8) + lane;
-            const double fx = wr[0], fy = wr[64], fz = wr[128], k = wr[192];
-            const NodeQ ot = load_nodeq(q, stride, code & kIdMask);
-            const FluxC fo = flux_contribution(ot);
-            const bool me_is_b = (code & kRoleB) != 0;
-            // factor = -|e|*0.2f*0.5 * (speed_a + speed_b + c_a + c_b), left-associated
-            // (flux_kernel.elemfunc.c:130-131); only the order of the two sound speeds depends
-            // on which end this node is.
-            const double c_a = me_is_b ? ot.c : me.c;
-            const double c_b = me_is_b ? me.c : ot.c;
-            const double factor = k * (((me.speed + ot.speed) + c_a) + c_b);
-            // flux_kernel.elemfunc.c:142-189 seen from this node ("me" - "other"; the b-side
-            // sign is folded into fx,fy,fz by the plan)
-            a0 += factor * (me.rho - ot.rho) + fx * (me.mx + ot.mx) + fy * (me.my + ot.my) + fz * (me.mz + ot.mz);
-            a4 += factor * (me.en - ot.en) + fx * (fm.ex + fo.ex) + fy * (fm.ey + fo.ey) + fz * (fm.ez + fo.ez);
-            a1 += factor * (me.mx - ot.mx) + fx * (fm.xx + fo.xx) + fy * (fm.xy + fo.xy) + fz * (fm.xz + fo.xz);
-            a2 += factor * (me.my - ot.my) + fx * (fm.xy + fo.xy) + fy * (fm.yy + fo.yy) + fz * (fm.yz + fo.yz);
-            a3 += factor * (me.mz - ot.mz) + fx * (fm.xz + fo.xz) + fy * (fm.yz + fo.yz) + fz * (fm.zz + fo.zz);
+            const EdgeRow e = load_row(nbr, w, int64_t(row0) + r, lane);
+            if (e.code < 0) continue;
+            const NodeQ ot = load_nodeq(q, stride, e.code & kIdMask);
+            add_edge(me, fm, ot, e, a0, a1, a2, a3, a4);
         }
     }
 
     if ((classes & 6) && n_bnd > 0) {
         // The reference runs ALL solid-wall faces, then ALL far-field faces; the plan lists a
         // node's faces in that order, so one pass per class keeps its per-node order.
+        const int32_t first_bnd = rows_int[slice];
         for (int pass = 0; pass < 2; pass++) {
             const int32_t want = pass == 0 ? kCodeWall : kCodeFar;
             if (!(classes & (pass == 0 ? 2 : 4))) continue;
             for (int32_t r = 0; r < n_bnd; r++) {
-                const int64_t row = int64_t(row0) + n_int + r;
+                const int64_t row = int64_t(row0) + first_bnd + r;
                 if (nbr[(row << 6) + lane] != want) continue;
                 const double *wr = w + (row << 8) + lane;
                 const double fx = wr[0], fy = wr[64], fz = wr[128];
@@ -305,6 +406,114 @@ k_flux_gather(int64_t nel, int64_t stride, const double *__restrict__ q, const i
     }
 
     if (active) {
+        fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
+        fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// flux_tile: the same node-centred gather with the neighbour state served from an LDS tile.
+// One 256-thread workgroup = one tile = 256 consecutive nodes forming a compact cluster of
+// the mesh graph (preprocess.cpp: cluster_order).  The workgroup first copies the records of
+// its own nodes and of its halo (the few hundred nodes outside the cluster that its edges
+// touch) from HBM into LDS with full-cache-line, 16-byte-per-lane loads — every node record is
+// fetched once per tile instead of once per incident edge — and then every lane walks its
+// incidence rows reading neighbour records from LDS by tile-local slot.  Rows are still
+// accumulated in the reference's order.  Halo nodes beyond the LDS capacity (rare, only for
+// ragged clusters) are read straight from HBM.
+// ------------------------------------------------------------------------------------------
+template <int MINW>
+__global__ void __launch_bounds__(kBlock, MINW)
+k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ rec, const int32_t *__restrict__ slice_row0,
+            const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
+            const int32_t *__restrict__ nbr_tile, const double *__restrict__ w,
+            const int32_t *__restrict__ tile_halo_ptr, const int32_t *__restrict__ tile_halo, FarField ff,
+            double *__restrict__ fluxes, int classes, int accumulate)
+{
+    __shared__ double2 tile[kTileCap * kLdsRecDoubles / 2];
+
+    const unsigned t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t base = int64_t(t) * kTile;
+    const int64_t i = base + tid;
+    const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
+
+    // ---- stage own + halo records: 8 lanes per record, 16 B each (pieces 6,7 are padding) ----
+    const int32_t h0 = tile_halo_ptr[t];
+    const int32_t n_halo = tile_halo_ptr[t + 1] - h0;
+    const int32_t n_staged = kTile + n_halo;
+    const int piece = tid & 7;
+    for (int32_t slot = tid >> 3; slot < n_staged; slot += kBlock / 8) {
+        const int64_t node = slot < kTile ? base + slot : int64_t(tile_halo[h0 + slot - kTile]);
+        if (piece < 6) {
+            const double2 v = reinterpret_cast<const double2 *>(rec + node * kRecDoubles)[piece];
+            tile[slot * (kLdsRecDoubles / 2) + piece] = v;
+        }
+    }
+
+    // first rows' ids and weights go in flight while the tile lands
+    const int32_t row0 = slice_row0[slice];
+    const int32_t n_int = (classes & 1) ? rows_int[slice] : 0;
+    const int32_t n_bnd = rows_bnd[slice];
+    EdgeRow e0 = pad_row(), e1 = pad_row();
+    if (n_int > 0) e0 = load_row(nbr_tile, w, row0, lane);
+    if (n_int > 1) e1 = load_row(nbr_tile, w, int64_t(row0) + 1, lane);
+
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+    if (accumulate) {
+        a0 = fluxes[i]; a1 = fluxes[stride + i]; a2 = fluxes[2 * stride + i];
+        a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
+    }
+    __syncthreads();
+
+    const NodeQ me = load_record(&tile[tid * (kLdsRecDoubles / 2)]);
+    const FluxC fm = flux_contribution(me);
+
+    auto neighbour = [&](int32_t code) -> NodeQ {
+        if (code < 0) return me;                                           // padding row: skipped by add_edge
+        if (code & kTileGlobal)                                            // halo beyond the LDS capacity
+            return load_record(reinterpret_cast<const double2 *>(rec + int64_t(code & kTileIdMask) * kRecDoubles));
+        return load_record(&tile[(code & kTileIdMask) * (kLdsRecDoubles / 2)]);
+    };
+
+    for (int32_t r = 0; r < n_int; r += 2) {
+        EdgeRow e2 = pad_row(), e3 = pad_row();
+        if (r + 2 < n_int) e2 = load_row(nbr_tile, w, int64_t(row0) + r + 2, lane);
+        if (r + 3 < n_int) e3 = load_row(nbr_tile, w, int64_t(row0) + r + 3, lane);
+        add_edge(me, fm, neighbour(e0.code), e0, a0, a1, a2, a3, a4);
+        add_edge(me, fm, neighbour(e1.code), e1, a0, a1, a2, a3, a4);
+        e0 = e2; e1 = e3;
+    }
+
+    if ((classes & 6) && n_bnd > 0) {
+        const int32_t first_bnd = rows_int[slice];
+        for (int pass = 0; pass < 2; pass++) {
+            const int32_t want = pass == 0 ? kCodeWall : kCodeFar;
+            if (!(classes & (pass == 0 ? 2 : 4))) continue;
+            for (int32_t r = 0; r < n_bnd; r++) {
+                const int64_t row = int64_t(row0) + first_bnd + r;
+                if (nbr_tile[(row << 6) + lane] != want) continue;
+                const double *wr = w + (row << 8) + lane;
+                const double fx = wr[0], fy = wr[64], fz = wr[128];
+                if (pass == 0) {
+                    a0 += 0.0;
+                    a1 += fx * me.p;
+                    a2 += fy * me.p;
+                    a3 += fz * me.p;
+                    a4 += 0.0;
+                } else {
+                    a0 += fx * (ff.var[1] + me.mx) + fy * (ff.var[2] + me.my) + fz * (ff.var[3] + me.mz);
+                    a4 += fx * (ff.fc_de[0] + fm.ex) + fy * (ff.fc_de[1] + fm.ey) + fz * (ff.fc_de[2] + fm.ez);
+                    a1 += fx * (ff.fc_mx[0] + fm.xx) + fy * (ff.fc_mx[1] + fm.xy) + fz * (ff.fc_mx[2] + fm.xz);
+                    a2 += fx * (ff.fc_my[0] + fm.xy) + fy * (ff.fc_my[1] + fm.yy) + fz * (ff.fc_my[2] + fm.yz);
+                    a3 += fx * (ff.fc_mz[0] + fm.xz) + fy * (ff.fc_mz[1] + fm.yz) + fz * (ff.fc_mz[2] + fm.zz);
+                }
+            }
+        }
+    }
+
+    if (i < nel) {
         fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
         fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
     }
@@ -362,7 +571,8 @@ k_indirect_rw(int64_t nel, int64_t stride, const double *__restrict__ q, const i
 __global__ void __launch_bounds__(kBlock)
 k_time_step(int64_t nel, int64_t stride, double rk_div, const double *__restrict__ step_factors,
             double *__restrict__ fluxes, const double *__restrict__ old_variables, double *__restrict__ q,
-            const int32_t *__restrict__ old_of_new, unsigned long long *__restrict__ err, int check)
+            double *__restrict__ rec, const int32_t *__restrict__ old_of_new, unsigned long long *__restrict__ err,
+            int check)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
@@ -375,7 +585,9 @@ k_time_step(int64_t nel, int64_t stride, double rk_div, const double *__restrict
     store_conserved(q, stride, i, rho, mx, my, mz, en);
     fluxes[i] = 0.0; fluxes[stride + i] = 0.0; fluxes[2 * stride + i] = 0.0;
     fluxes[3 * stride + i] = 0.0; fluxes[4 * stride + i] = 0.0;
-    store_derived(q, stride, i, derive(rho, mx, my, mz, en));
+    const Derived d = derive(rho, mx, my, mz, en);
+    store_derived(q, stride, i, d);
+    store_record(rec, i, rho, mx, my, mz, en, d);
     if (check) {
         const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
         int code = 0;
@@ -530,28 +742,48 @@ k_prolong(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t *__r
 // ==========================================================================================
 static inline unsigned grid_for(int64_t n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); }
 
-void launch_init_variables(hipStream_t st, int64_t stride, const FarField &ff, double *q)
-{ hipLaunchKernelGGL(k_init_variables, dim3(grid_for(stride)), dim3(kBlock), 0, st, stride, ff, q); }
+void launch_init_variables(hipStream_t st, int64_t stride, const FarField &ff, double *q, double *rec)
+{ hipLaunchKernelGGL(k_init_variables, dim3(grid_for(stride)), dim3(kBlock), 0, st, stride, ff, q, rec); }
 
-void launch_derive(hipStream_t st, int64_t nel, int64_t stride, double *q)
-{ hipLaunchKernelGGL(k_derive, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q); }
+void launch_derive(hipStream_t st, int64_t nel, int64_t stride, double *q, double *rec)
+{ hipLaunchKernelGGL(k_derive, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, rec); }
 
-void launch_step_factor_local(hipStream_t st, int64_t nel, int64_t stride, double *q, const double *cbrt_vol,
+void launch_step_factor_local(hipStream_t st, int64_t nel, int64_t stride, double *q, double *rec, const double *cbrt_vol,
                               double *sf, unsigned long long *min_bits)
-{ hipLaunchKernelGGL(k_step_factor_local, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, cbrt_vol, sf, min_bits); }
+{ hipLaunchKernelGGL(k_step_factor_local, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, rec, cbrt_vol, sf, min_bits); }
 
 void launch_step_factor_apply(hipStream_t st, int64_t nel, const unsigned long long *min_bits,
                               const double *volumes, double *sf)
 { hipLaunchKernelGGL(k_step_factor_apply, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, min_bits, volumes, sf); }
 
-void launch_step_factor_legacy(hipStream_t st, int64_t nel, int64_t stride, double *q, const double *volumes, double *sf)
-{ hipLaunchKernelGGL(k_step_factor_legacy, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, volumes, sf); }
+void launch_step_factor_legacy(hipStream_t st, int64_t nel, int64_t stride, double *q, double *rec, const double *volumes, double *sf)
+{ hipLaunchKernelGGL(k_step_factor_legacy, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, rec, volumes, sf); }
 
-void launch_flux_gather(hipStream_t st, const DevicePlan &p, const double *q, const FarField &ff,
-                        double *fluxes, int classes, int accumulate)
+void launch_flux_gather(hipStream_t st, const DevicePlan &p, const double *q, const double *rec, const FarField &ff,
+                        double *fluxes, int classes, int accumulate, int variant)
 {
-    hipLaunchKernelGGL(k_flux_gather, dim3(grid_for(p.stride)), dim3(kBlock), 0, st, p.nel, p.stride, q,
-                       p.slice_row0, p.rows_int, p.rows_bnd, p.nbr, p.w, ff, fluxes, classes, accumulate);
+    const dim3 grid(grid_for(p.stride)), block(kBlock);
+#define MGCFD_TILE_LAUNCH(MINW)                                                                                \
+    hipLaunchKernelGGL((k_flux_tile<MINW>), dim3(p.n_tiles), block, 0, st, p.nel, p.stride, rec, p.slice_row0,  \
+                       p.rows_int, p.rows_bnd, p.nbr_tile, p.w, p.tile_halo_ptr, p.tile_halo, ff, fluxes,      \
+                       classes, accumulate)
+    if (variant == 0 || variant == 8) { MGCFD_TILE_LAUNCH(1); return; }
+    if (variant == 9) { MGCFD_TILE_LAUNCH(3); return; }
+#undef MGCFD_TILE_LAUNCH
+#define MGCFD_FLUX_LAUNCH(MINW, PIPE)                                                                          \
+    hipLaunchKernelGGL((k_flux_gather<MINW, PIPE>), grid, block, 0, st, p.nel, p.stride, q, p.slice_row0,      \
+                       p.rows_int, p.rows_bnd, p.nbr, p.w, ff, fluxes, classes, accumulate)
+    switch (variant) {
+        case 1: MGCFD_FLUX_LAUNCH(1, false); break;     // plain loop, compiler-chosen registers
+        case 2: MGCFD_FLUX_LAUNCH(5, false); break;
+        case 3: MGCFD_FLUX_LAUNCH(8, false); break;
+        case 4: MGCFD_FLUX_LAUNCH(1, true); break;      // software-pipelined
+        case 5: MGCFD_FLUX_LAUNCH(3, true); break;
+        case 6: MGCFD_FLUX_LAUNCH(4, true); break;
+        case 7: MGCFD_FLUX_LAUNCH(5, true); break;
+        default: MGCFD_FLUX_LAUNCH(1, true); break;
+    }
+#undef MGCFD_FLUX_LAUNCH
 }
 
 void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, double *fluxes)
@@ -561,11 +793,12 @@ void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, do
 }
 
 void launch_time_step(hipStream_t st, int64_t nel, int64_t stride, int j, const double *sf, double *fluxes,
-                      const double *old_variables, double *q, const int32_t *old_of_new, unsigned long long *err, int check)
+                      const double *old_variables, double *q, double *rec, const int32_t *old_of_new,
+                      unsigned long long *err, int check)
 {
     const double rk_div = double(3 + 1 - j);    // double(RK+1-j), cfd_loops.cpp:243
     hipLaunchKernelGGL(k_time_step, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, rk_div, sf, fluxes,
-                       old_variables, q, old_of_new, err, check);
+                       old_variables, q, rec, old_of_new, err, check);
 }
 
 void launch_check_invalid(hipStream_t st, int64_t nel, int64_t stride, const double *q, const int32_t *old_of_new,

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <deque>
 #include <queue>
 #include <stdexcept>
 #include <string>
@@ -97,6 +98,54 @@ std::vector<int32_t> cuthill_mckee(const Adjacency &g, int64_t nel)
     return order;   // order[new] = old
 }
 
+// Greedy graph-growing partition into compact clusters of kTile nodes: grow a breadth-first
+// ball from a seed until it holds kTile nodes; the nodes left on its frontier seed the next
+// clusters.  Consecutive chunks of kTile nodes of the returned order are the clusters.  A ball
+// of 256 nodes in a 3-D mesh has a few hundred neighbours outside it, against ~600 for 256
+// consecutive nodes of a breadth-first band — that halo is what a tile stages in LDS.
+std::vector<int32_t> cluster_order(const Adjacency &g, int64_t nel)
+{
+    std::vector<int32_t> order;
+    order.reserve(static_cast<size_t>(nel));
+    std::vector<char> state(static_cast<size_t>(nel), 0);      // 0 free, 1 taken, 2 queued in the current ball
+    std::deque<int32_t> seeds;
+    std::vector<int32_t> ball;
+    int64_t scan = 0;
+    while (static_cast<int64_t>(order.size()) < nel) {
+        int32_t seed = -1;
+        while (!seeds.empty()) {
+            int32_t c = seeds.front();
+            seeds.pop_front();
+            if (state[static_cast<size_t>(c)] == 0) { seed = c; break; }
+        }
+        if (seed < 0) {
+            while (state[static_cast<size_t>(scan)] != 0) scan++;
+            seed = static_cast<int32_t>(scan);
+        }
+        // fill one tile; if a component runs out first, continue from the next seed so every
+        // tile (but the last) holds exactly kTile nodes
+        const size_t tile_end = std::min<size_t>(static_cast<size_t>(nel), (order.size() / kTile + 1) * kTile);
+        ball.clear();
+        ball.push_back(seed);
+        state[static_cast<size_t>(seed)] = 2;
+        size_t head = 0;
+        while (head < ball.size() && order.size() < tile_end) {
+            const int32_t v = ball[head++];
+            state[static_cast<size_t>(v)] = 1;
+            order.push_back(v);
+            for (int32_t k = g.ptr[static_cast<size_t>(v)]; k < g.ptr[static_cast<size_t>(v) + 1]; k++) {
+                const int32_t u = g.idx[static_cast<size_t>(k)];
+                if (state[static_cast<size_t>(u)] == 0) { state[static_cast<size_t>(u)] = 2; ball.push_back(u); }
+            }
+        }
+        for (; head < ball.size(); head++) {                   // frontier left over: future seeds
+            state[static_cast<size_t>(ball[head])] = 0;
+            seeds.push_back(ball[head]);
+        }
+    }
+    return order;
+}
+
 inline double inv_distance(const double *p, const double *q)
 {
     const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
@@ -162,7 +211,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                       const PlanOptions &opt, LevelPlan &P)
 {
     const int64_t nel = L.nel;
-    if (nel <= 0 || nel >= (int64_t(1) << 30)) throw std::runtime_error("level size out of range for 30-bit node ids");
+    if (nel <= 0 || nel >= (int64_t(1) << 29)) throw std::runtime_error("level size out of range for 29-bit node ids");
     for (int64_t e = L.internal_start; e < L.internal_start + L.n_internal; e++)
         if (edges[e].a < 0 || edges[e].a >= nel || edges[e].b < 0 || edges[e].b >= nel)
             throw std::runtime_error("internal edge " + std::to_string(e) + " has an end point outside [0, nel)");
@@ -176,15 +225,16 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
 
     // ---- node order ----
     std::vector<int32_t> order;
-    if (opt.renumber) order = cuthill_mckee(g, nel);
+    if (opt.ordering == 2) order = cluster_order(g, nel);
+    else if (opt.ordering == 1) order = cuthill_mckee(g, nel);
     else { order.resize(static_cast<size_t>(nel)); std::iota(order.begin(), order.end(), 0); }
     std::vector<int32_t> bnd_count(static_cast<size_t>(nel), 0);
     for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++) bnd_count[static_cast<size_t>(edges[e].b)]++;
     for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++) bnd_count[static_cast<size_t>(edges[e].b)]++;
-    if (opt.degree_sort_window > kSlice) {
-        // Inside each window sort by (internal degree, boundary faces) so the 64 nodes of a
-        // slice have equal row counts and ELL padding stays small; windows keep locality.
-        const int64_t W = opt.degree_sort_window;
+    if (opt.degree_sort) {
+        // Inside each tile sort by (internal degree, boundary faces) so the 64 nodes of a
+        // slice have equal row counts and ELL padding stays small; tile membership is kept.
+        const int64_t W = kTile;
         for (int64_t s = 0; s < nel; s += W) {
             auto b = order.begin() + s, e = order.begin() + std::min(nel, s + W);
             std::stable_sort(b, e, [&](int32_t x, int32_t y) {
@@ -200,7 +250,8 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     for (int64_t n = 0; n < nel; n++) P.new_of_old[static_cast<size_t>(order[static_cast<size_t>(n)])] = static_cast<int32_t>(n);
 
     // ---- slice geometry ----
-    P.n_slices = static_cast<int32_t>((nel + kSlice - 1) / kSlice);
+    P.n_tiles = static_cast<int32_t>((nel + kTile - 1) / kTile);
+    P.n_slices = P.n_tiles * (kTile / kSlice);          // the last tile may end in empty slices
     P.rows_int.assign(static_cast<size_t>(P.n_slices), 0);
     P.rows_bnd.assign(static_cast<size_t>(P.n_slices), 0);
     for (int64_t n = 0; n < nel; n++) {
@@ -248,6 +299,50 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     };
     for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++) add_face(edges[static_cast<size_t>(e)], kCodeWall, 1.0);
     for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++) add_face(edges[static_cast<size_t>(e)], kCodeFar, 0.5);
+
+    // ---- tiles: halo lists and tile-local neighbour codes ----
+    P.nbr_tile.assign(P.nbr.size(), kCodePad);
+    P.tile_halo_ptr.assign(static_cast<size_t>(P.n_tiles) + 1, 0);
+    P.tile_halo.clear();
+    {
+        std::vector<int32_t> halo;
+        const int32_t halo_cap = kTileCap - kTile;
+        int64_t halo_total = 0;
+        for (int32_t t = 0; t < P.n_tiles; t++) {
+            const int32_t base = t * kTile;
+            const int32_t s0 = t * (kTile / kSlice), s1 = s0 + kTile / kSlice;
+            const int64_t e0 = int64_t(P.slice_row0[static_cast<size_t>(s0)]) * kSlice;
+            const int64_t e1 = int64_t(P.slice_row0[static_cast<size_t>(s1)]) * kSlice;
+            halo.clear();
+            for (int64_t e = e0; e < e1; e++) {
+                const int32_t code = P.nbr[static_cast<size_t>(e)];
+                if (code < 0) continue;
+                const int32_t id = code & kIdMask;
+                if (id < base || id >= base + kTile) halo.push_back(id);
+            }
+            std::sort(halo.begin(), halo.end());
+            halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
+            const int32_t staged = std::min<int32_t>(static_cast<int32_t>(halo.size()), halo_cap);
+            halo_total += static_cast<int64_t>(halo.size());
+            P.halo_max = std::max<int32_t>(P.halo_max, static_cast<int32_t>(halo.size()));
+            for (int64_t e = e0; e < e1; e++) {
+                const int32_t code = P.nbr[static_cast<size_t>(e)];
+                if (code < 0) { P.nbr_tile[static_cast<size_t>(e)] = code; continue; }
+                const int32_t id = code & kIdMask, role = code & kRoleB;
+                int32_t local;
+                if (id >= base && id < base + kTile) local = id - base;
+                else {
+                    const int32_t pos = static_cast<int32_t>(std::lower_bound(halo.begin(), halo.end(), id) - halo.begin());
+                    if (pos < staged) local = kTile + pos;
+                    else { local = id | kTileGlobal; P.halo_overflow_refs++; }
+                }
+                P.nbr_tile[static_cast<size_t>(e)] = local | role;
+            }
+            P.tile_halo.insert(P.tile_halo.end(), halo.begin(), halo.begin() + staged);
+            P.tile_halo_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(P.tile_halo.size());
+        }
+        P.halo_mean = P.n_tiles ? double(halo_total) / double(P.n_tiles) : 0.0;
+    }
 
     P.n_internal_entries = useful;
     int64_t int_slots = 0;

@@ -19,10 +19,14 @@
 namespace mgcfd {
 
 constexpr int kSlice = 64;   // wavefront width
+constexpr int kTile = 256;   // nodes per tile = one 256-thread workgroup = 4 slices
+constexpr int kTileCap = 560;   // node records a tile can stage in LDS (560 * 96 B = 52.5 KiB => 3 tiles per CU)
 
 // neighbour codes in Sell::nbr
 constexpr int32_t kRoleB = 1 << 30;     // set when THIS node is the edge's 'b' end (else it is 'a')
 constexpr int32_t kIdMask = kRoleB - 1;
+constexpr int32_t kTileGlobal = 1 << 29;   // tile codes only: id is a global node id (halo beyond the LDS capacity)
+constexpr int32_t kTileIdMask = kTileGlobal - 1;
 constexpr int32_t kCodeWall = -1;       // reference neighbour code -1: solid wall   ("boundary" edges)
 constexpr int32_t kCodeFar = -2;        // reference neighbour code -2: far field    ("wall" edges)
 constexpr int32_t kCodePad = -3;
@@ -40,6 +44,13 @@ struct LevelPlan {
     std::vector<int32_t> rows_int;     // [n_slices] rows holding internal edges
     std::vector<int32_t> rows_bnd;     // [n_slices] rows holding boundary/far-field faces (after the internal rows)
     std::vector<int32_t> nbr;          // [rows*64] neighbour (new id | role bit) or a kCode*
+    // ---- tiles: 256 consecutive nodes staged in LDS together with their halo ----
+    int32_t n_tiles = 0;
+    std::vector<int32_t> tile_halo_ptr;   // [n_tiles+1]
+    std::vector<int32_t> tile_halo;       // global new ids of the halo nodes a tile stages (ascending, <= kTileCap-kTile each)
+    std::vector<int32_t> nbr_tile;        // [rows*64] as nbr, but ids are tile-local LDS slots (own 0..255, halo 256..)
+                                          //            or global ids flagged kTileGlobal when the halo overflows the LDS
+    double halo_mean = 0.0; int32_t halo_max = 0; int64_t halo_overflow_refs = 0;
     std::vector<EdgeW> w;              // [rows*64]
     //   internal, this node = a:  (x,y,z) = -0.5*e   k = -|e|*smoothing*0.5   (flux_kernel.elemfunc.c:130-140)
     //   internal, this node = b:  (x,y,z) = +0.5*e   k = same
@@ -59,8 +70,10 @@ struct LevelPlan {
 };
 
 struct PlanOptions {
-    int degree_sort_window = 1024;     // nodes per window inside which nodes are sorted by degree (0 = off)
-    bool renumber = true;
+    // 0: keep the caller's numbering; 1: breadth-first (Cuthill-McKee) bands; 2: compact clusters of
+    // kTile nodes grown greedily over the mesh graph (smallest halo per tile; default)
+    int ordering = 2;
+    bool degree_sort = true;           // inside each tile, sort nodes by degree (less ELL padding per slice)
 };
 
 // `edges` are the level's final edge weights (after adjust/dampen).  coarse_new_of_old is

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -55,6 +57,7 @@ struct DeviceLevel {
     LevelPlan plan;                      // host copy (permutations for get/set)
     DevicePlan dp;
     // SoA state, stride = dp.stride: q = 11 fields (0-4 = the reference's `variables`, 5-10 derived)
+    double *rec = nullptr;               // [stride][16] AoS node records read by the flux kernels
     double *q = nullptr, *old_variables = nullptr, *fluxes = nullptr, *residuals = nullptr;   // [5|11][stride]
     double *step_factors = nullptr, *volumes = nullptr, *cbrt_vol = nullptr;                  // [stride]
     unsigned long long *min_bits = nullptr;
@@ -140,8 +143,8 @@ struct mgcfd_solver {
     void ensure_nodeq(DeviceLevel &lv)
     {
         if (!lv.nodeq_stale) return;
-        if (opt_exact) exact::launch_derive(stream, lv.info.nel, lv.dp.stride, lv.q);
-        else fast::launch_derive(stream, lv.info.nel, lv.dp.stride, lv.q);
+        if (opt_exact) exact::launch_derive(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec);
+        else fast::launch_derive(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec);
         lv.nodeq_stale = false;
     }
     void op_copy_old(int l)
@@ -153,8 +156,8 @@ struct mgcfd_solver {
     {
         DeviceLevel &lv = level(l);
         HIP_CHECK(hipMemsetAsync(lv.min_bits, 0x7F, sizeof(unsigned long long), stream));
-        if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits);
-        else fast::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits);
+        if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec, lv.cbrt_vol, lv.step_factors, lv.min_bits);
+        else fast::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec, lv.cbrt_vol, lv.step_factors, lv.min_bits);
         lv.nodeq_stale = false;
     }
     void op_step_factor_apply(int l)
@@ -168,8 +171,8 @@ struct mgcfd_solver {
         DeviceLevel &lv = level(l);
         Timed t(this, l, MGCFD_LOOP_COMPUTE_STEP);
         if (mesh_variant == MGCFD_MESH_FVCORR) {
-            if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors);
-            else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors);
+            if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec, lv.volumes, lv.step_factors);
+            else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec, lv.volumes, lv.step_factors);
             lv.nodeq_stale = false;
         } else {
             op_step_factor_local(l);
@@ -184,8 +187,8 @@ struct mgcfd_solver {
         ensure_nodeq(lv);
         Timed t(this, l, MGCFD_LOOP_FLUX, (classes & 1) != 0);
         const int accumulate = lv.fluxes_zero ? 0 : 1;     // 0.0 + x: same bits either way
-        if (opt_exact) exact::launch_flux_gather(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate);
-        else fast::launch_flux_gather(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate);
+        if (opt_exact) exact::launch_flux_gather(stream, lv.dp, lv.q, lv.rec, ff, lv.fluxes, classes, accumulate, opt_variant);
+        else fast::launch_flux_gather(stream, lv.dp, lv.q, lv.rec, ff, lv.fluxes, classes, accumulate, opt_variant);
         lv.fluxes_zero = false;
         if (classes & 1) lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
     }
@@ -210,8 +213,8 @@ struct mgcfd_solver {
         if (j < 0 || j >= MGCFD_RK) throw std::invalid_argument("RK stage out of range");
         DeviceLevel &lv = level(l);
         Timed t(this, l, MGCFD_LOOP_TIME_STEP);
-        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check);
-        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check);
+        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.rec, lv.dp.old_of_new, err, opt_check);
+        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.rec, lv.dp.old_of_new, err, opt_check);
         lv.nodeq_stale = false;
         lv.fluxes_zero = true;
         lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
@@ -275,7 +278,7 @@ mgcfd_solver::~mgcfd_solver()
     for (auto &p : pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto e : free_events) (void)hipEventDestroy(e);
     for (auto &lv : L) {
-        void *ptrs[] = {lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
+        void *ptrs[] = {lv.rec, lv.dp.nbr_tile, lv.dp.tile_halo_ptr, lv.dp.tile_halo, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
                         lv.cbrt_vol, lv.min_bits, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.pro,
                         lv.dp.pro_parent, lv.dp.pro_wsum};
@@ -316,6 +319,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
 
     s->L.resize(static_cast<size_t>(nlevels));
     PlanOptions popt;
+    if (const char *o = std::getenv("MGCFD_ORDERING")) popt.ordering = std::atoi(o);   // diagnostic override
     // host-side plans first (coarse permutations are needed by the fine level's transfer plan)
     for (int l = 0; l < nlevels; l++) {
         const mgcfd_level_desc &d = levels[l];
@@ -327,6 +331,10 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.edges.assign(d.edges, d.edges + d.n_edges);
         adjust_and_dampen(d, mesh_variant, lv.edges);
         build_level_plan(d, lv.edges, popt, lv.plan);
+        if (std::getenv("MGCFD_VERBOSE"))
+            std::fprintf(stderr, "[mgcfd] level %d: %ld nodes, %d tiles, halo mean %.0f max %d (cap %d), overflow refs %ld, ELL padding %.1f%%\n",
+                         l, (long)d.nel, lv.plan.n_tiles, lv.plan.halo_mean, lv.plan.halo_max, kTileCap - kTile,
+                         (long)lv.plan.halo_overflow_refs, 100.0 * lv.plan.pad_fraction);
     }
     for (int l = 0; l + 1 < nlevels; l++) {
         const mgcfd_level_desc &d = levels[l];
@@ -353,6 +361,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.volumes = dev_upload(vol);
         lv.cbrt_vol = dev_upload(cb);
         lv.q = dev_alloc<double>(static_cast<size_t>(stride) * kNumStateFields);
+        lv.rec = dev_alloc<double>(static_cast<size_t>(stride) * 16);
         lv.old_variables = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.fluxes = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.residuals = dev_alloc<double>(static_cast<size_t>(stride) * 5);
@@ -382,6 +391,11 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
             lv.dp.w = dev_upload(ws);
         }
         lv.dp.old_of_new = dev_upload(P.old_of_new);
+        lv.dp.n_tiles = P.n_tiles;
+        lv.dp.nbr_tile = dev_upload(P.nbr_tile);
+        lv.dp.tile_halo_ptr = dev_upload(P.tile_halo_ptr);
+        lv.dp.tile_halo = dev_upload(P.tile_halo);
+        lv.plan.nbr_tile.clear(); lv.plan.nbr_tile.shrink_to_fit();
         if (lv.has_transfer) {
             lv.dp.child_ptr = dev_upload(P.child_ptr);
             lv.dp.child = dev_upload(P.child);
@@ -398,7 +412,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * stride, s->stream));
         HIP_CHECK(hipMemsetAsync(lv.residuals, 0, sizeof(double) * 5 * stride, s->stream));
         HIP_CHECK(hipMemsetAsync(lv.step_factors, 0, sizeof(double) * stride, s->stream));
-        exact::launch_init_variables(s->stream, stride, s->ff, lv.q);
+        exact::launch_init_variables(s->stream, stride, s->ff, lv.q, lv.rec);
     }
     HIP_CHECK(hipStreamSynchronize(s->stream));
     HIP_CHECK(hipGetLastError());
@@ -763,6 +777,34 @@ int mgcfd_get_flux_kernel_time(mgcfd_solver *s, int level, double *avg_seconds, 
         DeviceLevel &lv = s->level(level);
         *launches = lv.flux_launches;
         *avg_seconds = lv.flux_launches ? lv.flux_time / double(lv.flux_launches) : 0.0;
+    });
+}
+
+// Diagnostic: time `launches` back-to-back flux launches (all classes, from zero) between two
+// hipEvents on the solver's stream; the state is left as after one compute_fluxes call.
+int mgcfd_bench_flux(mgcfd_solver *s, int level, int launches, double *avg_seconds)
+{
+    REQUIRE(s); REQUIRE(avg_seconds);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        s->ensure_nodeq(lv);
+        hipEvent_t a = s->get_event(), b = s->get_event();
+        auto go = [&] {
+            if (s->opt_exact) exact::launch_flux_gather(s->stream, lv.dp, lv.q, lv.rec, s->ff, lv.fluxes, 7, 0, s->opt_variant);
+            else fast::launch_flux_gather(s->stream, lv.dp, lv.q, lv.rec, s->ff, lv.fluxes, 7, 0, s->opt_variant);
+        };
+        go();
+        HIP_CHECK(hipEventRecord(a, s->stream));
+        for (int k = 0; k < launches; k++) go();
+        HIP_CHECK(hipEventRecord(b, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        s->free_events.push_back(a);
+        s->free_events.push_back(b);
+        lv.fluxes_zero = false;
+        *avg_seconds = launches > 0 ? double(ms) * 1e-3 / launches : 0.0;
     });
 }
 

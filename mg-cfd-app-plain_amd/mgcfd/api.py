@@ -88,6 +88,7 @@ _SIGNATURES = [
     ("mgcfd_get_loop_times", C.c_int, [_vp, C.c_int, _vp]),
     ("mgcfd_reset_monitoring", C.c_int, [_vp]),
     ("mgcfd_get_flux_kernel_time", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    ("mgcfd_bench_flux", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_step_factor_local", C.c_int, [_vp, C.c_int]),
     ("mgcfd_step_factor_min_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_step_factor_apply", C.c_int, [_vp, C.c_int]),
@@ -339,6 +340,11 @@ class Solver:
         n = _i64()
         self._c(self.lib.mgcfd_get_flux_kernel_time(self.handle, l, C.byref(t), C.byref(n)))
         return t.value, n.value
+
+    def bench_flux(self, l: int, launches: int) -> float:
+        t = C.c_double()
+        self._c(self.lib.mgcfd_bench_flux(self.handle, l, launches, C.byref(t)))
+        return t.value
 
     # ---- multi-GPU hooks ----
     def step_factor_local(self, l): self._c(self.lib.mgcfd_step_factor_local(self.handle, l))

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Launch only the flux-gather kernel N times on the bench workload (for rocprofv3 --pmc runs)."""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd")); sys.path.insert(0, ROOT)
+import bench, mgcfd
+ap = argparse.ArgumentParser()
+ap.add_argument("--lattice", type=int, default=67)
+ap.add_argument("--variant", type=int, default=0)
+ap.add_argument("--launches", type=int, default=20)
+ap.add_argument("--fast", action="store_true")
+a = ap.parse_args()
+mg, levels = bench.build_workload(a.lattice)
+s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+s.set(0, "variables", bench.perturbed_state(s.nel(0), s.far_field()[:5]))
+s.set_option("exact", 0 if a.fast else 1)
+s.set_option("flux_variant", a.variant)
+print("avg us", s.bench_flux(0, a.launches) * 1e6)

@@ -8,11 +8,10 @@
 
 namespace mgcfd {
 
-// Node-state fields per level, stored structure-of-arrays with a common padded stride
-// (stride = 64 * n_slices): q[f*stride + i], f = 0..4 conserved variables (the reference's
-// `variables`), f = 5..10 the quantities the reference derives from them for every incident
-// edge (velocity, pressure, |v|, speed of sound; cfd_loops.h:121-148).
-constexpr int kNumStateFields = 11;
+// Per-node arrays are stored structure-of-arrays with a common padded stride
+// (stride = 256 * n_tiles): q[f*stride + i], f = 0..4 = the reference's `variables[i*5 + f]`;
+// likewise old_variables, fluxes, residuals.
+constexpr int kNumStateFields = 5;
 static_assert(sizeof(EdgeW) == 32, "EdgeW must be 32 bytes");
 static_assert(sizeof(ProlongW) == 24, "ProlongW must be 24 bytes");
 
@@ -25,12 +24,13 @@ struct FarField {
 // Device pointers of one level's gather plan.
 struct DevicePlan {
     int64_t nel = 0;
-    int64_t stride = 0;                 // 64 * n_slices
+    int64_t stride = 0;                 // 256 * n_tiles
     int32_t n_slices = 0;
     int32_t *slice_row0 = nullptr, *rows_int = nullptr, *rows_bnd = nullptr, *nbr = nullptr;
-    double *w = nullptr;                // [row][4 components][64 lanes]
+    double *w = nullptr;                // [row][3 components][64 lanes]: signed, halved edge weights
     int32_t n_tiles = 0;
-    int32_t *nbr_tile = nullptr, *tile_halo_ptr = nullptr, *tile_halo = nullptr;
+    uint16_t *nbr16 = nullptr;          // [row][64 lanes] tile-local codes
+    int32_t *tile_halo_ptr = nullptr, *tile_halo = nullptr, *tile_ovf_ptr = nullptr, *tile_ovf = nullptr;
     int32_t *old_of_new = nullptr;
     // transfer to/from the next-coarser level
     int32_t *child_ptr = nullptr, *child = nullptr;

@@ -7,16 +7,19 @@
 //   -DMGCFD_KERNEL_NS=fast  -ffp-contract=fast  same code, FMA contraction allowed
 //
 // Design: there is no dense contraction here, so no MFMA; every loop is a
-// node-centred sweep with one lane per node.
-//   * flux_gather   replaces the reference's edge loop + scatter-add
+// node-centred sweep with one lane per node, over structure-of-arrays state
+// (field f of node i at q[f*stride + i]) so that per-node accesses coalesce perfectly.
+//   * flux_tile     replaces the reference's edge loop + scatter-add
 //                   (src/Kernels/flux_loops.cpp:133-136, flux_kernel.elemfunc.c) by a per-node
-//                   gather over a sliced-ELLPACK incidence list: coalesced 36 B/entry streams,
-//                   structure-of-arrays node state gathered field by field, a sequential
-//                   per-node sum in the reference's order, no atomics, no colouring, deterministic.
-//   * The division / square-root work (8 div + 5 sqrt per edge in the reference) is hoisted to
-//     one per-node "derive" (3 div + 2 sqrt per node) that is fused into the kernels that
-//     produce `variables` (step factor, time step); values are identical because the
-//     reference recomputes the very same per-node expressions for every incident edge.
+//                   GATHER: a 256-thread workgroup owns a compact cluster of 256 nodes, stages
+//                   their state and their halo's state into an LDS tile (each node fetched once
+//                   per tile instead of once per incident edge), and every lane then walks its
+//                   incidence rows (sliced ELLPACK, 26 B per entry, coalesced) and sums the
+//                   edge fluxes in the reference's order — no atomics, no colouring,
+//                   deterministic, bit-identical.
+//   * The division / square-root work (8 div + 5 sqrt per edge in the reference) is done once
+//     per STAGED node while the tile is filled (3 div + 2 sqrt); values are identical because
+//     the reference recomputes the very same per-node expressions for every incident edge.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -51,21 +54,22 @@ __device__ __forceinline__ Derived derive(double rho, double mx, double my, doub
     return d;
 }
 
-// Node state is stored structure-of-arrays: field f of node i lives at q[f*stride + i]
-// (fields: 0 rho, 1 mx, 2 my, 3 mz, 4 en | 5 vx, 6 vy, 7 vz, 8 p, 9 |v|, 10 c).  A wavefront's
-// own-node accesses are then perfectly coalesced, and — because the plan numbers nodes
-// breadth-first — the r-th neighbours of 64 consecutive nodes are nearly consecutive too, so
-// each 8-byte gather instruction touches a handful of cache lines instead of 64.
+// What the flux needs of one node: the 5 conserved variables plus what the reference derives
+// from them for every incident edge.
 struct NodeQ { double rho, mx, my, mz, en, vx, vy, vz, p, speed, c; };
 
-__device__ __forceinline__ void store_derived(double *__restrict__ q, int64_t stride, int64_t i, const Derived &d)
+__device__ __forceinline__ NodeQ make_nodeq(double rho, double mx, double my, double mz, double en)
 {
-    q[5 * stride + i] = d.vx;
-    q[6 * stride + i] = d.vy;
-    q[7 * stride + i] = d.vz;
-    q[8 * stride + i] = d.p;
-    q[9 * stride + i] = d.speed;
-    q[10 * stride + i] = d.c;
+    const Derived d = derive(rho, mx, my, mz, en);
+    NodeQ r;
+    r.rho = rho; r.mx = mx; r.my = my; r.mz = mz; r.en = en;
+    r.vx = d.vx; r.vy = d.vy; r.vz = d.vz; r.p = d.p; r.speed = d.speed; r.c = d.c;
+    return r;
+}
+
+__device__ __forceinline__ NodeQ load_and_derive(const double *__restrict__ q, int64_t stride, int64_t i)
+{
+    return make_nodeq(q[i], q[stride + i], q[2 * stride + i], q[3 * stride + i], q[4 * stride + i]);
 }
 
 __device__ __forceinline__ void store_conserved(double *__restrict__ q, int64_t stride, int64_t i, double rho,
@@ -78,46 +82,23 @@ __device__ __forceinline__ void store_conserved(double *__restrict__ q, int64_t 
     q[4 * stride + i] = en;
 }
 
-__device__ __forceinline__ NodeQ load_nodeq(const double *__restrict__ q, int64_t stride, int64_t i)
+// LDS tile records: 12 doubles (96 B) per staged node, read back with 16-byte LDS loads.
+constexpr int kLdsRecD2 = 6;               // double2 per record
+
+__device__ __forceinline__ void lds_store_record(double2 *rec, const NodeQ &n)
 {
-    NodeQ r;
-    r.rho = q[i];
-    r.mx = q[stride + i];
-    r.my = q[2 * stride + i];
-    r.mz = q[3 * stride + i];
-    r.en = q[4 * stride + i];
-    r.vx = q[5 * stride + i];
-    r.vy = q[6 * stride + i];
-    r.vz = q[7 * stride + i];
-    r.p = q[8 * stride + i];
-    r.speed = q[9 * stride + i];
-    r.c = q[10 * stride + i];
-    return r;
+    rec[0] = make_double2(n.rho, n.mx);
+    rec[1] = make_double2(n.my, n.mz);
+    rec[2] = make_double2(n.en, n.vx);
+    rec[3] = make_double2(n.vy, n.vz);
+    rec[4] = make_double2(n.p, n.speed);
+    rec[5] = make_double2(n.c, 0.0);
 }
 
-// The flux kernels read node state as array-of-structures RECORDS instead: one 128-byte,
-// line-aligned record per node (11 doubles + padding), so that staging a halo node into LDS
-// costs exactly one cache-line access.
-constexpr int kRecDoubles = 16;            // 128 B in global memory
-constexpr int kLdsRecDoubles = 12;         // 96 B in LDS (padding dropped)
-
-__device__ __forceinline__ void store_record(double *__restrict__ rec, int64_t i, double rho, double mx, double my,
-                                             double mz, double en, const Derived &d)
+__device__ __forceinline__ NodeQ lds_load_record(const double2 *rec)
 {
-    double2 *dst = reinterpret_cast<double2 *>(rec + i * kRecDoubles);
-    dst[0] = make_double2(rho, mx);
-    dst[1] = make_double2(my, mz);
-    dst[2] = make_double2(en, d.vx);
-    dst[3] = make_double2(d.vy, d.vz);
-    dst[4] = make_double2(d.p, d.speed);
-    dst[5] = make_double2(d.c, 0.0);
-}
-
-template <typename P> __device__ __forceinline__ NodeQ load_record(P base)
-{
-    // base points at 6 x double2 (global or LDS)
-    const double2 a = base[0], b = base[1], c = base[2], d = base[3], e = base[4];
-    const double f = reinterpret_cast<const double *>(base)[10];
+    const double2 a = rec[0], b = rec[1], c = rec[2], d = rec[3], e = rec[4];
+    const double f = reinterpret_cast<const double *>(rec)[10];
     NodeQ r;
     r.rho = a.x; r.mx = a.y; r.my = b.x; r.mz = b.y; r.en = c.x; r.vx = c.y;
     r.vy = d.x; r.vz = d.y; r.p = e.x; r.speed = e.y; r.c = f;
@@ -156,63 +137,44 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-} // namespace
-
 // XCD-aware block order: hardware deals consecutive workgroups round-robin over the 8 XCDs
-// (each with a private L2).  Give every XCD one CONTIGUOUS range of slices instead, so the
-// neighbour windows of the blocks sharing an L2 overlap and node state is fetched from the
-// Infinity Cache / HBM about once, not eight times.  Pure speed: any placement is correct.
+// (each with a private L2).  Give every XCD one CONTIGUOUS range of tiles instead, so that a
+// tile's halo — owned by neighbouring tiles — is usually already in the same L2.  Pure speed:
+// any placement is correct.
 __device__ __forceinline__ unsigned xcd_contiguous_block(unsigned b, unsigned nb)
 {
     const unsigned q = nb >> 3, r = nb & 7u, x = b & 7u, k = b >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+} // namespace
+
 // ------------------------------------------------------------------------------------------
-// initialize_variables (cfd_loops.h:44-55) + first derive.  Runs over the padded length so
-// the tail of every field holds valid numbers.
+// initialize_variables (cfd_loops.h:44-55).  Runs over the padded length so the tail of every
+// field holds valid numbers.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_init_variables(int64_t stride, FarField ff, double *__restrict__ q, double *__restrict__ rec)
+k_init_variables(int64_t stride, FarField ff, double *__restrict__ q)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= stride) return;
     store_conserved(q, stride, i, ff.var[0], ff.var[1], ff.var[2], ff.var[3], ff.var[4]);
-    const Derived d = derive(ff.var[0], ff.var[1], ff.var[2], ff.var[3], ff.var[4]);
-    store_derived(q, stride, i, d);
-    store_record(rec, i, ff.var[0], ff.var[1], ff.var[2], ff.var[3], ff.var[4], d);
-}
-
-// conserved -> derived fields (after restrict / prolong / set_array changed variables)
-__global__ void __launch_bounds__(kBlock)
-k_derive(int64_t nel, int64_t stride, double *__restrict__ q, double *__restrict__ rec)
-{
-    const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
-    if (i >= nel) return;
-    const double rho = q[i], mx = q[stride + i], my = q[2 * stride + i], mz = q[3 * stride + i], en = q[4 * stride + i];
-    const Derived d = derive(rho, mx, my, mz, en);
-    store_derived(q, stride, i, d);
-    store_record(rec, i, rho, mx, my, mz, en, d);
 }
 
 // ------------------------------------------------------------------------------------------
 // compute_step_factor, first half (cfd_loops.cpp:98-125): sf = 0.5 * cbrt(vol) / (|v| + c) and
 // the minimum over the level.  cbrt(vol) is static and precomputed on the host with the same
-// libm the reference would call.  Also refreshes the derived fields (same expressions).
+// libm the reference would call.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_step_factor_local(int64_t nel, int64_t stride, double *__restrict__ q, double *__restrict__ rec,
-                    const double *__restrict__ cbrt_vol, double *__restrict__ step_factors,
-                    unsigned long long *__restrict__ min_bits)
+k_step_factor_local(int64_t nel, int64_t stride, const double *__restrict__ q, const double *__restrict__ cbrt_vol,
+                    double *__restrict__ step_factors, unsigned long long *__restrict__ min_bits)
 {
     __shared__ double s_min[kBlock / 64];
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     double sf = __longlong_as_double(0x7F7F7F7F7F7F7F7FLL);
     if (i < nel) {
-        const double rho = q[i], mx = q[stride + i], my = q[2 * stride + i], mz = q[3 * stride + i], en = q[4 * stride + i];
-        const Derived d = derive(rho, mx, my, mz, en);
-        store_derived(q, stride, i, d);
-        store_record(rec, i, rho, mx, my, mz, en, d);
+        const Derived d = derive(q[i], q[stride + i], q[2 * stride + i], q[3 * stride + i], q[4 * stride + i]);
         const double dt = cbrt_vol[i] / (d.speed + d.c);
         sf = 0.5 * dt;
         step_factors[i] = sf;
@@ -241,72 +203,73 @@ k_step_factor_apply(int64_t nel, const unsigned long long *__restrict__ min_bits
 
 // compute_step_factor_legacy (cfd_loops.cpp:37-61), mesh_name = fvcorr only
 __global__ void __launch_bounds__(kBlock)
-k_step_factor_legacy(int64_t nel, int64_t stride, double *__restrict__ q, double *__restrict__ rec,
-                     const double *__restrict__ volumes, double *__restrict__ step_factors)
+k_step_factor_legacy(int64_t nel, int64_t stride, const double *__restrict__ q, const double *__restrict__ volumes,
+                     double *__restrict__ step_factors)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
-    const double rho = q[i], mx = q[stride + i], my = q[2 * stride + i], mz = q[3 * stride + i], en = q[4 * stride + i];
-    const Derived d = derive(rho, mx, my, mz, en);
-    store_derived(q, stride, i, d);
-    store_record(rec, i, rho, mx, my, mz, en, d);
+    const Derived d = derive(q[i], q[stride + i], q[2 * stride + i], q[3 * stride + i], q[4 * stride + i]);
     step_factors[i] = 0.5 / (sqrt(volumes[i]) * (d.speed + d.c));
 }
 
 // ------------------------------------------------------------------------------------------
-// flux_gather: compute_flux_edge + compute_boundary_flux_edge + compute_wall_flux_edge
-// (flux_loops.cpp:10-153) as one node-centred gather.  One lane = one node, one wave = one
-// slice of the sliced-ELL plan.  `classes` selects which edge classes take part
-// (bit0 internal, bit1 solid wall "-1", bit2 far field "-2"); `accumulate` != 0 starts from the
-// value already in `fluxes` (the reference's "+=" when the array is not known to be zero).
-// Entry e = row*64 + lane; edge weights are stored [row][component][lane].
+// flux_tile: compute_flux_edge + compute_boundary_flux_edge + compute_wall_flux_edge
+// (flux_loops.cpp:10-153) as one node-centred gather served from an LDS tile.
 //
-// The level has only ~4.6 waves per SIMD of work (300K nodes / 64 / 1024 SIMDs), so latency
-// cannot be hidden by occupancy alone: the PIPE form software-pipelines the row loop —
-// neighbour ids and weights are fetched two rows ahead, the neighbour's state one row ahead —
-// and rows are still accumulated strictly in order (bit-exactness needs the reference's
-// summation order, not its instruction order).
+// One 256-thread workgroup = one tile = 256 consecutive nodes forming a compact cluster of
+// the mesh graph (preprocess.cpp: cluster_order).  Phase 1: every staged node — the 256 own
+// nodes (coalesced loads) and the tile's halo, the few hundred outside nodes its edges touch
+// (gathered by id) — has its 5 conserved variables read from HBM ONCE, its velocity, pressure,
+// |v| and speed of sound derived (cfd_loops.h:121-148) and the 11 values written to LDS as one
+// 96-byte record.  Phase 2: every lane walks the incidence rows of its node (sliced ELLPACK:
+// row r of a wave = the r-th incident edge of its 64 nodes, stored contiguously: a 16-bit
+// tile-local neighbour slot and the 3 signed, halved edge-weight components = 26 B per entry),
+// reads the neighbour's record from LDS and adds the edge flux.  Rows are in ORIGINAL edge
+// order, internal edges first, then solid-wall faces, then far-field faces — exactly the order
+// in which the reference's serial loops add into fluxes[node] — so the per-node sequential sum
+// reproduces the reference's floating-point result bit for bit (exact build).
+//
+// `classes` selects the edge classes (bit0 internal, bit1 solid wall "-1", bit2 far field
+// "-2"); `accumulate` != 0 starts from the value already in `fluxes` (the reference's "+=" when
+// the array is not known to be zero).  Halo nodes beyond the LDS capacity (ragged clusters
+// only) are listed in a per-tile overflow table and read straight from HBM.
 // ------------------------------------------------------------------------------------------
-struct EdgeRow { int32_t code; double fx, fy, fz, k; };
+struct EdgeRow { uint32_t code; double fx, fy, fz; };
 
-__device__ __forceinline__ EdgeRow load_row(const int32_t *__restrict__ nbr, const double *__restrict__ w,
+__device__ __forceinline__ EdgeRow load_row(const uint16_t *__restrict__ nbr, const double *__restrict__ w,
                                             int64_t row, int lane)
 {
     EdgeRow e;
     e.code = nbr[(row << 6) + lane];
-    const double *wr = w + (row << 8) + lane;
-    e.fx = wr[0]; e.fy = wr[64]; e.fz = wr[128]; e.k = wr[192];
+    const double *wr = w + row * 192 + lane;
+    e.fx = wr[0]; e.fy = wr[64]; e.fz = wr[128];
     return e;
 }
 
 __device__ __forceinline__ EdgeRow pad_row()
 {
     EdgeRow e;
-    e.code = kCodePad; e.fx = 0.0; e.fy = 0.0; e.fz = 0.0; e.k = 0.0;
+    e.code = kT16Pad; e.fx = 0.0; e.fy = 0.0; e.fz = 0.0;
     return e;
-}
-
-// padding rows read this lane's own (valid, cached) state and are skipped by add_edge
-__device__ __forceinline__ NodeQ gather_other(const double *__restrict__ q, int64_t stride, int32_t code, int64_t self)
-{
-    return load_nodeq(q, stride, code < 0 ? self : int64_t(code & kIdMask));
 }
 
 __device__ __forceinline__ void add_edge(const NodeQ &me, const FluxC &fm, const NodeQ &ot, const EdgeRow &e,
                                          double &a0, double &a1, double &a2, double &a3, double &a4)
 {
-    if (e.code < 0) return;                                       // ELL padding
     const FluxC fo = flux_contribution(ot);
-    const bool me_is_b = (e.code & kRoleB) != 0;
-    // factor = -|e|*0.2f*0.5 * (speed_a + speed_b + c_a + c_b), left-associated
-    // (flux_kernel.elemfunc.c:130-131); only the order of the two sound speeds depends on
-    // which end this node is.
+    const bool me_is_b = (e.code & kT16RoleB) != 0;
+    const double fx = e.fx, fy = e.fy, fz = e.fz;
+    // The plan stores f = -+0.5*e, so sqrt(f.f) = |e|/2 exactly and -(|e|/2 * s) is the
+    // reference's -|e|*s*0.5 bit for bit (power-of-two scalings commute with rounding).
+    const double half_ewt = sqrt(fx * fx + fy * fy + fz * fz);               // flux_kernel.elemfunc.c:27
+    const double k = -(half_ewt * double(0.2f));                              // :130, smoothing_coefficient = double(0.2f)
+    // factor = k * (speed_a + speed_b + c_a + c_b), left-associated (:130-131); only the order
+    // of the two sound speeds depends on which end this node is.
     const double c_a = me_is_b ? ot.c : me.c;
     const double c_b = me_is_b ? me.c : ot.c;
-    const double factor = e.k * (((me.speed + ot.speed) + c_a) + c_b);
-    const double fx = e.fx, fy = e.fy, fz = e.fz;
+    const double factor = k * (((me.speed + ot.speed) + c_a) + c_b);
     // flux_kernel.elemfunc.c:142-189 seen from this node ("me" - "other"; the b-side sign is
-    // folded into fx,fy,fz by the plan)
+    // folded into fx,fy,fz by the plan: x - f*y == x + (-f)*y exactly)
     a0 += factor * (me.rho - ot.rho) + fx * (me.mx + ot.mx) + fy * (me.my + ot.my) + fz * (me.mz + ot.mz);
     a4 += factor * (me.en - ot.en) + fx * (fm.ex + fo.ex) + fy * (fm.ey + fo.ey) + fz * (fm.ez + fo.ez);
     a1 += factor * (me.mx - ot.mx) + fx * (fm.xx + fo.xx) + fy * (fm.xy + fo.xy) + fz * (fm.xz + fo.xz);
@@ -314,64 +277,67 @@ __device__ __forceinline__ void add_edge(const NodeQ &me, const FluxC &fm, const
     a3 += factor * (me.mz - ot.mz) + fx * (fm.xz + fo.xz) + fy * (fm.yz + fo.yz) + fz * (fm.zz + fo.zz);
 }
 
-template <int MINW, bool PIPE>
+template <int MINW>
 __global__ void __launch_bounds__(kBlock, MINW)
-k_flux_gather(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
-              const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
-              const int32_t *__restrict__ nbr, const double *__restrict__ w, FarField ff,
-              double *__restrict__ fluxes, int classes, int accumulate)
+k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
+            const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
+            const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
+            const int32_t *__restrict__ tile_halo_ptr, const int32_t *__restrict__ tile_halo,
+            const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
+            double *__restrict__ fluxes, int classes, int accumulate)
 {
-    const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int64_t i = blk * int64_t(kBlock) + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
-    if ((int64_t(slice) << 6) >= nel) return;          // whole wave past the end
-    const bool active = i < nel;                        // padded tail lanes compute on valid padding
+    __shared__ double2 tile[kTileCap * kLdsRecD2];
 
+    const unsigned t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t base = int64_t(t) * kTile;
+    const int64_t i = base + tid;
+    const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
+
+    // first rows' ids and weights go in flight before anything else
     const int32_t row0 = slice_row0[slice];
     const int32_t n_int = (classes & 1) ? rows_int[slice] : 0;
     const int32_t n_bnd = rows_bnd[slice];
-
-    // issue the first rows' loads before anything else so they overlap the own-state loads
     EdgeRow e0 = pad_row(), e1 = pad_row();
-    if (PIPE) {
-        if (n_int > 0) e0 = load_row(nbr, w, row0, lane);
-        if (n_int > 1) e1 = load_row(nbr, w, int64_t(row0) + 1, lane);
-    }
+    if (n_int > 0) e0 = load_row(nbr16, w, row0, lane);
+    if (n_int > 1) e1 = load_row(nbr16, w, int64_t(row0) + 1, lane);
 
-    const NodeQ me = load_nodeq(q, stride, i);
+    // ---- phase 1: stage + derive.  Own node first (coalesced), then the halo by id. ----
+    const int32_t h0 = tile_halo_ptr[t];
+    const int32_t n_halo = tile_halo_ptr[t + 1] - h0;
+    const NodeQ me = load_and_derive(q, stride, i);
+    lds_store_record(&tile[tid * kLdsRecD2], me);
+    for (int32_t h = tid; h < n_halo; h += kBlock)
+        lds_store_record(&tile[(kTile + h) * kLdsRecD2], load_and_derive(q, stride, tile_halo[h0 + h]));
+
     const FluxC fm = flux_contribution(me);
-
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
     if (accumulate) {
         a0 = fluxes[i]; a1 = fluxes[stride + i]; a2 = fluxes[2 * stride + i];
         a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
     }
+    const int32_t ovf0 = tile_ovf_ptr[t];
+    __syncthreads();
 
-    if (PIPE) {
-        if (n_int > 0) {
-            NodeQ o0 = gather_other(q, stride, e0.code, i);
-            for (int32_t r = 0; r < n_int; r += 2) {
-                // row r+1's neighbour state and row r+2's ids/weights go in flight ...
-                const NodeQ o1 = gather_other(q, stride, e1.code, i);
-                EdgeRow e2 = pad_row();
-                if (r + 2 < n_int) e2 = load_row(nbr, w, int64_t(row0) + r + 2, lane);
-                // ... while row r is computed
-                add_edge(me, fm, o0, e0, a0, a1, a2, a3, a4);
-                const NodeQ o2 = gather_other(q, stride, e2.code, i);
-                EdgeRow e3 = pad_row();
-                if (r + 3 < n_int) e3 = load_row(nbr, w, int64_t(row0) + r + 3, lane);
-                add_edge(me, fm, o1, e1, a0, a1, a2, a3, a4);
-                e0 = e2; o0 = o2; e1 = e3;
-            }
+    // ---- phase 2: incidence rows, ids/weights fetched two rows ahead ----
+    auto edge = [&](const EdgeRow &e) {
+        const uint32_t slot = e.code & kT16SlotMask;
+        if (slot == kT16Pad) return;                                           // ELL padding
+        if (slot < uint32_t(kTileCap)) {
+            add_edge(me, fm, lds_load_record(&tile[slot * kLdsRecD2]), e, a0, a1, a2, a3, a4);
+        } else {                                                               // halo beyond the LDS capacity
+            const int64_t node = tile_ovf[ovf0 + int32_t(slot) - kTileCap];
+            add_edge(me, fm, load_and_derive(q, stride, node), e, a0, a1, a2, a3, a4);
         }
-    } else {
-        for (int32_t r = 0; r < n_int; r++) {
-            const EdgeRow e = load_row(nbr, w, int64_t(row0) + r, lane);
-            if (e.code < 0) continue;
-            const NodeQ ot = load_nodeq(q, stride, e.code & kIdMask);
-            add_edge(me, fm, ot, e, a0, a1, a2, a3, a4);
-        }
+    };
+    for (int32_t r = 0; r < n_int; r += 2) {
+        EdgeRow e2 = pad_row(), e3 = pad_row();
+        if (r + 2 < n_int) e2 = load_row(nbr16, w, int64_t(row0) + r + 2, lane);
+        if (r + 3 < n_int) e3 = load_row(nbr16, w, int64_t(row0) + r + 3, lane);
+        edge(e0);
+        edge(e1);
+        e0 = e2; e1 = e3;
     }
 
     if ((classes & 6) && n_bnd > 0) {
@@ -379,13 +345,12 @@ k_flux_gather(int64_t nel, int64_t stride, const double *__restrict__ q, const i
         // node's faces in that order, so one pass per class keeps its per-node order.
         const int32_t first_bnd = rows_int[slice];
         for (int pass = 0; pass < 2; pass++) {
-            const int32_t want = pass == 0 ? kCodeWall : kCodeFar;
+            const uint32_t want = pass == 0 ? kT16Wall : kT16Far;
             if (!(classes & (pass == 0 ? 2 : 4))) continue;
             for (int32_t r = 0; r < n_bnd; r++) {
-                const int64_t row = int64_t(row0) + first_bnd + r;
-                if (nbr[(row << 6) + lane] != want) continue;
-                const double *wr = w + (row << 8) + lane;
-                const double fx = wr[0], fy = wr[64], fz = wr[128];
+                const EdgeRow e = load_row(nbr16, w, int64_t(row0) + first_bnd + r, lane);
+                if (e.code != want) continue;
+                const double fx = e.fx, fy = e.fy, fz = e.fz;
                 if (pass == 0) {
                     // flux_boundary_kernel.elemfunc.c:37-64: pressure force only
                     a0 += 0.0;
@@ -405,114 +370,6 @@ k_flux_gather(int64_t nel, int64_t stride, const double *__restrict__ q, const i
         }
     }
 
-    if (active) {
-        fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
-        fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// flux_tile: the same node-centred gather with the neighbour state served from an LDS tile.
-// One 256-thread workgroup = one tile = 256 consecutive nodes forming a compact cluster of
-// the mesh graph (preprocess.cpp: cluster_order).  The workgroup first copies the records of
-// its own nodes and of its halo (the few hundred nodes outside the cluster that its edges
-// touch) from HBM into LDS with full-cache-line, 16-byte-per-lane loads — every node record is
-// fetched once per tile instead of once per incident edge — and then every lane walks its
-// incidence rows reading neighbour records from LDS by tile-local slot.  Rows are still
-// accumulated in the reference's order.  Halo nodes beyond the LDS capacity (rare, only for
-// ragged clusters) are read straight from HBM.
-// ------------------------------------------------------------------------------------------
-template <int MINW>
-__global__ void __launch_bounds__(kBlock, MINW)
-k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ rec, const int32_t *__restrict__ slice_row0,
-            const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
-            const int32_t *__restrict__ nbr_tile, const double *__restrict__ w,
-            const int32_t *__restrict__ tile_halo_ptr, const int32_t *__restrict__ tile_halo, FarField ff,
-            double *__restrict__ fluxes, int classes, int accumulate)
-{
-    __shared__ double2 tile[kTileCap * kLdsRecDoubles / 2];
-
-    const unsigned t = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int64_t base = int64_t(t) * kTile;
-    const int64_t i = base + tid;
-    const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
-
-    // ---- stage own + halo records: 8 lanes per record, 16 B each (pieces 6,7 are padding) ----
-    const int32_t h0 = tile_halo_ptr[t];
-    const int32_t n_halo = tile_halo_ptr[t + 1] - h0;
-    const int32_t n_staged = kTile + n_halo;
-    const int piece = tid & 7;
-    for (int32_t slot = tid >> 3; slot < n_staged; slot += kBlock / 8) {
-        const int64_t node = slot < kTile ? base + slot : int64_t(tile_halo[h0 + slot - kTile]);
-        if (piece < 6) {
-            const double2 v = reinterpret_cast<const double2 *>(rec + node * kRecDoubles)[piece];
-            tile[slot * (kLdsRecDoubles / 2) + piece] = v;
-        }
-    }
-
-    // first rows' ids and weights go in flight while the tile lands
-    const int32_t row0 = slice_row0[slice];
-    const int32_t n_int = (classes & 1) ? rows_int[slice] : 0;
-    const int32_t n_bnd = rows_bnd[slice];
-    EdgeRow e0 = pad_row(), e1 = pad_row();
-    if (n_int > 0) e0 = load_row(nbr_tile, w, row0, lane);
-    if (n_int > 1) e1 = load_row(nbr_tile, w, int64_t(row0) + 1, lane);
-
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
-    if (accumulate) {
-        a0 = fluxes[i]; a1 = fluxes[stride + i]; a2 = fluxes[2 * stride + i];
-        a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
-    }
-    __syncthreads();
-
-    const NodeQ me = load_record(&tile[tid * (kLdsRecDoubles / 2)]);
-    const FluxC fm = flux_contribution(me);
-
-    auto neighbour = [&](int32_t code) -> NodeQ {
-        if (code < 0) return me;                                           // padding row: skipped by add_edge
-        if (code & kTileGlobal)                                            // halo beyond the LDS capacity
-            return load_record(reinterpret_cast<const double2 *>(rec + int64_t(code & kTileIdMask) * kRecDoubles));
-        return load_record(&tile[(code & kTileIdMask) * (kLdsRecDoubles / 2)]);
-    };
-
-    for (int32_t r = 0; r < n_int; r += 2) {
-        EdgeRow e2 = pad_row(), e3 = pad_row();
-        if (r + 2 < n_int) e2 = load_row(nbr_tile, w, int64_t(row0) + r + 2, lane);
-        if (r + 3 < n_int) e3 = load_row(nbr_tile, w, int64_t(row0) + r + 3, lane);
-        add_edge(me, fm, neighbour(e0.code), e0, a0, a1, a2, a3, a4);
-        add_edge(me, fm, neighbour(e1.code), e1, a0, a1, a2, a3, a4);
-        e0 = e2; e1 = e3;
-    }
-
-    if ((classes & 6) && n_bnd > 0) {
-        const int32_t first_bnd = rows_int[slice];
-        for (int pass = 0; pass < 2; pass++) {
-            const int32_t want = pass == 0 ? kCodeWall : kCodeFar;
-            if (!(classes & (pass == 0 ? 2 : 4))) continue;
-            for (int32_t r = 0; r < n_bnd; r++) {
-                const int64_t row = int64_t(row0) + first_bnd + r;
-                if (nbr_tile[(row << 6) + lane] != want) continue;
-                const double *wr = w + (row << 8) + lane;
-                const double fx = wr[0], fy = wr[64], fz = wr[128];
-                if (pass == 0) {
-                    a0 += 0.0;
-                    a1 += fx * me.p;
-                    a2 += fy * me.p;
-                    a3 += fz * me.p;
-                    a4 += 0.0;
-                } else {
-                    a0 += fx * (ff.var[1] + me.mx) + fy * (ff.var[2] + me.my) + fz * (ff.var[3] + me.mz);
-                    a4 += fx * (ff.fc_de[0] + fm.ex) + fy * (ff.fc_de[1] + fm.ey) + fz * (ff.fc_de[2] + fm.ez);
-                    a1 += fx * (ff.fc_mx[0] + fm.xx) + fy * (ff.fc_mx[1] + fm.xy) + fz * (ff.fc_mx[2] + fm.xz);
-                    a2 += fx * (ff.fc_my[0] + fm.xy) + fy * (ff.fc_my[1] + fm.yy) + fz * (ff.fc_my[2] + fm.yz);
-                    a3 += fx * (ff.fc_mz[0] + fm.xz) + fy * (ff.fc_mz[1] + fm.yz) + fz * (ff.fc_mz[2] + fm.zz);
-                }
-            }
-        }
-    }
-
     if (i < nel) {
         fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
         fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
@@ -520,9 +377,9 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ rec, const i
 }
 
 // ------------------------------------------------------------------------------------------
-// indirect_rw (indirect_rw_kernel.elemfunc.c:4-94) in gather form: same data movement as
-// flux_gather, minimal arithmetic.  a-side gets q_b + (ex, ez, 0, 0, ey); b-side gets q_a.
-// The plan stores -0.5*e (a side), so e = -2*w exactly.
+// indirect_rw (indirect_rw_kernel.elemfunc.c:4-94) in gather form: the reference's "same data
+// movement, minimal arithmetic" probe.  a-side gets q_b + (ex, ez, 0, 0, ey); b-side gets q_a.
+// The plan stores -0.5*e (a side), so e = -2*w exactly.  Neighbour state straight from HBM/L2.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_indirect_rw(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
@@ -533,8 +390,6 @@ k_indirect_rw(int64_t nel, int64_t stride, const double *__restrict__ q, const i
     const int64_t i = blk * int64_t(kBlock) + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
-    if ((int64_t(slice) << 6) >= nel) return;
-    const bool active = i < nel;
     const int32_t row0 = slice_row0[slice];
     const int32_t n_int = rows_int[slice];
     double a0 = fluxes[i], a1 = fluxes[stride + i], a2 = fluxes[2 * stride + i],
@@ -548,7 +403,7 @@ k_indirect_rw(int64_t nel, int64_t stride, const double *__restrict__ q, const i
         if (code & kRoleB) {
             a0 += o0; a1 += o1; a2 += o2; a3 += o3; a4 += o4;
         } else {
-            const double *wr = w + (row << 8) + lane;
+            const double *wr = w + row * 192 + lane;
             a0 += o0 + (-2.0 * wr[0]);
             a1 += o1 + (-2.0 * wr[128]);
             a2 += o2;
@@ -556,7 +411,7 @@ k_indirect_rw(int64_t nel, int64_t stride, const double *__restrict__ q, const i
             a4 += o4 + (-2.0 * wr[64]);
         }
     }
-    if (active) {
+    if (i < nel) {
         fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
         fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
     }
@@ -564,15 +419,13 @@ k_indirect_rw(int64_t nel, int64_t stride, const double *__restrict__ q, const i
 
 // ------------------------------------------------------------------------------------------
 // time_step (cfd_loops.cpp:241-268): variables = old + sf/(RK+1-j) * fluxes ; fluxes = 0.
-// Fused: refresh the derived fields for the next flux pass and raise the
-// check_for_invalid_variables flag (validation.cpp:107-138) — err = (smallest offending
-// ORIGINAL cell id << 8) | code.
+// Fused: the check_for_invalid_variables flag (validation.cpp:107-138) —
+// err = (smallest offending ORIGINAL cell id << 8) | code.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_time_step(int64_t nel, int64_t stride, double rk_div, const double *__restrict__ step_factors,
             double *__restrict__ fluxes, const double *__restrict__ old_variables, double *__restrict__ q,
-            double *__restrict__ rec, const int32_t *__restrict__ old_of_new, unsigned long long *__restrict__ err,
-            int check)
+            const int32_t *__restrict__ old_of_new, unsigned long long *__restrict__ err, int check)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
@@ -585,9 +438,6 @@ k_time_step(int64_t nel, int64_t stride, double rk_div, const double *__restrict
     store_conserved(q, stride, i, rho, mx, my, mz, en);
     fluxes[i] = 0.0; fluxes[stride + i] = 0.0; fluxes[2 * stride + i] = 0.0;
     fluxes[3 * stride + i] = 0.0; fluxes[4 * stride + i] = 0.0;
-    const Derived d = derive(rho, mx, my, mz, en);
-    store_derived(q, stride, i, d);
-    store_record(rec, i, rho, mx, my, mz, en, d);
     if (check) {
         const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
         int code = 0;
@@ -742,63 +592,49 @@ k_prolong(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t *__r
 // ==========================================================================================
 static inline unsigned grid_for(int64_t n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); }
 
-void launch_init_variables(hipStream_t st, int64_t stride, const FarField &ff, double *q, double *rec)
-{ hipLaunchKernelGGL(k_init_variables, dim3(grid_for(stride)), dim3(kBlock), 0, st, stride, ff, q, rec); }
+void launch_init_variables(hipStream_t st, int64_t stride, const FarField &ff, double *q)
+{ hipLaunchKernelGGL(k_init_variables, dim3(grid_for(stride)), dim3(kBlock), 0, st, stride, ff, q); }
 
-void launch_derive(hipStream_t st, int64_t nel, int64_t stride, double *q, double *rec)
-{ hipLaunchKernelGGL(k_derive, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, rec); }
-
-void launch_step_factor_local(hipStream_t st, int64_t nel, int64_t stride, double *q, double *rec, const double *cbrt_vol,
+void launch_step_factor_local(hipStream_t st, int64_t nel, int64_t stride, const double *q, const double *cbrt_vol,
                               double *sf, unsigned long long *min_bits)
-{ hipLaunchKernelGGL(k_step_factor_local, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, rec, cbrt_vol, sf, min_bits); }
+{ hipLaunchKernelGGL(k_step_factor_local, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, cbrt_vol, sf, min_bits); }
 
 void launch_step_factor_apply(hipStream_t st, int64_t nel, const unsigned long long *min_bits,
                               const double *volumes, double *sf)
 { hipLaunchKernelGGL(k_step_factor_apply, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, min_bits, volumes, sf); }
 
-void launch_step_factor_legacy(hipStream_t st, int64_t nel, int64_t stride, double *q, double *rec, const double *volumes, double *sf)
-{ hipLaunchKernelGGL(k_step_factor_legacy, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, rec, volumes, sf); }
+void launch_step_factor_legacy(hipStream_t st, int64_t nel, int64_t stride, const double *q, const double *volumes, double *sf)
+{ hipLaunchKernelGGL(k_step_factor_legacy, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, volumes, sf); }
 
-void launch_flux_gather(hipStream_t st, const DevicePlan &p, const double *q, const double *rec, const FarField &ff,
-                        double *fluxes, int classes, int accumulate, int variant)
+void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const FarField &ff, double *fluxes,
+                 int classes, int accumulate, int variant)
 {
-    const dim3 grid(grid_for(p.stride)), block(kBlock);
+    const dim3 grid(p.n_tiles), block(kBlock);
 #define MGCFD_TILE_LAUNCH(MINW)                                                                                \
-    hipLaunchKernelGGL((k_flux_tile<MINW>), dim3(p.n_tiles), block, 0, st, p.nel, p.stride, rec, p.slice_row0,  \
-                       p.rows_int, p.rows_bnd, p.nbr_tile, p.w, p.tile_halo_ptr, p.tile_halo, ff, fluxes,      \
-                       classes, accumulate)
-    if (variant == 0 || variant == 8) { MGCFD_TILE_LAUNCH(1); return; }
-    if (variant == 9) { MGCFD_TILE_LAUNCH(3); return; }
-#undef MGCFD_TILE_LAUNCH
-#define MGCFD_FLUX_LAUNCH(MINW, PIPE)                                                                          \
-    hipLaunchKernelGGL((k_flux_gather<MINW, PIPE>), grid, block, 0, st, p.nel, p.stride, q, p.slice_row0,      \
-                       p.rows_int, p.rows_bnd, p.nbr, p.w, ff, fluxes, classes, accumulate)
+    hipLaunchKernelGGL((k_flux_tile<MINW>), grid, block, 0, st, p.nel, p.stride, q, p.slice_row0, p.rows_int,  \
+                       p.rows_bnd, p.nbr16, p.w, p.tile_halo_ptr, p.tile_halo, p.tile_ovf_ptr, p.tile_ovf, ff, \
+                       fluxes, classes, accumulate)
     switch (variant) {
-        case 1: MGCFD_FLUX_LAUNCH(1, false); break;     // plain loop, compiler-chosen registers
-        case 2: MGCFD_FLUX_LAUNCH(5, false); break;
-        case 3: MGCFD_FLUX_LAUNCH(8, false); break;
-        case 4: MGCFD_FLUX_LAUNCH(1, true); break;      // software-pipelined
-        case 5: MGCFD_FLUX_LAUNCH(3, true); break;
-        case 6: MGCFD_FLUX_LAUNCH(4, true); break;
-        case 7: MGCFD_FLUX_LAUNCH(5, true); break;
-        default: MGCFD_FLUX_LAUNCH(1, true); break;
+        case 1: MGCFD_TILE_LAUNCH(1); break;
+        case 2: MGCFD_TILE_LAUNCH(2); break;
+        case 4: MGCFD_TILE_LAUNCH(4); break;
+        default: MGCFD_TILE_LAUNCH(3); break;       // 3 tiles of 52.5 KiB LDS fit a CU
     }
-#undef MGCFD_FLUX_LAUNCH
+#undef MGCFD_TILE_LAUNCH
 }
 
 void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, double *fluxes)
 {
-    hipLaunchKernelGGL(k_indirect_rw, dim3(grid_for(p.stride)), dim3(kBlock), 0, st, p.nel, p.stride, q,
+    hipLaunchKernelGGL(k_indirect_rw, dim3(p.n_tiles), dim3(kBlock), 0, st, p.nel, p.stride, q,
                        p.slice_row0, p.rows_int, p.nbr, p.w, fluxes);
 }
 
 void launch_time_step(hipStream_t st, int64_t nel, int64_t stride, int j, const double *sf, double *fluxes,
-                      const double *old_variables, double *q, double *rec, const int32_t *old_of_new,
-                      unsigned long long *err, int check)
+                      const double *old_variables, double *q, const int32_t *old_of_new, unsigned long long *err, int check)
 {
     const double rk_div = double(3 + 1 - j);    // double(RK+1-j), cfd_loops.cpp:243
     hipLaunchKernelGGL(k_time_step, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, rk_div, sf, fluxes,
-                       old_variables, q, rec, old_of_new, err, check);
+                       old_variables, q, old_of_new, err, check);
 }
 
 void launch_check_invalid(hipStream_t st, int64_t nel, int64_t stride, const double *q, const int32_t *old_of_new,

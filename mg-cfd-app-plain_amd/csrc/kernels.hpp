@@ -5,20 +5,18 @@
 
 #define MGCFD_DECLARE_LAUNCHERS(NS)                                                                                  \
     namespace mgcfd { namespace NS {                                                                                 \
-    void launch_init_variables(hipStream_t, int64_t stride, const FarField &, double *q, double *rec);               \
-    void launch_derive(hipStream_t, int64_t nel, int64_t stride, double *q, double *rec);                            \
-    void launch_step_factor_local(hipStream_t, int64_t nel, int64_t stride, double *q, double *rec,                  \
-                                  const double *cbrt_vol, double *sf, unsigned long long *min_bits);                 \
+    void launch_init_variables(hipStream_t, int64_t stride, const FarField &, double *q);                            \
+    void launch_step_factor_local(hipStream_t, int64_t nel, int64_t stride, const double *q, const double *cbrt_vol, \
+                                  double *sf, unsigned long long *min_bits);                                         \
     void launch_step_factor_apply(hipStream_t, int64_t nel, const unsigned long long *min_bits,                      \
                                   const double *volumes, double *sf);                                                \
-    void launch_step_factor_legacy(hipStream_t, int64_t nel, int64_t stride, double *q, double *rec,                 \
-                                   const double *volumes, double *sf);                                               \
-    void launch_flux_gather(hipStream_t, const DevicePlan &, const double *q, const double *rec, const FarField &,   \
-                            double *fluxes,                                                                          \
-                            int classes, int accumulate, int variant);                                               \
+    void launch_step_factor_legacy(hipStream_t, int64_t nel, int64_t stride, const double *q, const double *volumes, \
+                                   double *sf);                                                                      \
+    void launch_flux(hipStream_t, const DevicePlan &, const double *q, const FarField &, double *fluxes,             \
+                     int classes, int accumulate, int variant);                                                      \
     void launch_indirect_rw(hipStream_t, const DevicePlan &, const double *q, double *fluxes);                       \
     void launch_time_step(hipStream_t, int64_t nel, int64_t stride, int j, const double *sf, double *fluxes,         \
-                          const double *old_variables, double *q, double *rec, const int32_t *old_of_new,            \
+                          const double *old_variables, double *q, const int32_t *old_of_new,                         \
                           unsigned long long *err, int check);                                                       \
     void launch_check_invalid(hipStream_t, int64_t nel, int64_t stride, const double *q,                             \
                               const int32_t *old_of_new, unsigned long long *err);                                   \

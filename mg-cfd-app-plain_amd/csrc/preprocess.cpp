@@ -300,13 +300,16 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++) add_face(edges[static_cast<size_t>(e)], kCodeWall, 1.0);
     for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++) add_face(edges[static_cast<size_t>(e)], kCodeFar, 0.5);
 
-    // ---- tiles: halo lists and tile-local neighbour codes ----
-    P.nbr_tile.assign(P.nbr.size(), kCodePad);
+    // ---- tiles: halo lists and 16-bit tile-local neighbour codes ----
+    P.nbr16.assign(P.nbr.size(), static_cast<uint16_t>(kT16Pad));
     P.tile_halo_ptr.assign(static_cast<size_t>(P.n_tiles) + 1, 0);
+    P.tile_ovf_ptr.assign(static_cast<size_t>(P.n_tiles) + 1, 0);
     P.tile_halo.clear();
+    P.tile_ovf.clear();
     {
         std::vector<int32_t> halo;
         const int32_t halo_cap = kTileCap - kTile;
+        const int32_t ovf_cap = int32_t(kT16Far) - kTileCap;          // overflow slots a 15-bit code can name
         int64_t halo_total = 0;
         for (int32_t t = 0; t < P.n_tiles; t++) {
             const int32_t base = t * kTile;
@@ -322,24 +325,35 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             }
             std::sort(halo.begin(), halo.end());
             halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
-            const int32_t staged = std::min<int32_t>(static_cast<int32_t>(halo.size()), halo_cap);
-            halo_total += static_cast<int64_t>(halo.size());
-            P.halo_max = std::max<int32_t>(P.halo_max, static_cast<int32_t>(halo.size()));
+            const int32_t n_halo = static_cast<int32_t>(halo.size());
+            const int32_t staged = std::min<int32_t>(n_halo, halo_cap);
+            if (n_halo - staged > ovf_cap) throw std::runtime_error("tile halo exceeds what 15-bit slots can address");
+            halo_total += n_halo;
+            P.halo_max = std::max<int32_t>(P.halo_max, n_halo);
             for (int64_t e = e0; e < e1; e++) {
                 const int32_t code = P.nbr[static_cast<size_t>(e)];
-                if (code < 0) { P.nbr_tile[static_cast<size_t>(e)] = code; continue; }
-                const int32_t id = code & kIdMask, role = code & kRoleB;
-                int32_t local;
-                if (id >= base && id < base + kTile) local = id - base;
+                uint32_t c16;
+                if (code == kCodeWall) c16 = kT16Wall;
+                else if (code == kCodeFar) c16 = kT16Far;
+                else if (code < 0) c16 = kT16Pad;
                 else {
-                    const int32_t pos = static_cast<int32_t>(std::lower_bound(halo.begin(), halo.end(), id) - halo.begin());
-                    if (pos < staged) local = kTile + pos;
-                    else { local = id | kTileGlobal; P.halo_overflow_refs++; }
+                    const int32_t id = code & kIdMask;
+                    uint32_t slot;
+                    if (id >= base && id < base + kTile) slot = static_cast<uint32_t>(id - base);
+                    else {
+                        // ascending halo: the first `staged` ids live in LDS, the rest in the overflow table
+                        const int32_t pos = static_cast<int32_t>(std::lower_bound(halo.begin(), halo.end(), id) - halo.begin());
+                        slot = static_cast<uint32_t>(kTile + pos);        // pos >= staged  =>  slot >= kTileCap
+                        if (pos >= staged) P.halo_overflow_refs++;
+                    }
+                    c16 = slot | ((code & kRoleB) ? kT16RoleB : 0u);
                 }
-                P.nbr_tile[static_cast<size_t>(e)] = local | role;
+                P.nbr16[static_cast<size_t>(e)] = static_cast<uint16_t>(c16);
             }
             P.tile_halo.insert(P.tile_halo.end(), halo.begin(), halo.begin() + staged);
             P.tile_halo_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(P.tile_halo.size());
+            P.tile_ovf.insert(P.tile_ovf.end(), halo.begin() + staged, halo.end());
+            P.tile_ovf_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(P.tile_ovf.size());
         }
         P.halo_mean = P.n_tiles ? double(halo_total) / double(P.n_tiles) : 0.0;
     }

@@ -25,8 +25,14 @@ constexpr int kTileCap = 560;   // node records a tile can stage in LDS (560 * 9
 // neighbour codes in Sell::nbr
 constexpr int32_t kRoleB = 1 << 30;     // set when THIS node is the edge's 'b' end (else it is 'a')
 constexpr int32_t kIdMask = kRoleB - 1;
-constexpr int32_t kTileGlobal = 1 << 29;   // tile codes only: id is a global node id (halo beyond the LDS capacity)
-constexpr int32_t kTileIdMask = kTileGlobal - 1;
+// 16-bit tile-local codes (LevelPlan::nbr16): bit 15 = role, low 15 bits = LDS slot
+// (own nodes 0..255, staged halo 256..kTileCap-1), kTileCap+k = k-th entry of the tile's
+// overflow table (halo beyond the LDS capacity), or one of the specials below.
+constexpr uint32_t kT16RoleB = 0x8000u;
+constexpr uint32_t kT16SlotMask = 0x7FFFu;
+constexpr uint32_t kT16Pad = 0x7FFFu;
+constexpr uint32_t kT16Wall = 0x7FFEu;    // solid wall face   (reference neighbour code -1)
+constexpr uint32_t kT16Far = 0x7FFDu;     // far-field face    (reference neighbour code -2)
 constexpr int32_t kCodeWall = -1;       // reference neighbour code -1: solid wall   ("boundary" edges)
 constexpr int32_t kCodeFar = -2;        // reference neighbour code -2: far field    ("wall" edges)
 constexpr int32_t kCodePad = -3;
@@ -48,8 +54,9 @@ struct LevelPlan {
     int32_t n_tiles = 0;
     std::vector<int32_t> tile_halo_ptr;   // [n_tiles+1]
     std::vector<int32_t> tile_halo;       // global new ids of the halo nodes a tile stages (ascending, <= kTileCap-kTile each)
-    std::vector<int32_t> nbr_tile;        // [rows*64] as nbr, but ids are tile-local LDS slots (own 0..255, halo 256..)
-                                          //            or global ids flagged kTileGlobal when the halo overflows the LDS
+    std::vector<int32_t> tile_ovf_ptr;    // [n_tiles+1]
+    std::vector<int32_t> tile_ovf;        // global new ids of halo nodes that did not fit the LDS tile
+    std::vector<uint16_t> nbr16;          // [rows*64] 16-bit tile-local codes (see kT16*)
     double halo_mean = 0.0; int32_t halo_max = 0; int64_t halo_overflow_refs = 0;
     std::vector<EdgeW> w;              // [rows*64]
     //   internal, this node = a:  (x,y,z) = -0.5*e   k = -|e|*smoothing*0.5   (flux_kernel.elemfunc.c:130-140)

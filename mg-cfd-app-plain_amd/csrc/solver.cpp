@@ -56,14 +56,12 @@ struct DeviceLevel {
     std::vector<mgcfd_edge> edges;       // final edge weights, original order
     LevelPlan plan;                      // host copy (permutations for get/set)
     DevicePlan dp;
-    // SoA state, stride = dp.stride: q = 11 fields (0-4 = the reference's `variables`, 5-10 derived)
-    double *rec = nullptr;               // [stride][16] AoS node records read by the flux kernels
-    double *q = nullptr, *old_variables = nullptr, *fluxes = nullptr, *residuals = nullptr;   // [5|11][stride]
+    // SoA state, stride = dp.stride: q = the reference's `variables`
+    double *q = nullptr, *old_variables = nullptr, *fluxes = nullptr, *residuals = nullptr;   // [5][stride]
     double *step_factors = nullptr, *volumes = nullptr, *cbrt_vol = nullptr;                  // [stride]
     unsigned long long *min_bits = nullptr;
     double *sumsq = nullptr, *partials = nullptr;
     int n_partials = 0;
-    bool nodeq_stale = false;
     bool fluxes_zero = true;             // fluxes[] is known to hold zeros (skip the read in flux_gather)
     bool has_transfer = false;           // plan to the next-coarser level present
     int64_t iters[MGCFD_NUM_LOOPS] = {0};
@@ -140,13 +138,6 @@ struct mgcfd_solver {
     };
 
     // ---- operations ----------------------------------------------------------------------
-    void ensure_nodeq(DeviceLevel &lv)
-    {
-        if (!lv.nodeq_stale) return;
-        if (opt_exact) exact::launch_derive(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec);
-        else fast::launch_derive(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec);
-        lv.nodeq_stale = false;
-    }
     void op_copy_old(int l)
     {
         DeviceLevel &lv = level(l);
@@ -156,9 +147,8 @@ struct mgcfd_solver {
     {
         DeviceLevel &lv = level(l);
         HIP_CHECK(hipMemsetAsync(lv.min_bits, 0x7F, sizeof(unsigned long long), stream));
-        if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec, lv.cbrt_vol, lv.step_factors, lv.min_bits);
-        else fast::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec, lv.cbrt_vol, lv.step_factors, lv.min_bits);
-        lv.nodeq_stale = false;
+        if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits);
+        else fast::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits);
     }
     void op_step_factor_apply(int l)
     {
@@ -171,10 +161,9 @@ struct mgcfd_solver {
         DeviceLevel &lv = level(l);
         Timed t(this, l, MGCFD_LOOP_COMPUTE_STEP);
         if (mesh_variant == MGCFD_MESH_FVCORR) {
-            if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec, lv.volumes, lv.step_factors);
-            else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.rec, lv.volumes, lv.step_factors);
-            lv.nodeq_stale = false;
-        } else {
+            if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors);
+            else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors);
+            } else {
             op_step_factor_local(l);
             op_step_factor_apply(l);
         }
@@ -184,18 +173,16 @@ struct mgcfd_solver {
     void op_flux(int l, int classes)
     {
         DeviceLevel &lv = level(l);
-        ensure_nodeq(lv);
         Timed t(this, l, MGCFD_LOOP_FLUX, (classes & 1) != 0);
         const int accumulate = lv.fluxes_zero ? 0 : 1;     // 0.0 + x: same bits either way
-        if (opt_exact) exact::launch_flux_gather(stream, lv.dp, lv.q, lv.rec, ff, lv.fluxes, classes, accumulate, opt_variant);
-        else fast::launch_flux_gather(stream, lv.dp, lv.q, lv.rec, ff, lv.fluxes, classes, accumulate, opt_variant);
+        if (opt_exact) exact::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant);
+        else fast::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant);
         lv.fluxes_zero = false;
         if (classes & 1) lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
     }
     void op_indirect_rw(int l)
     {
         DeviceLevel &lv = level(l);
-        ensure_nodeq(lv);
         Timed t(this, l, MGCFD_LOOP_INDIRECT_RW);
         if (opt_exact) exact::launch_indirect_rw(stream, lv.dp, lv.q, lv.fluxes);
         else fast::launch_indirect_rw(stream, lv.dp, lv.q, lv.fluxes);
@@ -213,9 +200,8 @@ struct mgcfd_solver {
         if (j < 0 || j >= MGCFD_RK) throw std::invalid_argument("RK stage out of range");
         DeviceLevel &lv = level(l);
         Timed t(this, l, MGCFD_LOOP_TIME_STEP);
-        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.rec, lv.dp.old_of_new, err, opt_check);
-        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.rec, lv.dp.old_of_new, err, opt_check);
-        lv.nodeq_stale = false;
+        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check);
+        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check);
         lv.fluxes_zero = true;
         lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
     }
@@ -241,7 +227,6 @@ struct mgcfd_solver {
         Timed t(this, fine + 1, MGCFD_LOOP_RESTRICT);
         if (opt_exact) exact::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q);
         else fast::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q);
-        C.nodeq_stale = true;
         C.iters[MGCFD_LOOP_RESTRICT] += 2 * F.info.mgc + C.info.nel;   // mg_loops.cpp:61,117,172
     }
     void op_prolong(int fine)
@@ -252,7 +237,6 @@ struct mgcfd_solver {
         Timed t(this, fine, MGCFD_LOOP_PROLONG);
         if (opt_exact) exact::launch_prolong(stream, F.dp, C.dp.stride, C.residuals, F.residuals, F.q);
         else fast::launch_prolong(stream, F.dp, C.dp.stride, C.residuals, F.residuals, F.q);
-        F.nodeq_stale = true;
         F.iters[MGCFD_LOOP_PROLONG] += F.info.n_internal + F.info.nel;  // mg_loops.cpp:728,842
     }
     int read_error(int64_t *bad_cell)
@@ -278,7 +262,7 @@ mgcfd_solver::~mgcfd_solver()
     for (auto &p : pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto e : free_events) (void)hipEventDestroy(e);
     for (auto &lv : L) {
-        void *ptrs[] = {lv.rec, lv.dp.nbr_tile, lv.dp.tile_halo_ptr, lv.dp.tile_halo, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
+        void *ptrs[] = {lv.dp.nbr16, lv.dp.tile_halo_ptr, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
                         lv.cbrt_vol, lv.min_bits, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.pro,
                         lv.dp.pro_parent, lv.dp.pro_wsum};
@@ -361,7 +345,6 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.volumes = dev_upload(vol);
         lv.cbrt_vol = dev_upload(cb);
         lv.q = dev_alloc<double>(static_cast<size_t>(stride) * kNumStateFields);
-        lv.rec = dev_alloc<double>(static_cast<size_t>(stride) * 16);
         lv.old_variables = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.fluxes = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.residuals = dev_alloc<double>(static_cast<size_t>(stride) * 5);
@@ -380,22 +363,23 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         {
             // edge weights as [row][component][lane] so each component load of a wave is one
             // contiguous 512-byte run
-            std::vector<double> ws(P.w.size() * 4);
+            std::vector<double> ws(P.w.size() * 3);
             for (size_t e = 0; e < P.w.size(); e++) {
                 const size_t row = e / kSlice, lane = e % kSlice;
-                ws[(row * 4 + 0) * kSlice + lane] = P.w[e].x;
-                ws[(row * 4 + 1) * kSlice + lane] = P.w[e].y;
-                ws[(row * 4 + 2) * kSlice + lane] = P.w[e].z;
-                ws[(row * 4 + 3) * kSlice + lane] = P.w[e].k;
+                ws[(row * 3 + 0) * kSlice + lane] = P.w[e].x;
+                ws[(row * 3 + 1) * kSlice + lane] = P.w[e].y;
+                ws[(row * 3 + 2) * kSlice + lane] = P.w[e].z;
             }
             lv.dp.w = dev_upload(ws);
         }
         lv.dp.old_of_new = dev_upload(P.old_of_new);
         lv.dp.n_tiles = P.n_tiles;
-        lv.dp.nbr_tile = dev_upload(P.nbr_tile);
+        lv.dp.nbr16 = dev_upload(P.nbr16);
         lv.dp.tile_halo_ptr = dev_upload(P.tile_halo_ptr);
         lv.dp.tile_halo = dev_upload(P.tile_halo);
-        lv.plan.nbr_tile.clear(); lv.plan.nbr_tile.shrink_to_fit();
+        lv.dp.tile_ovf_ptr = dev_upload(P.tile_ovf_ptr);
+        lv.dp.tile_ovf = dev_upload(P.tile_ovf);
+        lv.plan.nbr16.clear(); lv.plan.nbr16.shrink_to_fit();
         if (lv.has_transfer) {
             lv.dp.child_ptr = dev_upload(P.child_ptr);
             lv.dp.child = dev_upload(P.child);
@@ -412,7 +396,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * stride, s->stream));
         HIP_CHECK(hipMemsetAsync(lv.residuals, 0, sizeof(double) * 5 * stride, s->stream));
         HIP_CHECK(hipMemsetAsync(lv.step_factors, 0, sizeof(double) * stride, s->stream));
-        exact::launch_init_variables(s->stream, stride, s->ff, lv.q, lv.rec);
+        exact::launch_init_variables(s->stream, stride, s->ff, lv.q);
     }
     HIP_CHECK(hipStreamSynchronize(s->stream));
     HIP_CHECK(hipGetLastError());
@@ -724,7 +708,6 @@ int mgcfd_set_array(mgcfd_solver *s, int level, int which, const double *in)
         }
         HIP_CHECK(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
         HIP_CHECK(hipStreamSynchronize(s->stream));
-        if (which == MGCFD_ARR_VARIABLES) lv.nodeq_stale = true;
         if (which == MGCFD_ARR_FLUXES) lv.fluxes_zero = false;
     });
 }
@@ -788,11 +771,10 @@ int mgcfd_bench_flux(mgcfd_solver *s, int level, int launches, double *avg_secon
     return guarded([&] {
         s->use_device();
         DeviceLevel &lv = s->level(level);
-        s->ensure_nodeq(lv);
         hipEvent_t a = s->get_event(), b = s->get_event();
         auto go = [&] {
-            if (s->opt_exact) exact::launch_flux_gather(s->stream, lv.dp, lv.q, lv.rec, s->ff, lv.fluxes, 7, 0, s->opt_variant);
-            else fast::launch_flux_gather(s->stream, lv.dp, lv.q, lv.rec, s->ff, lv.fluxes, 7, 0, s->opt_variant);
+            if (s->opt_exact) exact::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, s->opt_variant);
+            else fast::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, s->opt_variant);
         };
         go();
         HIP_CHECK(hipEventRecord(a, s->stream));

@@ -27,7 +27,7 @@ struct DevicePlan {
     int64_t stride = 0;                 // 256 * n_tiles
     int32_t n_slices = 0;
     int32_t *slice_row0 = nullptr, *rows_int = nullptr, *rows_bnd = nullptr, *nbr = nullptr;
-    double *w = nullptr;                // [row][3 components][64 lanes]: signed, halved edge weights
+    double *w = nullptr;                // [row][4 components][64 lanes]: signed, halved edge weights fx,fy,fz and k = -|e|*0.2f*0.5
     int32_t n_tiles = 0;
     uint16_t *nbr16 = nullptr;          // [row][64 lanes] tile-local codes
     int32_t *tile_halo_ptr = nullptr, *tile_halo = nullptr, *tile_ovf_ptr = nullptr, *tile_ovf = nullptr;

@@ -14,7 +14,7 @@
 //                   GATHER: a 256-thread workgroup owns a compact cluster of 256 nodes, stages
 //                   their state and their halo's state into an LDS tile (each node fetched once
 //                   per tile instead of once per incident edge), and every lane then walks its
-//                   incidence rows (sliced ELLPACK, 26 B per entry, coalesced) and sums the
+//                   incidence rows (sliced ELLPACK, 26-34 B per entry, coalesced) and sums the
 //                   edge fluxes in the reference's order — no atomics, no colouring,
 //                   deterministic, bit-identical.
 //   * The division / square-root work (8 div + 5 sqrt per edge in the reference) is done once
@@ -223,7 +223,8 @@ k_step_factor_legacy(int64_t nel, int64_t stride, const double *__restrict__ q, 
 // |v| and speed of sound derived (cfd_loops.h:121-148) and the 11 values written to LDS as one
 // 96-byte record.  Phase 2: every lane walks the incidence rows of its node (sliced ELLPACK:
 // row r of a wave = the r-th incident edge of its 64 nodes, stored contiguously: a 16-bit
-// tile-local neighbour slot and the 3 signed, halved edge-weight components = 26 B per entry),
+// tile-local neighbour slot, the 3 signed, halved edge-weight components and optionally the
+// precomputed length factor = 26 or 34 B per entry),
 // reads the neighbour's record from LDS and adds the edge flux.  Rows are in ORIGINAL edge
 // order, internal edges first, then solid-wall faces, then far-field faces — exactly the order
 // in which the reference's serial loops add into fluxes[node] — so the per-node sequential sum
@@ -234,50 +235,62 @@ k_step_factor_legacy(int64_t nel, int64_t stride, const double *__restrict__ q, 
 // the array is not known to be zero).  Halo nodes beyond the LDS capacity (ragged clusters
 // only) are listed in a per-tile overflow table and read straight from HBM.
 // ------------------------------------------------------------------------------------------
-struct EdgeRow { uint32_t code; double fx, fy, fz; };
+struct EdgeRow { uint32_t code; double fx, fy, fz, k; };
 
+// Edge weights are stored [row][4 components][64 lanes]: fx, fy, fz (signed, halved) and
+// k = -|e|*smoothing*0.5.  LOADK = false skips the k stream (8 of 34 bytes per entry) and
+// recomputes it from fx,fy,fz — bit-identical either way, a bandwidth-for-arithmetic trade.
+template <bool LOADK>
 __device__ __forceinline__ EdgeRow load_row(const uint16_t *__restrict__ nbr, const double *__restrict__ w,
                                             int64_t row, int lane)
 {
     EdgeRow e;
     e.code = nbr[(row << 6) + lane];
-    const double *wr = w + row * 192 + lane;
+    const double *wr = w + (row << 8) + lane;
     e.fx = wr[0]; e.fy = wr[64]; e.fz = wr[128];
+    e.k = LOADK ? wr[192] : 0.0;
     return e;
 }
 
 __device__ __forceinline__ EdgeRow pad_row()
 {
     EdgeRow e;
-    e.code = kT16Pad; e.fx = 0.0; e.fy = 0.0; e.fz = 0.0;
+    e.code = kT16Pad; e.fx = 0.0; e.fy = 0.0; e.fz = 0.0; e.k = 0.0;
     return e;
 }
 
-__device__ __forceinline__ void add_edge(const NodeQ &me, const FluxC &fm, const NodeQ &ot, const EdgeRow &e,
-                                         double &a0, double &a1, double &a2, double &a3, double &a4)
+struct Flux5 { double d, mx, my, mz, en; };
+
+// One edge's contribution to THIS node's flux (flux_kernel.elemfunc.c:130-189 seen from this
+// node: "me" - "other"; the b-side sign is folded into fx,fy,fz by the plan, x - f*y == x + (-f)*y).
+template <bool LOADK>
+__device__ __forceinline__ Flux5 edge_flux(const NodeQ &me, const FluxC &fm, const NodeQ &ot, const EdgeRow &e)
 {
     const FluxC fo = flux_contribution(ot);
     const bool me_is_b = (e.code & kT16RoleB) != 0;
     const double fx = e.fx, fy = e.fy, fz = e.fz;
-    // The plan stores f = -+0.5*e, so sqrt(f.f) = |e|/2 exactly and -(|e|/2 * s) is the
-    // reference's -|e|*s*0.5 bit for bit (power-of-two scalings commute with rounding).
-    const double half_ewt = sqrt(fx * fx + fy * fy + fz * fz);               // flux_kernel.elemfunc.c:27
-    const double k = -(half_ewt * double(0.2f));                              // :130, smoothing_coefficient = double(0.2f)
+    double k = e.k;
+    if (!LOADK) {
+        // The plan stores f = -+0.5*e, so sqrt(f.f) = |e|/2 exactly and -(|e|/2 * s) is the
+        // reference's -|e|*s*0.5 bit for bit (power-of-two scalings commute with rounding).
+        const double half_ewt = sqrt(fx * fx + fy * fy + fz * fz);           // flux_kernel.elemfunc.c:27
+        k = -(half_ewt * double(0.2f));                                       // :130, smoothing_coefficient = double(0.2f)
+    }
     // factor = k * (speed_a + speed_b + c_a + c_b), left-associated (:130-131); only the order
     // of the two sound speeds depends on which end this node is.
     const double c_a = me_is_b ? ot.c : me.c;
     const double c_b = me_is_b ? me.c : ot.c;
     const double factor = k * (((me.speed + ot.speed) + c_a) + c_b);
-    // flux_kernel.elemfunc.c:142-189 seen from this node ("me" - "other"; the b-side sign is
-    // folded into fx,fy,fz by the plan: x - f*y == x + (-f)*y exactly)
-    a0 += factor * (me.rho - ot.rho) + fx * (me.mx + ot.mx) + fy * (me.my + ot.my) + fz * (me.mz + ot.mz);
-    a4 += factor * (me.en - ot.en) + fx * (fm.ex + fo.ex) + fy * (fm.ey + fo.ey) + fz * (fm.ez + fo.ez);
-    a1 += factor * (me.mx - ot.mx) + fx * (fm.xx + fo.xx) + fy * (fm.xy + fo.xy) + fz * (fm.xz + fo.xz);
-    a2 += factor * (me.my - ot.my) + fx * (fm.xy + fo.xy) + fy * (fm.yy + fo.yy) + fz * (fm.yz + fo.yz);
-    a3 += factor * (me.mz - ot.mz) + fx * (fm.xz + fo.xz) + fy * (fm.yz + fo.yz) + fz * (fm.zz + fo.zz);
+    Flux5 f;
+    f.d = factor * (me.rho - ot.rho) + fx * (me.mx + ot.mx) + fy * (me.my + ot.my) + fz * (me.mz + ot.mz);
+    f.en = factor * (me.en - ot.en) + fx * (fm.ex + fo.ex) + fy * (fm.ey + fo.ey) + fz * (fm.ez + fo.ez);
+    f.mx = factor * (me.mx - ot.mx) + fx * (fm.xx + fo.xx) + fy * (fm.xy + fo.xy) + fz * (fm.xz + fo.xz);
+    f.my = factor * (me.my - ot.my) + fx * (fm.xy + fo.xy) + fy * (fm.yy + fo.yy) + fz * (fm.yz + fo.yz);
+    f.mz = factor * (me.mz - ot.mz) + fx * (fm.xz + fo.xz) + fy * (fm.yz + fo.yz) + fz * (fm.zz + fo.zz);
+    return f;
 }
 
-template <int MINW>
+template <int MINW, bool LOADK>
 __global__ void __launch_bounds__(kBlock, MINW)
 k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
             const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
@@ -300,15 +313,23 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
     const int32_t n_int = (classes & 1) ? rows_int[slice] : 0;
     const int32_t n_bnd = rows_bnd[slice];
     EdgeRow e0 = pad_row(), e1 = pad_row();
-    if (n_int > 0) e0 = load_row(nbr16, w, row0, lane);
-    if (n_int > 1) e1 = load_row(nbr16, w, int64_t(row0) + 1, lane);
+    if (n_int > 0) e0 = load_row<LOADK>(nbr16, w, row0, lane);
+    if (n_int > 1) e1 = load_row<LOADK>(nbr16, w, int64_t(row0) + 1, lane);
 
-    // ---- phase 1: stage + derive.  Own node first (coalesced), then the halo by id. ----
+    // ---- phase 1: stage + derive.  All loads are issued before any arithmetic: halo ids first
+    //      (the halo gather depends on them), then the own node's state (coalesced), then the
+    //      halo state by id. ----
     const int32_t h0 = tile_halo_ptr[t];
     const int32_t n_halo = tile_halo_ptr[t + 1] - h0;
-    const NodeQ me = load_and_derive(q, stride, i);
+    const bool has_halo = tid < n_halo;
+    const int64_t hnode = has_halo ? int64_t(tile_halo[h0 + tid]) : i;
+    const double o0 = q[i], o1 = q[stride + i], o2 = q[2 * stride + i], o3 = q[3 * stride + i], o4 = q[4 * stride + i];
+    const double g0 = q[hnode], g1 = q[stride + hnode], g2 = q[2 * stride + hnode], g3 = q[3 * stride + hnode],
+                 g4 = q[4 * stride + hnode];
+    const NodeQ me = make_nodeq(o0, o1, o2, o3, o4);
     lds_store_record(&tile[tid * kLdsRecD2], me);
-    for (int32_t h = tid; h < n_halo; h += kBlock)
+    if (has_halo) lds_store_record(&tile[(kTile + tid) * kLdsRecD2], make_nodeq(g0, g1, g2, g3, g4));
+    for (int32_t h = tid + kBlock; h < n_halo; h += kBlock)            // halo larger than the workgroup (rare)
         lds_store_record(&tile[(kTile + h) * kLdsRecD2], load_and_derive(q, stride, tile_halo[h0 + h]));
 
     const FluxC fm = flux_contribution(me);
@@ -320,52 +341,58 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
     const int32_t ovf0 = tile_ovf_ptr[t];
     __syncthreads();
 
-    // ---- phase 2: incidence rows, ids/weights fetched two rows ahead ----
-    auto edge = [&](const EdgeRow &e) {
-        const uint32_t slot = e.code & kT16SlotMask;
-        if (slot == kT16Pad) return;                                           // ELL padding
-        if (slot < uint32_t(kTileCap)) {
-            add_edge(me, fm, lds_load_record(&tile[slot * kLdsRecD2]), e, a0, a1, a2, a3, a4);
-        } else {                                                               // halo beyond the LDS capacity
-            const int64_t node = tile_ovf[ovf0 + int32_t(slot) - kTileCap];
-            add_edge(me, fm, load_and_derive(q, stride, node), e, a0, a1, a2, a3, a4);
-        }
-    };
+    // ---- phase 2: incidence rows two at a time (independent arithmetic, ordered accumulation),
+    //      ids/weights fetched two rows ahead ----
     for (int32_t r = 0; r < n_int; r += 2) {
         EdgeRow e2 = pad_row(), e3 = pad_row();
-        if (r + 2 < n_int) e2 = load_row(nbr16, w, int64_t(row0) + r + 2, lane);
-        if (r + 3 < n_int) e3 = load_row(nbr16, w, int64_t(row0) + r + 3, lane);
-        edge(e0);
-        edge(e1);
+        if (r + 2 < n_int) e2 = load_row<LOADK>(nbr16, w, int64_t(row0) + r + 2, lane);
+        if (r + 3 < n_int) e3 = load_row<LOADK>(nbr16, w, int64_t(row0) + r + 3, lane);
+
+        const uint32_t s0 = e0.code & kT16SlotMask, s1 = e1.code & kT16SlotMask;
+        const bool v0 = s0 != kT16Pad, v1 = s1 != kT16Pad;               // ELL padding contributes nothing
+        const bool o0 = v0 && s0 >= uint32_t(kTileCap), o1 = v1 && s1 >= uint32_t(kTileCap);
+        NodeQ n0, n1;
+        if (__builtin_expect(__any(o0 || o1), 0)) {
+            // ragged cluster: some neighbour did not fit the LDS tile, read it from HBM
+            n0 = o0 ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s0) - kTileCap])
+                    : lds_load_record(&tile[(v0 ? s0 : uint32_t(tid)) * kLdsRecD2]);
+            n1 = o1 ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s1) - kTileCap])
+                    : lds_load_record(&tile[(v1 ? s1 : uint32_t(tid)) * kLdsRecD2]);
+        } else {
+            n0 = lds_load_record(&tile[(v0 ? s0 : uint32_t(tid)) * kLdsRecD2]);
+            n1 = lds_load_record(&tile[(v1 ? s1 : uint32_t(tid)) * kLdsRecD2]);
+        }
+        const Flux5 f0 = edge_flux<LOADK>(me, fm, n0, e0);
+        const Flux5 f1 = edge_flux<LOADK>(me, fm, n1, e1);
+        // accumulate strictly in row order (the reference's summation order)
+        a0 = v0 ? a0 + f0.d : a0;   a1 = v0 ? a1 + f0.mx : a1;   a2 = v0 ? a2 + f0.my : a2;
+        a3 = v0 ? a3 + f0.mz : a3;  a4 = v0 ? a4 + f0.en : a4;
+        a0 = v1 ? a0 + f1.d : a0;   a1 = v1 ? a1 + f1.mx : a1;   a2 = v1 ? a2 + f1.my : a2;
+        a3 = v1 ? a3 + f1.mz : a3;  a4 = v1 ? a4 + f1.en : a4;
         e0 = e2; e1 = e3;
     }
 
     if ((classes & 6) && n_bnd > 0) {
         // The reference runs ALL solid-wall faces, then ALL far-field faces; the plan lists a
-        // node's faces in that order, so one pass per class keeps its per-node order.
+        // node's faces in exactly that order, so one walk over the rows keeps the per-node order.
         const int32_t first_bnd = rows_int[slice];
-        for (int pass = 0; pass < 2; pass++) {
-            const uint32_t want = pass == 0 ? kT16Wall : kT16Far;
-            if (!(classes & (pass == 0 ? 2 : 4))) continue;
-            for (int32_t r = 0; r < n_bnd; r++) {
-                const EdgeRow e = load_row(nbr16, w, int64_t(row0) + first_bnd + r, lane);
-                if (e.code != want) continue;
-                const double fx = e.fx, fy = e.fy, fz = e.fz;
-                if (pass == 0) {
-                    // flux_boundary_kernel.elemfunc.c:37-64: pressure force only
-                    a0 += 0.0;
-                    a1 += fx * me.p;
-                    a2 += fy * me.p;
-                    a3 += fz * me.p;
-                    a4 += 0.0;
-                } else {
-                    // flux_wall_kernel.elemfunc.c:51-88: average with the far-field state
-                    a0 += fx * (ff.var[1] + me.mx) + fy * (ff.var[2] + me.my) + fz * (ff.var[3] + me.mz);
-                    a4 += fx * (ff.fc_de[0] + fm.ex) + fy * (ff.fc_de[1] + fm.ey) + fz * (ff.fc_de[2] + fm.ez);
-                    a1 += fx * (ff.fc_mx[0] + fm.xx) + fy * (ff.fc_mx[1] + fm.xy) + fz * (ff.fc_mx[2] + fm.xz);
-                    a2 += fx * (ff.fc_my[0] + fm.xy) + fy * (ff.fc_my[1] + fm.yy) + fz * (ff.fc_my[2] + fm.yz);
-                    a3 += fx * (ff.fc_mz[0] + fm.xz) + fy * (ff.fc_mz[1] + fm.yz) + fz * (ff.fc_mz[2] + fm.zz);
-                }
+        for (int32_t r = 0; r < n_bnd; r++) {
+            const EdgeRow e = load_row<false>(nbr16, w, int64_t(row0) + first_bnd + r, lane);
+            const double fx = e.fx, fy = e.fy, fz = e.fz;
+            if (e.code == kT16Wall && (classes & 2)) {
+                // flux_boundary_kernel.elemfunc.c:37-64: pressure force only
+                a0 += 0.0;
+                a1 += fx * me.p;
+                a2 += fy * me.p;
+                a3 += fz * me.p;
+                a4 += 0.0;
+            } else if (e.code == kT16Far && (classes & 4)) {
+                // flux_wall_kernel.elemfunc.c:51-88: average with the far-field state
+                a0 += fx * (ff.var[1] + me.mx) + fy * (ff.var[2] + me.my) + fz * (ff.var[3] + me.mz);
+                a4 += fx * (ff.fc_de[0] + fm.ex) + fy * (ff.fc_de[1] + fm.ey) + fz * (ff.fc_de[2] + fm.ez);
+                a1 += fx * (ff.fc_mx[0] + fm.xx) + fy * (ff.fc_mx[1] + fm.xy) + fz * (ff.fc_mx[2] + fm.xz);
+                a2 += fx * (ff.fc_my[0] + fm.xy) + fy * (ff.fc_my[1] + fm.yy) + fz * (ff.fc_my[2] + fm.yz);
+                a3 += fx * (ff.fc_mz[0] + fm.xz) + fy * (ff.fc_mz[1] + fm.yz) + fz * (ff.fc_mz[2] + fm.zz);
             }
         }
     }
@@ -403,7 +430,7 @@ k_indirect_rw(int64_t nel, int64_t stride, const double *__restrict__ q, const i
         if (code & kRoleB) {
             a0 += o0; a1 += o1; a2 += o2; a3 += o3; a4 += o4;
         } else {
-            const double *wr = w + row * 192 + lane;
+            const double *wr = w + (row << 8) + lane;
             a0 += o0 + (-2.0 * wr[0]);
             a1 += o1 + (-2.0 * wr[128]);
             a2 += o2;
@@ -610,15 +637,15 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
                  int classes, int accumulate, int variant)
 {
     const dim3 grid(p.n_tiles), block(kBlock);
-#define MGCFD_TILE_LAUNCH(MINW)                                                                                \
-    hipLaunchKernelGGL((k_flux_tile<MINW>), grid, block, 0, st, p.nel, p.stride, q, p.slice_row0, p.rows_int,  \
-                       p.rows_bnd, p.nbr16, p.w, p.tile_halo_ptr, p.tile_halo, p.tile_ovf_ptr, p.tile_ovf, ff, \
-                       fluxes, classes, accumulate)
+#define MGCFD_TILE_LAUNCH(MINW, LOADK)                                                                         \
+    hipLaunchKernelGGL((k_flux_tile<MINW, LOADK>), grid, block, 0, st, p.nel, p.stride, q, p.slice_row0,       \
+                       p.rows_int, p.rows_bnd, p.nbr16, p.w, p.tile_halo_ptr, p.tile_halo, p.tile_ovf_ptr,     \
+                       p.tile_ovf, ff, fluxes, classes, accumulate)
     switch (variant) {
-        case 1: MGCFD_TILE_LAUNCH(1); break;
-        case 2: MGCFD_TILE_LAUNCH(2); break;
-        case 4: MGCFD_TILE_LAUNCH(4); break;
-        default: MGCFD_TILE_LAUNCH(3); break;       // 3 tiles of 52.5 KiB LDS fit a CU
+        case 1: MGCFD_TILE_LAUNCH(3, false); break;    // recompute k = -|e|*s*0.5 from the weights
+        case 2: MGCFD_TILE_LAUNCH(2, true); break;
+        case 3: MGCFD_TILE_LAUNCH(2, false); break;
+        default: MGCFD_TILE_LAUNCH(3, true); break;    // 3 tiles of 52.5 KiB LDS fit a CU
     }
 #undef MGCFD_TILE_LAUNCH
 }

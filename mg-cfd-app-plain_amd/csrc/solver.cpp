@@ -363,12 +363,13 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         {
             // edge weights as [row][component][lane] so each component load of a wave is one
             // contiguous 512-byte run
-            std::vector<double> ws(P.w.size() * 3);
+            std::vector<double> ws(P.w.size() * 4);
             for (size_t e = 0; e < P.w.size(); e++) {
                 const size_t row = e / kSlice, lane = e % kSlice;
-                ws[(row * 3 + 0) * kSlice + lane] = P.w[e].x;
-                ws[(row * 3 + 1) * kSlice + lane] = P.w[e].y;
-                ws[(row * 3 + 2) * kSlice + lane] = P.w[e].z;
+                ws[(row * 4 + 0) * kSlice + lane] = P.w[e].x;
+                ws[(row * 4 + 1) * kSlice + lane] = P.w[e].y;
+                ws[(row * 4 + 2) * kSlice + lane] = P.w[e].z;
+                ws[(row * 4 + 3) * kSlice + lane] = P.w[e].k;
             }
             lv.dp.w = dev_upload(ws);
         }

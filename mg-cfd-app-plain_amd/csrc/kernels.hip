@@ -168,19 +168,26 @@ k_init_variables(int64_t stride, FarField ff, double *__restrict__ q)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_step_factor_local(int64_t nel, int64_t stride, const double *__restrict__ q, const double *__restrict__ cbrt_vol,
-                    double *__restrict__ step_factors, unsigned long long *__restrict__ min_bits)
+                    double *__restrict__ step_factors, unsigned long long *__restrict__ min_bits,
+                    double *__restrict__ old_variables /* nullptr, or: fused copy<double>(old, variables) */)
 {
     __shared__ double s_min[kBlock / 64];
-    const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
-    double sf = __longlong_as_double(0x7F7F7F7F7F7F7F7FLL);
-    if (i < nel) {
-        const Derived d = derive(q[i], q[stride + i], q[2 * stride + i], q[3 * stride + i], q[4 * stride + i]);
+    double sf_min = __longlong_as_double(0x7F7F7F7F7F7F7F7FLL);
+    // grid-stride: few workgroups => few atomics on the one minimum word
+    for (int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x; i < nel; i += int64_t(gridDim.x) * kBlock) {
+        const double rho = q[i], mx = q[stride + i], my = q[2 * stride + i], mz = q[3 * stride + i], en = q[4 * stride + i];
+        if (old_variables) {
+            old_variables[i] = rho; old_variables[stride + i] = mx; old_variables[2 * stride + i] = my;
+            old_variables[3 * stride + i] = mz; old_variables[4 * stride + i] = en;
+        }
+        const Derived d = derive(rho, mx, my, mz, en);
         const double dt = cbrt_vol[i] / (d.speed + d.c);
-        sf = 0.5 * dt;
+        const double sf = 0.5 * dt;
         step_factors[i] = sf;
+        sf_min = fmin(sf_min, sf);
     }
-    sf = wave_min(sf);
-    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = sf;
+    sf_min = wave_min(sf_min);
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = sf_min;
     __syncthreads();
     if (threadIdx.x == 0) {
         double m = s_min[0];
@@ -204,11 +211,16 @@ k_step_factor_apply(int64_t nel, const unsigned long long *__restrict__ min_bits
 // compute_step_factor_legacy (cfd_loops.cpp:37-61), mesh_name = fvcorr only
 __global__ void __launch_bounds__(kBlock)
 k_step_factor_legacy(int64_t nel, int64_t stride, const double *__restrict__ q, const double *__restrict__ volumes,
-                     double *__restrict__ step_factors)
+                     double *__restrict__ step_factors, double *__restrict__ old_variables /* nullptr or fused copy */)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
-    const Derived d = derive(q[i], q[stride + i], q[2 * stride + i], q[3 * stride + i], q[4 * stride + i]);
+    const double rho = q[i], mx = q[stride + i], my = q[2 * stride + i], mz = q[3 * stride + i], en = q[4 * stride + i];
+    if (old_variables) {
+        old_variables[i] = rho; old_variables[stride + i] = mx; old_variables[2 * stride + i] = my;
+        old_variables[3 * stride + i] = mz; old_variables[4 * stride + i] = en;
+    }
+    const Derived d = derive(rho, mx, my, mz, en);
     step_factors[i] = 0.5 / (sqrt(volumes[i]) * (d.speed + d.c));
 }
 
@@ -446,25 +458,44 @@ k_indirect_rw(int64_t nel, int64_t stride, const double *__restrict__ q, const i
 
 // ------------------------------------------------------------------------------------------
 // time_step (cfd_loops.cpp:241-268): variables = old + sf/(RK+1-j) * fluxes ; fluxes = 0.
-// Fused: the check_for_invalid_variables flag (validation.cpp:107-138) —
-// err = (smallest offending ORIGINAL cell id << 8) | code.
+// Fused options (same operations, fewer passes over memory):
+//   * min_bits != nullptr: this is the first stage after compute_step_factor's reduction — apply
+//     its second half here, step_factors[i] = min_dt / volumes[i] (cfd_loops.cpp:146-156);
+//   * residuals != nullptr: last stage — residuals = variables - old_variables (validation.cpp:77-89);
+//   * check: raise the check_for_invalid_variables flag (validation.cpp:107-138),
+//     err = (smallest offending ORIGINAL cell id << 8) | code.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_time_step(int64_t nel, int64_t stride, double rk_div, const double *__restrict__ step_factors,
+k_time_step(int64_t nel, int64_t stride, double rk_div, double *__restrict__ step_factors,
             double *__restrict__ fluxes, const double *__restrict__ old_variables, double *__restrict__ q,
-            const int32_t *__restrict__ old_of_new, unsigned long long *__restrict__ err, int check)
+            const int32_t *__restrict__ old_of_new, unsigned long long *__restrict__ err, int check,
+            const unsigned long long *__restrict__ min_bits, const double *__restrict__ volumes,
+            double *__restrict__ residuals)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
-    const double factor = step_factors[i] / rk_div;
-    const double rho = old_variables[i] + factor * fluxes[i];
-    const double mx = old_variables[stride + i] + factor * fluxes[stride + i];
-    const double my = old_variables[2 * stride + i] + factor * fluxes[2 * stride + i];
-    const double mz = old_variables[3 * stride + i] + factor * fluxes[3 * stride + i];
-    const double en = old_variables[4 * stride + i] + factor * fluxes[4 * stride + i];
+    double sf;
+    if (min_bits) {
+        sf = __longlong_as_double(static_cast<long long>(*min_bits)) / volumes[i];
+        step_factors[i] = sf;
+    } else {
+        sf = step_factors[i];
+    }
+    const double factor = sf / rk_div;
+    const double r0 = old_variables[i], r1 = old_variables[stride + i], r2 = old_variables[2 * stride + i],
+                 r3 = old_variables[3 * stride + i], r4 = old_variables[4 * stride + i];
+    const double rho = r0 + factor * fluxes[i];
+    const double mx = r1 + factor * fluxes[stride + i];
+    const double my = r2 + factor * fluxes[2 * stride + i];
+    const double mz = r3 + factor * fluxes[3 * stride + i];
+    const double en = r4 + factor * fluxes[4 * stride + i];
     store_conserved(q, stride, i, rho, mx, my, mz, en);
     fluxes[i] = 0.0; fluxes[stride + i] = 0.0; fluxes[2 * stride + i] = 0.0;
     fluxes[3 * stride + i] = 0.0; fluxes[4 * stride + i] = 0.0;
+    if (residuals) {
+        residuals[i] = rho - r0; residuals[stride + i] = mx - r1; residuals[2 * stride + i] = my - r2;
+        residuals[3 * stride + i] = mz - r3; residuals[4 * stride + i] = en - r4;
+    }
     if (check) {
         const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
         int code = 0;
@@ -623,15 +654,19 @@ void launch_init_variables(hipStream_t st, int64_t stride, const FarField &ff, d
 { hipLaunchKernelGGL(k_init_variables, dim3(grid_for(stride)), dim3(kBlock), 0, st, stride, ff, q); }
 
 void launch_step_factor_local(hipStream_t st, int64_t nel, int64_t stride, const double *q, const double *cbrt_vol,
-                              double *sf, unsigned long long *min_bits)
-{ hipLaunchKernelGGL(k_step_factor_local, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, cbrt_vol, sf, min_bits); }
+                              double *sf, unsigned long long *min_bits, double *old_variables)
+{
+    const unsigned grid = grid_for(nel) < 512u ? grid_for(nel) : 512u;
+    hipLaunchKernelGGL(k_step_factor_local, dim3(grid), dim3(kBlock), 0, st, nel, stride, q, cbrt_vol, sf, min_bits, old_variables);
+}
 
 void launch_step_factor_apply(hipStream_t st, int64_t nel, const unsigned long long *min_bits,
                               const double *volumes, double *sf)
 { hipLaunchKernelGGL(k_step_factor_apply, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, min_bits, volumes, sf); }
 
-void launch_step_factor_legacy(hipStream_t st, int64_t nel, int64_t stride, const double *q, const double *volumes, double *sf)
-{ hipLaunchKernelGGL(k_step_factor_legacy, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, volumes, sf); }
+void launch_step_factor_legacy(hipStream_t st, int64_t nel, int64_t stride, const double *q, const double *volumes, double *sf,
+                               double *old_variables)
+{ hipLaunchKernelGGL(k_step_factor_legacy, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, volumes, sf, old_variables); }
 
 void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const FarField &ff, double *fluxes,
                  int classes, int accumulate, int variant)
@@ -656,12 +691,13 @@ void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, do
                        p.slice_row0, p.rows_int, p.nbr, p.w, fluxes);
 }
 
-void launch_time_step(hipStream_t st, int64_t nel, int64_t stride, int j, const double *sf, double *fluxes,
-                      const double *old_variables, double *q, const int32_t *old_of_new, unsigned long long *err, int check)
+void launch_time_step(hipStream_t st, int64_t nel, int64_t stride, int j, double *sf, double *fluxes,
+                      const double *old_variables, double *q, const int32_t *old_of_new, unsigned long long *err, int check,
+                      const unsigned long long *min_bits, const double *volumes, double *residuals)
 {
     const double rk_div = double(3 + 1 - j);    // double(RK+1-j), cfd_loops.cpp:243
     hipLaunchKernelGGL(k_time_step, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, rk_div, sf, fluxes,
-                       old_variables, q, old_of_new, err, check);
+                       old_variables, q, old_of_new, err, check, min_bits, volumes, residuals);
 }
 
 void launch_check_invalid(hipStream_t st, int64_t nel, int64_t stride, const double *q, const int32_t *old_of_new,

@@ -7,17 +7,18 @@
     namespace mgcfd { namespace NS {                                                                                 \
     void launch_init_variables(hipStream_t, int64_t stride, const FarField &, double *q);                            \
     void launch_step_factor_local(hipStream_t, int64_t nel, int64_t stride, const double *q, const double *cbrt_vol, \
-                                  double *sf, unsigned long long *min_bits);                                         \
+                                  double *sf, unsigned long long *min_bits, double *old_variables);                  \
     void launch_step_factor_apply(hipStream_t, int64_t nel, const unsigned long long *min_bits,                      \
                                   const double *volumes, double *sf);                                                \
     void launch_step_factor_legacy(hipStream_t, int64_t nel, int64_t stride, const double *q, const double *volumes, \
-                                   double *sf);                                                                      \
+                                   double *sf, double *old_variables);                                               \
     void launch_flux(hipStream_t, const DevicePlan &, const double *q, const FarField &, double *fluxes,             \
                      int classes, int accumulate, int variant);                                                      \
     void launch_indirect_rw(hipStream_t, const DevicePlan &, const double *q, double *fluxes);                       \
-    void launch_time_step(hipStream_t, int64_t nel, int64_t stride, int j, const double *sf, double *fluxes,         \
+    void launch_time_step(hipStream_t, int64_t nel, int64_t stride, int j, double *sf, double *fluxes,               \
                           const double *old_variables, double *q, const int32_t *old_of_new,                         \
-                          unsigned long long *err, int check);                                                       \
+                          unsigned long long *err, int check, const unsigned long long *min_bits,                    \
+                          const double *volumes, double *residuals);                                                 \
     void launch_check_invalid(hipStream_t, int64_t nel, int64_t stride, const double *q,                             \
                               const int32_t *old_of_new, unsigned long long *err);                                   \
     void launch_residual(hipStream_t, int64_t stride, const double *old_variables, const double *q,                  \

@@ -143,12 +143,13 @@ struct mgcfd_solver {
         DeviceLevel &lv = level(l);
         HIP_CHECK(hipMemcpyAsync(lv.old_variables, lv.q, sizeof(double) * 5 * lv.dp.stride, hipMemcpyDeviceToDevice, stream));
     }
-    void op_step_factor_local(int l)
+    void op_step_factor_local(int l, bool fuse_copy_old = false)
     {
         DeviceLevel &lv = level(l);
         HIP_CHECK(hipMemsetAsync(lv.min_bits, 0x7F, sizeof(unsigned long long), stream));
-        if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits);
-        else fast::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits);
+        double *old = fuse_copy_old ? lv.old_variables : nullptr;
+        if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits, old);
+        else fast::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits, old);
     }
     void op_step_factor_apply(int l)
     {
@@ -156,18 +157,24 @@ struct mgcfd_solver {
         if (opt_exact) exact::launch_step_factor_apply(stream, lv.info.nel, lv.min_bits, lv.volumes, lv.step_factors);
         else fast::launch_step_factor_apply(stream, lv.info.nel, lv.min_bits, lv.volumes, lv.step_factors);
     }
-    void op_step_factor(int l)
+    // fused = true: also copy old_variables <- variables, and leave the "/ volume" half of the
+    // global time step to the first time_step of the sweep (returns true in that case)
+    bool op_step_factor(int l, bool fused = false)
     {
         DeviceLevel &lv = level(l);
         Timed t(this, l, MGCFD_LOOP_COMPUTE_STEP);
+        bool apply_pending = false;
         if (mesh_variant == MGCFD_MESH_FVCORR) {
-            if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors);
-            else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors);
-            } else {
-            op_step_factor_local(l);
-            op_step_factor_apply(l);
+            double *old = fused ? lv.old_variables : nullptr;
+            if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors, old);
+            else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors, old);
+        } else {
+            op_step_factor_local(l, fused);
+            if (fused) apply_pending = true;
+            else op_step_factor_apply(l);
         }
         lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;
+        return apply_pending;
     }
     // classes: bit0 internal, bit1 solid wall (-1), bit2 far field (-2)
     void op_flux(int l, int classes)
@@ -195,13 +202,15 @@ struct mgcfd_solver {
         HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * lv.dp.stride, stream));
         lv.fluxes_zero = true;
     }
-    void op_time_step(int l, int j)
+    void op_time_step(int l, int j, bool apply_min = false, bool with_residual = false)
     {
         if (j < 0 || j >= MGCFD_RK) throw std::invalid_argument("RK stage out of range");
         DeviceLevel &lv = level(l);
         Timed t(this, l, MGCFD_LOOP_TIME_STEP);
-        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check);
-        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check);
+        const unsigned long long *mb = apply_min ? lv.min_bits : nullptr;
+        double *res = with_residual ? lv.residuals : nullptr;
+        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, mb, lv.volumes, res);
+        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, mb, lv.volumes, res);
         lv.fluxes_zero = true;
         lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
     }
@@ -595,24 +604,24 @@ int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_c
 
 // One smoothing sweep = the per-level body of the reference's cycle loop
 // (src/euler3d_cpu_double.cpp:383-508): copy, step factor, RK x (fluxes, time_step), residual.
-static void smooth_once(mgcfd_solver *s, int level, bool split_flux_classes)
+// Same operations, fewer passes over memory: the copy rides on the step-factor kernel, the
+// "/ volume" half of the global time step on the first time_step, the residual on the last, and
+// the three edge classes share one flux launch.
+static void smooth_once(mgcfd_solver *s, int level)
 {
-    s->op_copy_old(level);                                         // :383
-    s->op_step_factor(level);                                      // :388-395
+    const bool apply_pending = s->op_step_factor(level, true);     // :383 + :388-395
     for (int j = 0; j < MGCFD_RK; j++) {                           // :397-506
-        if (split_flux_classes) { s->op_flux(level, 1); s->op_flux(level, 2); s->op_flux(level, 4); }
-        else s->op_flux(level, 7);
-        s->op_time_step(level, j);
+        s->op_flux(level, 7);
+        s->op_time_step(level, j, apply_pending && j == 0, j == MGCFD_RK - 1);   // + :508 on the last stage
         if (s->opt_indirect_rw) { s->op_indirect_rw(level); s->op_zero_fluxes(level); }
     }
-    s->op_residual(level);                                         // :508
 }
 
 int mgcfd_smooth(mgcfd_solver *s, int level, int sweeps)
 {
     OP({
         s->level(level);
-        for (int k = 0; k < sweeps; k++) smooth_once(s, level, false);
+        for (int k = 0; k < sweeps; k++) smooth_once(s, level);
     });
 }
 
@@ -628,7 +637,7 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
         int level = 0;
         bool going_up = true;
         for (int cyc = 0; cyc < cycles;) {
-            smooth_once(s, level, false);                                  // :383-508
+            smooth_once(s, level);                                  // :383-508
             if (level == 0) {                                              // :509-512
                 s->op_sumsq(0);
                 HIP_CHECK(hipMemcpyAsync(rms_dev + cyc, s->L[0].sumsq, sizeof(double), hipMemcpyDeviceToDevice, s->stream));

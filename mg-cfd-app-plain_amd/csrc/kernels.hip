@@ -168,13 +168,13 @@ k_init_variables(int64_t stride, FarField ff, double *__restrict__ q)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_step_factor_local(int64_t nel, int64_t stride, const double *__restrict__ q, const double *__restrict__ cbrt_vol,
-                    double *__restrict__ step_factors, unsigned long long *__restrict__ min_bits,
+                    double *__restrict__ step_factors, double *__restrict__ partial_min,
                     double *__restrict__ old_variables /* nullptr, or: fused copy<double>(old, variables) */)
 {
     __shared__ double s_min[kBlock / 64];
-    double sf_min = __longlong_as_double(0x7F7F7F7F7F7F7F7FLL);
-    // grid-stride: few workgroups => few atomics on the one minimum word
-    for (int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x; i < nel; i += int64_t(gridDim.x) * kBlock) {
+    const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    double sf = __longlong_as_double(0x7FF0000000000000LL);          // +inf
+    if (i < nel) {
         const double rho = q[i], mx = q[stride + i], my = q[2 * stride + i], mz = q[3 * stride + i], en = q[4 * stride + i];
         if (old_variables) {
             old_variables[i] = rho; old_variables[stride + i] = mx; old_variables[2 * stride + i] = my;
@@ -182,30 +182,52 @@ k_step_factor_local(int64_t nel, int64_t stride, const double *__restrict__ q, c
         }
         const Derived d = derive(rho, mx, my, mz, en);
         const double dt = cbrt_vol[i] / (d.speed + d.c);
-        const double sf = 0.5 * dt;
+        sf = 0.5 * dt;
         step_factors[i] = sf;
-        sf_min = fmin(sf_min, sf);
     }
-    sf_min = wave_min(sf_min);
-    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = sf_min;
+    // One partial minimum per workgroup; the consumer reduces them (min is order independent,
+    // and one atomic word would serialise ~1200 updates).
+    sf = wave_min(sf);
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = sf;
     __syncthreads();
     if (threadIdx.x == 0) {
         double m = s_min[0];
         for (int w = 1; w < kBlock / 64; w++) m = fmin(m, s_min[w]);
-        // positive doubles order like their bit patterns
-        atomicMin(min_bits, static_cast<unsigned long long>(__double_as_longlong(m)));
+        partial_min[blockIdx.x] = m;
     }
+}
+
+// minimum of the partial minima, by every thread of a workgroup (result in all lanes)
+__device__ __forceinline__ double block_min_of_partials(const double *__restrict__ partial_min, int n_partial)
+{
+    __shared__ double s_red[kBlock / 64];
+    double m = __longlong_as_double(0x7FF0000000000000LL);
+    for (int k = threadIdx.x; k < n_partial; k += kBlock) m = fmin(m, partial_min[k]);
+    m = wave_min(m);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    double r = s_red[0];
+    for (int w = 1; w < kBlock / 64; w++) r = fmin(r, s_red[w]);
+    return r;
+}
+
+// partial minima -> one scalar (only needed where the scalar itself is the interface: the
+// kernel-granular API and the multi-GPU all-reduce hook)
+__global__ void __launch_bounds__(kBlock)
+k_min_reduce(const double *__restrict__ partial_min, int n_partial, double *__restrict__ out)
+{
+    const double m = block_min_of_partials(partial_min, n_partial);
+    if (threadIdx.x == 0) out[0] = m;
 }
 
 // second half (cfd_loops.cpp:146-156): step_factors[i] = min_dt / volumes[i]
 __global__ void __launch_bounds__(kBlock)
-k_step_factor_apply(int64_t nel, const unsigned long long *__restrict__ min_bits,
+k_step_factor_apply(int64_t nel, const double *__restrict__ min_dt_scalar,
                     const double *__restrict__ volumes, double *__restrict__ step_factors)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     if (i >= nel) return;
-    const double min_dt = __longlong_as_double(static_cast<long long>(*min_bits));
-    step_factors[i] = min_dt / volumes[i];
+    step_factors[i] = min_dt_scalar[0] / volumes[i];
 }
 
 // compute_step_factor_legacy (cfd_loops.cpp:37-61), mesh_name = fvcorr only
@@ -459,8 +481,11 @@ k_indirect_rw(int64_t nel, int64_t stride, const double *__restrict__ q, const i
 // ------------------------------------------------------------------------------------------
 // time_step (cfd_loops.cpp:241-268): variables = old + sf/(RK+1-j) * fluxes ; fluxes = 0.
 // Fused options (same operations, fewer passes over memory):
-//   * min_bits != nullptr: this is the first stage after compute_step_factor's reduction — apply
-//     its second half here, step_factors[i] = min_dt / volumes[i] (cfd_loops.cpp:146-156);
+//   * partial_min != nullptr: this is the first stage after compute_step_factor's first half —
+//     finish it here: min over the workgroups' partial minima, then
+//     step_factors[i] = min_dt / volumes[i] (cfd_loops.cpp:137-156);
+//   * zero_fluxes == 0: leave fluxes[] stale; the caller treats the array as logically zero and
+//     the next flux launch overwrites it (saves the 40 B/node of zero stores);
 //   * residuals != nullptr: last stage — residuals = variables - old_variables (validation.cpp:77-89);
 //   * check: raise the check_for_invalid_variables flag (validation.cpp:107-138),
 //     err = (smallest offending ORIGINAL cell id << 8) | code.
@@ -469,14 +494,16 @@ __global__ void __launch_bounds__(kBlock)
 k_time_step(int64_t nel, int64_t stride, double rk_div, double *__restrict__ step_factors,
             double *__restrict__ fluxes, const double *__restrict__ old_variables, double *__restrict__ q,
             const int32_t *__restrict__ old_of_new, unsigned long long *__restrict__ err, int check,
-            const unsigned long long *__restrict__ min_bits, const double *__restrict__ volumes,
-            double *__restrict__ residuals)
+            const double *__restrict__ partial_min, int n_partial, const double *__restrict__ volumes,
+            double *__restrict__ residuals, int zero_fluxes)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    double min_dt = 0.0;
+    if (partial_min) min_dt = block_min_of_partials(partial_min, n_partial);   // all threads take part
     if (i >= nel) return;
     double sf;
-    if (min_bits) {
-        sf = __longlong_as_double(static_cast<long long>(*min_bits)) / volumes[i];
+    if (partial_min) {
+        sf = min_dt / volumes[i];
         step_factors[i] = sf;
     } else {
         sf = step_factors[i];
@@ -490,8 +517,10 @@ k_time_step(int64_t nel, int64_t stride, double rk_div, double *__restrict__ ste
     const double mz = r3 + factor * fluxes[3 * stride + i];
     const double en = r4 + factor * fluxes[4 * stride + i];
     store_conserved(q, stride, i, rho, mx, my, mz, en);
-    fluxes[i] = 0.0; fluxes[stride + i] = 0.0; fluxes[2 * stride + i] = 0.0;
-    fluxes[3 * stride + i] = 0.0; fluxes[4 * stride + i] = 0.0;
+    if (zero_fluxes) {
+        fluxes[i] = 0.0; fluxes[stride + i] = 0.0; fluxes[2 * stride + i] = 0.0;
+        fluxes[3 * stride + i] = 0.0; fluxes[4 * stride + i] = 0.0;
+    }
     if (residuals) {
         residuals[i] = rho - r0; residuals[stride + i] = mx - r1; residuals[2 * stride + i] = my - r2;
         residuals[3 * stride + i] = mz - r3; residuals[4 * stride + i] = en - r4;
@@ -653,16 +682,17 @@ static inline unsigned grid_for(int64_t n) { return static_cast<unsigned>((n + k
 void launch_init_variables(hipStream_t st, int64_t stride, const FarField &ff, double *q)
 { hipLaunchKernelGGL(k_init_variables, dim3(grid_for(stride)), dim3(kBlock), 0, st, stride, ff, q); }
 
+// partial_min must hold grid_for(nel) doubles
 void launch_step_factor_local(hipStream_t st, int64_t nel, int64_t stride, const double *q, const double *cbrt_vol,
-                              double *sf, unsigned long long *min_bits, double *old_variables)
-{
-    const unsigned grid = grid_for(nel) < 512u ? grid_for(nel) : 512u;
-    hipLaunchKernelGGL(k_step_factor_local, dim3(grid), dim3(kBlock), 0, st, nel, stride, q, cbrt_vol, sf, min_bits, old_variables);
-}
+                              double *sf, double *partial_min, double *old_variables)
+{ hipLaunchKernelGGL(k_step_factor_local, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, cbrt_vol, sf, partial_min, old_variables); }
 
-void launch_step_factor_apply(hipStream_t st, int64_t nel, const unsigned long long *min_bits,
+void launch_min_reduce(hipStream_t st, int64_t nel, const double *partial_min, double *out)
+{ hipLaunchKernelGGL(k_min_reduce, dim3(1), dim3(kBlock), 0, st, partial_min, int(grid_for(nel)), out); }
+
+void launch_step_factor_apply(hipStream_t st, int64_t nel, const double *min_dt_scalar,
                               const double *volumes, double *sf)
-{ hipLaunchKernelGGL(k_step_factor_apply, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, min_bits, volumes, sf); }
+{ hipLaunchKernelGGL(k_step_factor_apply, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, min_dt_scalar, volumes, sf); }
 
 void launch_step_factor_legacy(hipStream_t st, int64_t nel, int64_t stride, const double *q, const double *volumes, double *sf,
                                double *old_variables)
@@ -693,11 +723,12 @@ void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, do
 
 void launch_time_step(hipStream_t st, int64_t nel, int64_t stride, int j, double *sf, double *fluxes,
                       const double *old_variables, double *q, const int32_t *old_of_new, unsigned long long *err, int check,
-                      const unsigned long long *min_bits, const double *volumes, double *residuals)
+                      const double *partial_min, const double *volumes, double *residuals, int zero_fluxes)
 {
     const double rk_div = double(3 + 1 - j);    // double(RK+1-j), cfd_loops.cpp:243
     hipLaunchKernelGGL(k_time_step, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, rk_div, sf, fluxes,
-                       old_variables, q, old_of_new, err, check, min_bits, volumes, residuals);
+                       old_variables, q, old_of_new, err, check, partial_min, int(grid_for(nel)), volumes, residuals,
+                       zero_fluxes);
 }
 
 void launch_check_invalid(hipStream_t st, int64_t nel, int64_t stride, const double *q, const int32_t *old_of_new,

@@ -7,8 +7,9 @@
     namespace mgcfd { namespace NS {                                                                                 \
     void launch_init_variables(hipStream_t, int64_t stride, const FarField &, double *q);                            \
     void launch_step_factor_local(hipStream_t, int64_t nel, int64_t stride, const double *q, const double *cbrt_vol, \
-                                  double *sf, unsigned long long *min_bits, double *old_variables);                  \
-    void launch_step_factor_apply(hipStream_t, int64_t nel, const unsigned long long *min_bits,                      \
+                                  double *sf, double *partial_min, double *old_variables);                           \
+    void launch_min_reduce(hipStream_t, int64_t nel, const double *partial_min, double *out);                        \
+    void launch_step_factor_apply(hipStream_t, int64_t nel, const double *min_dt_scalar,                             \
                                   const double *volumes, double *sf);                                                \
     void launch_step_factor_legacy(hipStream_t, int64_t nel, int64_t stride, const double *q, const double *volumes, \
                                    double *sf, double *old_variables);                                               \
@@ -17,8 +18,8 @@
     void launch_indirect_rw(hipStream_t, const DevicePlan &, const double *q, double *fluxes);                       \
     void launch_time_step(hipStream_t, int64_t nel, int64_t stride, int j, double *sf, double *fluxes,               \
                           const double *old_variables, double *q, const int32_t *old_of_new,                         \
-                          unsigned long long *err, int check, const unsigned long long *min_bits,                    \
-                          const double *volumes, double *residuals);                                                 \
+                          unsigned long long *err, int check, const double *partial_min,                             \
+                          const double *volumes, double *residuals, int zero_fluxes);                                \
     void launch_check_invalid(hipStream_t, int64_t nel, int64_t stride, const double *q,                             \
                               const int32_t *old_of_new, unsigned long long *err);                                   \
     void launch_residual(hipStream_t, int64_t stride, const double *old_variables, const double *q,                  \

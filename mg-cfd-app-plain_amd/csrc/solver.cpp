@@ -59,10 +59,12 @@ struct DeviceLevel {
     // SoA state, stride = dp.stride: q = the reference's `variables`
     double *q = nullptr, *old_variables = nullptr, *fluxes = nullptr, *residuals = nullptr;   // [5][stride]
     double *step_factors = nullptr, *volumes = nullptr, *cbrt_vol = nullptr;                  // [stride]
-    unsigned long long *min_bits = nullptr;
+    double *min_dt = nullptr;            // global-min time step scalar (after the reduction)
+    double *partial_min = nullptr;       // one partial minimum per step-factor workgroup
     double *sumsq = nullptr, *partials = nullptr;
     int n_partials = 0;
-    bool fluxes_zero = true;             // fluxes[] is known to hold zeros (skip the read in flux_gather)
+    bool fluxes_zero = true;             // fluxes[] is logically zero (the flux launch need not read it)
+    bool fluxes_stale = false;           // ... but its memory has not been zeroed (lazy zero after a fused time_step)
     bool has_transfer = false;           // plan to the next-coarser level present
     int64_t iters[MGCFD_NUM_LOOPS] = {0};
     double times[MGCFD_NUM_LOOPS] = {0};
@@ -143,19 +145,28 @@ struct mgcfd_solver {
         DeviceLevel &lv = level(l);
         HIP_CHECK(hipMemcpyAsync(lv.old_variables, lv.q, sizeof(double) * 5 * lv.dp.stride, hipMemcpyDeviceToDevice, stream));
     }
-    void op_step_factor_local(int l, bool fuse_copy_old = false)
+    // first half of compute_step_factor; reduce_to_scalar also folds the workgroups' partial
+    // minima into the one fp64 scalar the kernel-granular API / the all-reduce hook work on
+    void op_step_factor_local(int l, bool fuse_copy_old, bool reduce_to_scalar)
     {
         DeviceLevel &lv = level(l);
-        HIP_CHECK(hipMemsetAsync(lv.min_bits, 0x7F, sizeof(unsigned long long), stream));
         double *old = fuse_copy_old ? lv.old_variables : nullptr;
-        if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits, old);
-        else fast::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.min_bits, old);
+        if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.partial_min, old);
+        else fast::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.partial_min, old);
+        if (reduce_to_scalar) exact::launch_min_reduce(stream, lv.info.nel, lv.partial_min, lv.min_dt);
     }
     void op_step_factor_apply(int l)
     {
         DeviceLevel &lv = level(l);
-        if (opt_exact) exact::launch_step_factor_apply(stream, lv.info.nel, lv.min_bits, lv.volumes, lv.step_factors);
-        else fast::launch_step_factor_apply(stream, lv.info.nel, lv.min_bits, lv.volumes, lv.step_factors);
+        if (opt_exact) exact::launch_step_factor_apply(stream, lv.info.nel, lv.min_dt, lv.volumes, lv.step_factors);
+        else fast::launch_step_factor_apply(stream, lv.info.nel, lv.min_dt, lv.volumes, lv.step_factors);
+    }
+    // materialise a logically-zero flux array before anything reads its memory
+    void settle_fluxes(DeviceLevel &lv)
+    {
+        if (!lv.fluxes_stale) return;
+        HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * lv.dp.stride, stream));
+        lv.fluxes_stale = false;
     }
     // fused = true: also copy old_variables <- variables, and leave the "/ volume" half of the
     // global time step to the first time_step of the sweep (returns true in that case)
@@ -169,7 +180,7 @@ struct mgcfd_solver {
             if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors, old);
             else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors, old);
         } else {
-            op_step_factor_local(l, fused);
+            op_step_factor_local(l, fused, !fused);
             if (fused) apply_pending = true;
             else op_step_factor_apply(l);
         }
@@ -181,15 +192,18 @@ struct mgcfd_solver {
     {
         DeviceLevel &lv = level(l);
         Timed t(this, l, MGCFD_LOOP_FLUX, (classes & 1) != 0);
+        if (classes != 7) settle_fluxes(lv);                // a partial launch leaves other nodes' memory as it is
         const int accumulate = lv.fluxes_zero ? 0 : 1;     // 0.0 + x: same bits either way
         if (opt_exact) exact::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant);
         else fast::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant);
         lv.fluxes_zero = false;
+        lv.fluxes_stale = false;
         if (classes & 1) lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
     }
     void op_indirect_rw(int l)
     {
         DeviceLevel &lv = level(l);
+        settle_fluxes(lv);
         Timed t(this, l, MGCFD_LOOP_INDIRECT_RW);
         if (opt_exact) exact::launch_indirect_rw(stream, lv.dp, lv.q, lv.fluxes);
         else fast::launch_indirect_rw(stream, lv.dp, lv.q, lv.fluxes);
@@ -201,16 +215,19 @@ struct mgcfd_solver {
         DeviceLevel &lv = level(l);
         HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * lv.dp.stride, stream));
         lv.fluxes_zero = true;
+        lv.fluxes_stale = false;
     }
-    void op_time_step(int l, int j, bool apply_min = false, bool with_residual = false)
+    void op_time_step(int l, int j, bool apply_min = false, bool with_residual = false, bool lazy_zero = false)
     {
         if (j < 0 || j >= MGCFD_RK) throw std::invalid_argument("RK stage out of range");
         DeviceLevel &lv = level(l);
+        settle_fluxes(lv);
         Timed t(this, l, MGCFD_LOOP_TIME_STEP);
-        const unsigned long long *mb = apply_min ? lv.min_bits : nullptr;
+        const double *pm = apply_min ? lv.partial_min : nullptr;
         double *res = with_residual ? lv.residuals : nullptr;
-        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, mb, lv.volumes, res);
-        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, mb, lv.volumes, res);
+        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, pm, lv.volumes, res, lazy_zero ? 0 : 1);
+        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, pm, lv.volumes, res, lazy_zero ? 0 : 1);
+        lv.fluxes_stale = lazy_zero;
         lv.fluxes_zero = true;
         lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
     }
@@ -272,7 +289,7 @@ mgcfd_solver::~mgcfd_solver()
     for (auto e : free_events) (void)hipEventDestroy(e);
     for (auto &lv : L) {
         void *ptrs[] = {lv.dp.nbr16, lv.dp.tile_halo_ptr, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
-                        lv.cbrt_vol, lv.min_bits, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
+                        lv.cbrt_vol, lv.min_dt, lv.partial_min, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.pro,
                         lv.dp.pro_parent, lv.dp.pro_wsum};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -358,7 +375,8 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.fluxes = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.residuals = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.step_factors = dev_alloc<double>(static_cast<size_t>(stride));
-        lv.min_bits = dev_alloc<unsigned long long>(1);
+        lv.min_dt = dev_alloc<double>(1);
+        lv.partial_min = dev_alloc<double>(static_cast<size_t>((nel + 255) / 256));
         lv.sumsq = dev_alloc<double>(1);
         lv.n_partials = static_cast<int>(std::min<int64_t>(1024, (nel * 5 + 255) / 256));
         lv.partials = dev_alloc<double>(static_cast<size_t>(lv.n_partials));
@@ -564,12 +582,12 @@ int mgcfd_step_factor_local(mgcfd_solver *s, int level)
 {
     OP({
         if (s->mesh_variant == MGCFD_MESH_FVCORR) throw std::invalid_argument("fvcorr uses a local time step: nothing to reduce");
-        s->op_step_factor_local(level);
+        s->op_step_factor_local(level, false, true);
         s->level(level).iters[MGCFD_LOOP_COMPUTE_STEP] += s->level(level).info.nel;
     });
 }
 int mgcfd_step_factor_min_devptr(mgcfd_solver *s, int level, void **devptr)
-{ REQUIRE(devptr); OP(*devptr = s->level(level).min_bits); }
+{ REQUIRE(devptr); OP(*devptr = s->level(level).min_dt); }
 int mgcfd_step_factor_apply(mgcfd_solver *s, int level) { OP(s->op_step_factor_apply(level)); }
 int mgcfd_residual_sumsq(mgcfd_solver *s, int level, void **devptr)
 { REQUIRE(devptr); OP({ s->op_sumsq(level); *devptr = s->level(level).sumsq; }); }
@@ -612,7 +630,8 @@ static void smooth_once(mgcfd_solver *s, int level)
     const bool apply_pending = s->op_step_factor(level, true);     // :383 + :388-395
     for (int j = 0; j < MGCFD_RK; j++) {                           // :397-506
         s->op_flux(level, 7);
-        s->op_time_step(level, j, apply_pending && j == 0, j == MGCFD_RK - 1);   // + :508 on the last stage
+        // the indirect_rw probe reads fluxes[] right after, so zero for real when it is on
+        s->op_time_step(level, j, apply_pending && j == 0, j == MGCFD_RK - 1, !s->opt_indirect_rw);   // + :508 on the last stage
         if (s->opt_indirect_rw) { s->op_indirect_rw(level); s->op_zero_fluxes(level); }
     }
 }
@@ -688,6 +707,7 @@ int mgcfd_get_array(mgcfd_solver *s, int level, int which, double *out)
         DeviceLevel &lv = s->level(level);
         int nc = 0;
         double *src = array_ptr(lv, which, &nc);
+        if (which == MGCFD_ARR_FLUXES) s->settle_fluxes(lv);
         const int64_t stride = lv.dp.stride;
         std::vector<double> tmp(static_cast<size_t>(stride) * nc);
         HIP_CHECK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -718,7 +738,7 @@ int mgcfd_set_array(mgcfd_solver *s, int level, int which, const double *in)
         }
         HIP_CHECK(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
         HIP_CHECK(hipStreamSynchronize(s->stream));
-        if (which == MGCFD_ARR_FLUXES) lv.fluxes_zero = false;
+        if (which == MGCFD_ARR_FLUXES) { lv.fluxes_zero = false; lv.fluxes_stale = false; }
     });
 }
 int mgcfd_get_edges(mgcfd_solver *s, int level, mgcfd_edge *out)

@@ -58,10 +58,13 @@ enum {
     MGCFD_OPT_EXACT = 0,       /* 1 (default): kernels compiled without FMA contraction and summing in the
                                   reference's order => bit-identical to the reference built with
                                   -ffp-contract=off.  0: contraction allowed (faster, ~1e-16 relative). */
-    MGCFD_OPT_TIMING = 1,      /* 1: bracket every loop with hipEvents (Times.csv columns); 2: only the flux launches */
+    MGCFD_OPT_TIMING = 1,      /* 1: bracket every loop with hipEvents (Times.csv columns); 2: only the flux launches of every 8th sweep */
     MGCFD_OPT_INDIRECT_RW = 2, /* 1: also run the indirect_rw probe each RK stage, as the reference's main() does */
     MGCFD_OPT_CHECK_INVALID = 3, /* 1 (default): NaN / negativity check every RK stage (validation.cpp:107-138) */
-    MGCFD_OPT_FLUX_VARIANT = 4 /* 0 (default) node-centred gather; other values select experimental kernels */
+    MGCFD_OPT_FLUX_VARIANT = 4, /* 0 (default): edge-length factor streamed; 1: recomputed from the weights */
+    MGCFD_OPT_FUSE_UPDATE = 5, /* 1 (default): mgcfd_smooth / mgcfd_run_cycles run each Runge-Kutta stage as ONE
+                                  launch (fluxes + time_step, same operations); 0: one launch per loop */
+    MGCFD_OPT_GRAPH = 6        /* 1 (default): replay each smoothing sweep from a captured hipGraph */
 };
 
 /* Same 40-byte layout as the reference's edge_neighbour (src/Base/definitions.h:83). */

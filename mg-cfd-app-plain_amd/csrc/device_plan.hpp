@@ -21,6 +21,21 @@ struct FarField {
     double fc_mx[3], fc_my[3], fc_mz[3], fc_de[3];
 };
 
+// Arguments of the time_step half of a fused flux + time_step launch (kernels.hip: k_flux_tile<FUSE>).
+struct FusedStep {
+    double rk_div = 1.0;                      // double(RK+1-j)
+    double *step_factors = nullptr;
+    const double *old_variables = nullptr;
+    double *q_out = nullptr;                  // new variables (must differ from the launch's input state)
+    const double *partial_min = nullptr;      // != nullptr on the first stage: finish compute_step_factor here
+    int n_partial = 0;
+    const double *volumes = nullptr;
+    double *residuals = nullptr;              // != nullptr on the last stage: residuals = variables - old
+    const int32_t *old_of_new = nullptr;
+    unsigned long long *err = nullptr;
+    int check = 0;
+};
+
 // Device pointers of one level's gather plan.
 struct DevicePlan {
     int64_t nel = 0;

@@ -324,16 +324,22 @@ __device__ __forceinline__ Flux5 edge_flux(const NodeQ &me, const FluxC &fm, con
     return f;
 }
 
-template <int MINW, bool LOADK>
+template <int MINW, bool LOADK, bool FUSE>
 __global__ void __launch_bounds__(kBlock, MINW)
 k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
             const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
             const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
             const int32_t *__restrict__ tile_halo_ptr, const int32_t *__restrict__ tile_halo,
             const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
-            double *__restrict__ fluxes, int classes, int accumulate)
+            double *__restrict__ fluxes, int classes, int accumulate, FusedStep fs)
 {
     __shared__ double2 tile[kTileCap * kLdsRecD2];
+
+    // FUSE: this launch is a whole Runge-Kutta stage — the node's complete flux never leaves
+    // registers; time_step (cfd_loops.cpp:241-268) is applied to it at the end and the new state
+    // goes to fs.q_out (a different buffer: neighbours still read the stage's input from q).
+    double min_dt = 0.0;
+    if (FUSE && fs.partial_min) min_dt = block_min_of_partials(fs.partial_min, fs.n_partial);
 
     const unsigned t = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
@@ -365,6 +371,14 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
     if (has_halo) lds_store_record(&tile[(kTile + tid) * kLdsRecD2], make_nodeq(g0, g1, g2, g3, g4));
     for (int32_t h = tid + kBlock; h < n_halo; h += kBlock)            // halo larger than the workgroup (rare)
         lds_store_record(&tile[(kTile + h) * kLdsRecD2], load_and_derive(q, stride, tile_halo[h0 + h]));
+
+    // FUSE: the time_step operands are independent of the flux — fetch them now, under the row loop
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, sf_in = 0.0;
+    if (FUSE) {
+        r0 = fs.old_variables[i]; r1 = fs.old_variables[stride + i]; r2 = fs.old_variables[2 * stride + i];
+        r3 = fs.old_variables[3 * stride + i]; r4 = fs.old_variables[4 * stride + i];
+        sf_in = fs.partial_min ? fs.volumes[i] : fs.step_factors[i];
+    }
 
     const FluxC fm = flux_contribution(me);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
@@ -431,9 +445,33 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
         }
     }
 
-    if (i < nel) {
+    if (i >= nel) return;
+    if (!FUSE) {
         fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
         fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
+        return;
+    }
+    // ---- fused time_step: same operations as k_time_step on the flux just summed ----
+    double sf = sf_in;
+    if (fs.partial_min) {                       // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
+        sf = min_dt / sf_in;                    // sf_in holds volumes[i] here
+        fs.step_factors[i] = sf;
+    }
+    const double factor = sf / fs.rk_div;
+    const double rho = r0 + factor * a0, mx = r1 + factor * a1, my = r2 + factor * a2, mz = r3 + factor * a3,
+                 en = r4 + factor * a4;
+    store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
+    if (fs.residuals) {
+        fs.residuals[i] = rho - r0; fs.residuals[stride + i] = mx - r1; fs.residuals[2 * stride + i] = my - r2;
+        fs.residuals[3 * stride + i] = mz - r3; fs.residuals[4 * stride + i] = en - r4;
+    }
+    if (fs.check) {
+        const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
+        int code = 0;
+        if (!finite) code = 1;
+        else if (rho < 0.0) code = 2;
+        else if (en < 0.0) code = 3;
+        if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
     }
 }
 
@@ -699,18 +737,23 @@ void launch_step_factor_legacy(hipStream_t st, int64_t nel, int64_t stride, cons
 { hipLaunchKernelGGL(k_step_factor_legacy, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, volumes, sf, old_variables); }
 
 void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const FarField &ff, double *fluxes,
-                 int classes, int accumulate, int variant)
+                 int classes, int accumulate, int variant, const FusedStep *fused)
 {
     const dim3 grid(p.n_tiles), block(kBlock);
-#define MGCFD_TILE_LAUNCH(MINW, LOADK)                                                                         \
-    hipLaunchKernelGGL((k_flux_tile<MINW, LOADK>), grid, block, 0, st, p.nel, p.stride, q, p.slice_row0,       \
+    FusedStep fs{};
+    if (fused) fs = *fused;
+#define MGCFD_TILE_LAUNCH(MINW, LOADK, FUSE)                                                                   \
+    hipLaunchKernelGGL((k_flux_tile<MINW, LOADK, FUSE>), grid, block, 0, st, p.nel, p.stride, q, p.slice_row0, \
                        p.rows_int, p.rows_bnd, p.nbr16, p.w, p.tile_halo_ptr, p.tile_halo, p.tile_ovf_ptr,     \
-                       p.tile_ovf, ff, fluxes, classes, accumulate)
+                       p.tile_ovf, ff, fluxes, classes, accumulate, fs)
+    if (fused) {
+        if (variant == 1) MGCFD_TILE_LAUNCH(3, false, true);
+        else MGCFD_TILE_LAUNCH(3, true, true);
+        return;
+    }
     switch (variant) {
-        case 1: MGCFD_TILE_LAUNCH(3, false); break;    // recompute k = -|e|*s*0.5 from the weights
-        case 2: MGCFD_TILE_LAUNCH(2, true); break;
-        case 3: MGCFD_TILE_LAUNCH(2, false); break;
-        default: MGCFD_TILE_LAUNCH(3, true); break;    // 3 tiles of 52.5 KiB LDS fit a CU
+        case 1: MGCFD_TILE_LAUNCH(3, false, false); break;    // recompute k = -|e|*s*0.5 from the weights
+        default: MGCFD_TILE_LAUNCH(3, true, false); break;    // 3 tiles of 52.5 KiB LDS fit a CU
     }
 #undef MGCFD_TILE_LAUNCH
 }

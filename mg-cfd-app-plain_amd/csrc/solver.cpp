@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -58,6 +59,7 @@ struct DeviceLevel {
     DevicePlan dp;
     // SoA state, stride = dp.stride: q = the reference's `variables`
     double *q = nullptr, *old_variables = nullptr, *fluxes = nullptr, *residuals = nullptr;   // [5][stride]
+    double *q_alt = nullptr;             // [5][stride] second state buffer for the fused RK stages
     double *step_factors = nullptr, *volumes = nullptr, *cbrt_vol = nullptr;                  // [stride]
     double *min_dt = nullptr;            // global-min time step scalar (after the reduction)
     double *partial_min = nullptr;       // one partial minimum per step-factor workgroup
@@ -86,7 +88,11 @@ struct mgcfd_solver {
     FarField ff{};
     double ff17[17] = {0};
     unsigned long long *err = nullptr;       // device: packed (cell << 8 | code), ~0 = clean
-    int opt_exact = 1, opt_timing = 0, opt_indirect_rw = 0, opt_check = 1, opt_variant = 0;
+    int opt_exact = 1, opt_timing = 0, opt_indirect_rw = 0, opt_check = 1, opt_variant = 0, opt_fuse = 1, opt_graph = 1;
+    int timing_stride = 8;                  // OPT_TIMING == 2: bracket the flux launches of every Nth sweep
+    int64_t sweep_counter = 0;
+    struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; };
+    std::map<uint64_t, SweepGraph> sweep_graphs;   // captured smoothing sweeps, keyed by (level, options)
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> free_events;
 
@@ -194,11 +200,34 @@ struct mgcfd_solver {
         Timed t(this, l, MGCFD_LOOP_FLUX, (classes & 1) != 0);
         if (classes != 7) settle_fluxes(lv);                // a partial launch leaves other nodes' memory as it is
         const int accumulate = lv.fluxes_zero ? 0 : 1;     // 0.0 + x: same bits either way
-        if (opt_exact) exact::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant);
-        else fast::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant);
+        if (opt_exact) exact::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant, nullptr);
+        else fast::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant, nullptr);
         lv.fluxes_zero = false;
         lv.fluxes_stale = false;
         if (classes & 1) lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
+    }
+    // One whole Runge-Kutta stage in one launch: fluxes of all edge classes from `in`, then
+    // time_step into `out` (in != out).  fluxes[] stays logically zero, as after time_step.
+    void op_fused_stage(int l, int j, const double *in, double *out, bool apply_min, bool with_residual)
+    {
+        DeviceLevel &lv = level(l);
+        FusedStep fs;
+        fs.rk_div = double(MGCFD_RK + 1 - j);
+        fs.step_factors = lv.step_factors;
+        fs.old_variables = lv.old_variables;
+        fs.q_out = out;
+        fs.partial_min = apply_min ? lv.partial_min : nullptr;
+        fs.n_partial = static_cast<int>((lv.info.nel + 255) / 256);
+        fs.volumes = lv.volumes;
+        fs.residuals = with_residual ? lv.residuals : nullptr;
+        fs.old_of_new = lv.dp.old_of_new;
+        fs.err = err;
+        fs.check = opt_check;
+        Timed t(this, l, MGCFD_LOOP_FLUX, true);
+        if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, opt_variant, &fs);
+        else fast::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, opt_variant, &fs);
+        lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
+        lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
     }
     void op_indirect_rw(int l)
     {
@@ -285,10 +314,11 @@ mgcfd_solver::~mgcfd_solver()
 {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    for (auto &g : sweep_graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
     for (auto &p : pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto e : free_events) (void)hipEventDestroy(e);
     for (auto &lv : L) {
-        void *ptrs[] = {lv.dp.nbr16, lv.dp.tile_halo_ptr, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
+        void *ptrs[] = {lv.q_alt, lv.dp.nbr16, lv.dp.tile_halo_ptr, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
                         lv.cbrt_vol, lv.min_dt, lv.partial_min, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.pro,
                         lv.dp.pro_parent, lv.dp.pro_wsum};
@@ -371,6 +401,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.volumes = dev_upload(vol);
         lv.cbrt_vol = dev_upload(cb);
         lv.q = dev_alloc<double>(static_cast<size_t>(stride) * kNumStateFields);
+        lv.q_alt = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.old_variables = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.fluxes = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.residuals = dev_alloc<double>(static_cast<size_t>(stride) * 5);
@@ -425,6 +456,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         HIP_CHECK(hipMemsetAsync(lv.residuals, 0, sizeof(double) * 5 * stride, s->stream));
         HIP_CHECK(hipMemsetAsync(lv.step_factors, 0, sizeof(double) * stride, s->stream));
         exact::launch_init_variables(s->stream, stride, s->ff, lv.q);
+        exact::launch_init_variables(s->stream, stride, s->ff, lv.q_alt);     // valid numbers in the padded tail
     }
     HIP_CHECK(hipStreamSynchronize(s->stream));
     HIP_CHECK(hipGetLastError());
@@ -520,6 +552,8 @@ int mgcfd_set_option(mgcfd_solver *s, int option, int value)
             case MGCFD_OPT_INDIRECT_RW: s->opt_indirect_rw = value != 0; break;
             case MGCFD_OPT_CHECK_INVALID: s->opt_check = value != 0; break;
             case MGCFD_OPT_FLUX_VARIANT: s->opt_variant = value; break;
+            case MGCFD_OPT_FUSE_UPDATE: s->opt_fuse = value != 0; break;
+            case MGCFD_OPT_GRAPH: s->opt_graph = value != 0; break;
             default: throw std::invalid_argument("unknown option");
         }
     });
@@ -533,6 +567,8 @@ int mgcfd_get_option(const mgcfd_solver *s, int option, int *value)
         case MGCFD_OPT_INDIRECT_RW: *value = s->opt_indirect_rw; break;
         case MGCFD_OPT_CHECK_INVALID: *value = s->opt_check; break;
         case MGCFD_OPT_FLUX_VARIANT: *value = s->opt_variant; break;
+        case MGCFD_OPT_FUSE_UPDATE: *value = s->opt_fuse; break;
+        case MGCFD_OPT_GRAPH: *value = s->opt_graph; break;
         default: g_last_error = "unknown option"; return MGCFD_ERR_ARG;
     }
     return MGCFD_OK;
@@ -628,6 +664,16 @@ int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_c
 static void smooth_once(mgcfd_solver *s, int level)
 {
     const bool apply_pending = s->op_step_factor(level, true);     // :383 + :388-395
+    DeviceLevel &lv = s->level(level);
+    if (s->opt_fuse && !s->opt_indirect_rw && s->opt_timing != 1 && lv.fluxes_zero) {
+        // Fused stages: flux + time_step in one launch each.  Stage 0 reads the sweep's start
+        // state from old_variables (just copied) so it can write variables in place; the state
+        // then ping-pongs variables -> q_alt -> variables.
+        s->op_fused_stage(level, 0, lv.old_variables, lv.q, apply_pending, false);
+        s->op_fused_stage(level, 1, lv.q, lv.q_alt, false, false);
+        s->op_fused_stage(level, 2, lv.q_alt, lv.q, false, true);  // + :508
+        return;
+    }
     for (int j = 0; j < MGCFD_RK; j++) {                           // :397-506
         s->op_flux(level, 7);
         // the indirect_rw probe reads fluxes[] right after, so zero for real when it is on
@@ -636,11 +682,56 @@ static void smooth_once(mgcfd_solver *s, int level)
     }
 }
 
+// A sweep with the fused stages is four kernel launches with fixed arguments: capture it once
+// per (level, options) into a hipGraph and replay it — one host call per sweep instead of four
+// launches.  Sweeps that are being timed per kernel (OPT_TIMING) run eagerly.
+static void run_sweep(mgcfd_solver *s, int level)
+{
+    DeviceLevel &lv = s->level(level);
+    const int64_t n = s->sweep_counter++;
+    const bool timed = s->opt_timing == 1 || (s->opt_timing == 2 && (n % s->timing_stride) == 0);
+    const bool graphable = s->opt_graph && s->opt_fuse && !s->opt_indirect_rw && !timed && lv.fluxes_zero && !lv.fluxes_stale;
+    if (!graphable) {
+        const int keep = s->opt_timing;
+        if (!timed) s->opt_timing = 0;
+        smooth_once(s, level);
+        s->opt_timing = keep;
+        return;
+    }
+    const uint64_t key = (uint64_t(level) << 32) | (uint64_t(s->opt_exact) << 16) | (uint64_t(s->opt_check) << 8) | uint64_t(s->opt_variant & 0xFF);
+    auto it = s->sweep_graphs.find(key);
+    if (it == s->sweep_graphs.end()) {
+        mgcfd_solver::SweepGraph g;
+        int64_t before[MGCFD_NUM_LOOPS];
+        std::memcpy(before, lv.iters, sizeof(before));
+        const int keep = s->opt_timing;
+        s->opt_timing = 0;
+        hipGraph_t graph = nullptr;
+        HIP_CHECK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+        try {
+            smooth_once(s, level);
+        } catch (...) {
+            (void)hipStreamEndCapture(s->stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            s->opt_timing = keep;
+            throw;
+        }
+        s->opt_timing = keep;
+        HIP_CHECK(hipStreamEndCapture(s->stream, &graph));
+        HIP_CHECK(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+        HIP_CHECK(hipGraphDestroy(graph));
+        for (int k = 0; k < MGCFD_NUM_LOOPS; k++) { g.iters[k] = lv.iters[k] - before[k]; lv.iters[k] = before[k]; }
+        it = s->sweep_graphs.emplace(key, g).first;
+    }
+    HIP_CHECK(hipGraphLaunch(it->second.exec, s->stream));
+    for (int k = 0; k < MGCFD_NUM_LOOPS; k++) lv.iters[k] += it->second.iters[k];
+}
+
 int mgcfd_smooth(mgcfd_solver *s, int level, int sweeps)
 {
     OP({
         s->level(level);
-        for (int k = 0; k < sweeps; k++) smooth_once(s, level);
+        for (int k = 0; k < sweeps; k++) run_sweep(s, level);
     });
 }
 
@@ -656,7 +747,7 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
         int level = 0;
         bool going_up = true;
         for (int cyc = 0; cyc < cycles;) {
-            smooth_once(s, level);                                  // :383-508
+            run_sweep(s, level);                                    // :383-508
             if (level == 0) {                                              // :509-512
                 s->op_sumsq(0);
                 HIP_CHECK(hipMemcpyAsync(rms_dev + cyc, s->L[0].sumsq, sizeof(double), hipMemcpyDeviceToDevice, s->stream));
@@ -803,8 +894,8 @@ int mgcfd_bench_flux(mgcfd_solver *s, int level, int launches, double *avg_secon
         DeviceLevel &lv = s->level(level);
         hipEvent_t a = s->get_event(), b = s->get_event();
         auto go = [&] {
-            if (s->opt_exact) exact::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, s->opt_variant);
-            else fast::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, s->opt_variant);
+            if (s->opt_exact) exact::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, s->opt_variant, nullptr);
+            else fast::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, s->opt_variant, nullptr);
         };
         go();
         HIP_CHECK(hipEventRecord(a, s->stream));

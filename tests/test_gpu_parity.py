@@ -146,10 +146,11 @@ def test_restrict_and_prolong(setup, oracle, exact):
     solver.set_option("exact", 1)
 
 
-def _run_both(mgcfd, oracle, directory, cycles, exact, indirect_rw=False, duplicate=1):
+def _run_both(mgcfd, oracle, directory, cycles, exact, indirect_rw=False, duplicate=1, fuse=True):
     mesh = mgcfd.Mesh("input.dat", directory, duplicate)
     solver = mgcfd.Solver.from_mesh(mesh)
     solver.set_option("exact", int(exact))
+    solver.set_option("fuse_update", int(fuse))
     solver.set_option("indirect_rw", int(indirect_rw))
     rms = solver.run_cycles(cycles)
     case = oracle.OracleCase.from_input_dat(directory + "/input.dat", duplicate)
@@ -168,10 +169,11 @@ def _run_both(mgcfd, oracle, directory, cycles, exact, indirect_rw=False, duplic
     solver.close()
 
 
+@pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("exact", [True, False])
-def test_vcycles_three_levels(oracle, mesh3_dir, exact):
+def test_vcycles_three_levels(oracle, mesh3_dir, exact, fuse):
     import mgcfd
-    _run_both(mgcfd, oracle, mesh3_dir, 4, exact)
+    _run_both(mgcfd, oracle, mesh3_dir, 4, exact, fuse=fuse)
 
 
 def test_vcycles_with_indirect_rw_and_duplication(oracle, mesh_dir):
@@ -179,10 +181,11 @@ def test_vcycles_with_indirect_rw_and_duplication(oracle, mesh_dir):
     _run_both(mgcfd, oracle, mesh_dir, 3, True, indirect_rw=True, duplicate=2)
 
 
+@pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("exact", [True, False])
-def test_fvcorr_single_level(oracle, fvcorr_dir, exact):
+def test_fvcorr_single_level(oracle, fvcorr_dir, exact, fuse):
     import mgcfd
-    _run_both(mgcfd, oracle, fvcorr_dir, 50, exact)
+    _run_both(mgcfd, oracle, fvcorr_dir, 50, exact, fuse=fuse)
 
 
 def test_invalid_state_is_reported(setup, oracle):

@@ -54,14 +54,6 @@ def perturbed_state(nel, ff_var, seed=1234, amplitude=0.01):
     return base * (1.0 + amplitude * rng.uniform(-1.0, 1.0, base.shape))
 
 
-class _DevScalar:
-    """Zero-copy view of an fp64 device scalar owned by the library, for torch/RCCL."""
-
-    def __init__(self, ptr):
-        self.__cuda_array_interface__ = {"shape": (1,), "typestr": "<f8", "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-
 def cpu_baseline(levels, sample_seconds: float):
     """Time compute_flux_edge on ONE host core for a bounded number of passes."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -134,23 +126,17 @@ def main():
     nel, n_int = solver.nel(0), solver.num_internal_edges(0)
     solver.set(0, "variables", perturbed_state(nel, solver.far_field()[:5]))
 
-    min_view = None
+    sharded = None
     if world > 1:
-        min_view = torch.as_tensor(_DevScalar(solver.step_factor_min_devptr(0)), device=torch.device("cuda", local_rank))
+        from mgcfd.distributed import HipSolverAdapter, ShardedSweep
+        sharded = ShardedSweep(HipSolverAdapter(solver, torch.device("cuda", local_rank)), dist)
 
     def step():
         if world == 1:
             solver.smooth(0, 1)
-            return
-        # same sweep, with the global-min time step reduced over all ranks' mesh copies
-        solver.copy_old_variables(0)
-        solver.step_factor_local(0)
-        dist.all_reduce(min_view, op=dist.ReduceOp.MIN)
-        solver.step_factor_apply(0)
-        for j in range(3):
-            solver.compute_fluxes(0)
-            solver.time_step(0, j)
-        solver.residual(0)
+        else:
+            # same sweep, with the global-min time step reduced over all ranks' mesh copies
+            sharded.sweep(0)
 
     def barrier():
         if world > 1:

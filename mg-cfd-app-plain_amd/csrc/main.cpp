@@ -1,2 +1,384 @@
-// placeholder until the driver lands (next commit)
-int main() { return 0; }
+// euler3d_gpu_double — drop-in replacement for the reference's euler3d_cpu_double binary
+// (src/euler3d_cpu_double.cpp) on one MI355X, written purely against the C ABI of
+// include/mgcfd.h.  Same command line (src/Base/config.cpp:32-47), same input.dat / mesh /
+// .coords / MG-map inputs, same stdout progress lines, same `variables` dump, and the same
+// Times.csv / LoopNumIters.csv schema (src/Monitoring/timer.cpp:106-195,
+// src/Monitoring/loop_stats.cpp:83-171, identification columns src/Base/io_enhanced.cpp:858-1016).
+#include <getopt.h>
+#include <sched.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "mgcfd.h"
+
+namespace {
+
+struct Config {                       // the reference's `config` (src/Base/config.h:27-47)
+    std::string config_filepath, input_file, input_file_directory, papi_config_file, output_file_prefix;
+    int mesh_duplicate_count = 1;
+    int num_cycles = 25;              // src/Base/config.cpp:63
+    bool validate_result = false;
+    bool output_variables = false, output_old_variables = false, output_step_factors = false,
+         output_edge_fluxes = false, output_fluxes = false, output_volumes = false;
+    // extensions (not in the reference)
+    bool timers = true;               // --no-timers: fused, graph-replayed fast path; Times.csv holds only Total
+    bool fast_math = false;           // --fast: allow FMA contraction (MGCFD_OPT_EXACT = 0)
+    bool indirect_rw = true;          // the reference runs the probe every RK stage; --no-indirect-rw skips it
+    int device = 0;
+};
+
+std::string trim(const std::string &s)
+{
+    size_t b = s.find_first_not_of(" \t\r\n");
+    if (b == std::string::npos) return "";
+    return s.substr(b, s.find_last_not_of(" \t\r\n") - b + 1);
+}
+
+void set_param(Config &c, const std::string &key, const std::string &value)
+{
+    // src/Base/config.cpp:81-157
+    if (key == "config_filepath") c.config_filepath = value;
+    else if (key == "input_file") c.input_file = value;
+    else if (key == "input_file_directory") c.input_file_directory = value;
+    else if (key == "papi_config_file") c.papi_config_file = value;
+    else if (key == "output_file_prefix") c.output_file_prefix = value;
+    else if (key == "mesh_duplicate_count") c.mesh_duplicate_count = std::atoi(value.c_str());
+    else if (key == "cycles") c.num_cycles = std::atoi(value.c_str());
+    else if (key == "omp_num_threads") { /* no OpenMP here */ }
+    else if (key == "output_variables") { if (value == "Y") c.output_variables = true; }
+    else if (key == "output_old_variables") { if (value == "Y") c.output_old_variables = true; }
+    else if (key == "output_step_factors") { if (value == "Y") c.output_step_factors = true; }
+    else if (key == "output_edge_fluxes") { if (value == "Y") c.output_edge_fluxes = true; }
+    else if (key == "output_fluxes") { if (value == "Y") c.output_fluxes = true; }
+    else if (key == "output_volumes") { if (value == "Y") c.output_volumes = true; }
+    else std::printf("WARNING: Unknown key '%s' encountered during parsing of config file.\n", key.c_str());
+}
+
+void read_config(Config &c)
+{
+    // src/Base/config.cpp:159-217
+    if (access(c.config_filepath.c_str(), F_OK) == -1) {
+        std::fprintf(stderr, "ERROR: \"%s\" does not exist.\n", c.config_filepath.c_str());
+        return;
+    }
+    std::ifstream file(c.config_filepath);
+    std::string line;
+    while (std::getline(file, line)) {
+        if (!line.empty() && line[0] == '#') continue;
+        size_t eq = line.find('=');
+        if (eq == std::string::npos || eq + 1 >= line.size()) continue;
+        set_param(c, trim(line.substr(0, eq)), trim(line.substr(eq + 1)));
+    }
+    std::string dir;
+    size_t slash = c.config_filepath.rfind('/');
+    if (slash != std::string::npos) dir = c.config_filepath.substr(0, slash);
+    if ((c.input_file_directory.empty() || c.input_file_directory[0] != '/') && !dir.empty()) {
+        if (c.input_file_directory == "./") c.input_file_directory = dir;
+        else c.input_file_directory = dir + "/" + c.input_file_directory;
+    }
+}
+
+void print_help()
+{
+    std::fprintf(stderr,
+        "MG-CFD (MI355X) instructions\n\n"
+        "Usage: euler3d_gpu_double [OPTIONS] \n\n"
+        "  -h, --help                       Print help\n\n"
+        "CRITICAL ARGUMENTS\n  One of these must be set:\n"
+        "  -i, --input-file=FILEPATH        Multigrid input grid (.dat file)\n"
+        "  -c, --config-filepath=FILEPATH   Config file\n\n"
+        "OPTIONAL ARGUMENTS\n"
+        "  -d, --input-directory=DIRPATH    Directory path to input files\n"
+        "  -o, --output-file-prefix=STRING  String to prepend to output filenames\n"
+        "  -p, --papi-config-file=FILEPATH  Accepted and ignored (CPU performance counters)\n\n"
+        "  -g, --num-cycles=INT             Number of multigrid V-cycles\n"
+        "  -m, --mesh-duplicate-count=INT   Number of times to duplicate mesh\n"
+        "  -v, --validate-result            Check final state against pre-calculated solution\n\n"
+        "DEBUGGING ARGUMENTS\n"
+        "  --output-variables               Write Euler equation variable values to file\n"
+        "  --output-fluxes                  Write flux accumulations to file\n"
+        "  --output-step-factors            Write step factors to file\n\n"
+        "GPU ARGUMENTS (extensions)\n"
+        "  --device=INT                     GPU to run on (default 0)\n"
+        "  --no-timers                      Fused, graph-replayed kernels; no per-loop times\n"
+        "  --no-indirect-rw                 Skip the indirect_rw bandwidth probe each RK stage\n"
+        "  --fast                           Allow FMA contraction (results within 1e-12 relative)\n");
+}
+
+bool parse_arguments(int argc, char **argv, Config &c)
+{
+    // src/Base/config.cpp:32-47,219-259.  (The reference stores the three --output-* flags
+    // through bool-to-int* casts, so each one also clobbers the bools after it; here every
+    // flag sets exactly its own field.)
+    static const option long_opts[] = {
+        {"help", no_argument, nullptr, 'h'},
+        {"config-filepath", required_argument, nullptr, 'c'},
+        {"input-file", required_argument, nullptr, 'i'},
+        {"input-directory", required_argument, nullptr, 'd'},
+        {"papi_config_file", required_argument, nullptr, 'p'},
+        {"output-file-prefix", required_argument, nullptr, 'o'},
+        {"mesh-duplicate-count", required_argument, nullptr, 'm'},
+        {"num-cycles", required_argument, nullptr, 'g'},
+        {"validate-result", no_argument, nullptr, 'v'},
+        {"output-variables", no_argument, nullptr, 1001},
+        {"output-fluxes", no_argument, nullptr, 1002},
+        {"output-step-factors", no_argument, nullptr, 1003},
+        {"device", required_argument, nullptr, 1004},
+        {"no-timers", no_argument, nullptr, 1005},
+        {"no-indirect-rw", no_argument, nullptr, 1006},
+        {"fast", no_argument, nullptr, 1007},
+        {nullptr, 0, nullptr, 0}};
+    int optc;
+    while ((optc = getopt_long(argc, argv, "hc:i:d:p:o:m:g:v", long_opts, nullptr)) != -1) {
+        switch (optc) {
+            case 'h': print_help(); return false;
+            case 'i': c.input_file = optarg; break;
+            case 'c': c.config_filepath = optarg; read_config(c); break;
+            case 'd': c.input_file_directory = optarg; break;
+            case 'p': c.papi_config_file = optarg; break;
+            case 'o': c.output_file_prefix = optarg; break;
+            case 'm': c.mesh_duplicate_count = std::atoi(optarg); break;
+            case 'g': c.num_cycles = std::atoi(optarg); break;
+            case 'v': c.validate_result = true; break;
+            case 1001: c.output_variables = true; break;
+            case 1002: c.output_fluxes = true; break;
+            case 1003: c.output_step_factors = true; break;
+            case 1004: c.device = std::atoi(optarg); break;
+            case 1005: c.timers = false; break;
+            case 1006: c.indirect_rw = false; break;
+            case 1007: c.fast_math = true; break;
+            default: std::printf("Unknown command line parameter '%c'\n", optc);
+        }
+    }
+    return true;
+}
+
+// src/Base/io_enhanced.cpp:26-74
+std::string filename_suffix(const Config &c, int level)
+{
+    std::string s = "size=" + std::to_string(c.mesh_duplicate_count) + "x.cycles=" + std::to_string(c.num_cycles);
+    if (level >= 0) s += ".level=" + std::to_string(level);
+    return s;
+}
+std::string output_filepath(const Config &c, const std::string &name, int level)
+{
+    std::string p = c.output_file_prefix;
+    if (!p.empty() && p.back() != '/') p += ".";
+    return p + name + "." + filename_suffix(c, level);
+}
+std::string solution_filepath(const Config &c, const std::string &name, int level)
+{
+    std::string p = c.input_file_directory;
+    if (!p.empty() && p.back() != '/') p += "/";
+    return p + "solution." + name + "." + filename_suffix(c, level);
+}
+std::string csv_filepath(const Config &c, const char *name)
+{
+    std::string p = c.output_file_prefix;
+    if (!p.empty() && p.back() != '/') p += ".";
+    return p + name;
+}
+
+const char *mesh_name(int v)
+{
+    switch (v) {
+        case MGCFD_MESH_LA_CASCADE: return "la_cascade";
+        case MGCFD_MESH_ROTOR_37: return "rotor37";
+        case MGCFD_MESH_FVCORR: return "fvcorr";
+        case MGCFD_MESH_M6_WING: return "m6wing";
+        default: return "unknown";
+    }
+}
+
+#define STR2(x) #x
+#define STR(x) STR2(x)
+
+// The 16 identification columns of src/Base/io_enhanced.cpp:858-1016, re-read for a GPU build:
+// CC = hipcc's clang, Instruction set = gfx950, Num threads = number of GPUs, CPU = device name.
+void csv_identification(const Config &c, int size, int mesh_variant, const std::string &device_name,
+                        std::string &header, std::string &line)
+{
+    std::ostringstream h, d;
+    h << "Size,";                  d << size << ",";
+    h << "Mesh,";                  d << mesh_name(mesh_variant) << ",";
+    h << "MG cycles,";             d << c.num_cycles << ",";
+    h << "Flux variant,";          d << "Normal,";
+    h << "Flux options,";          d << ",";
+    h << "CC,";                    d << "hipcc,";
+    h << "CC version,";            d << STR(__clang_major__) "." STR(__clang_minor__) "." STR(__clang_patchlevel__) ",";
+    h << "Opt level,";             d << "3,";
+    h << "Instruction set,";       d << "gfx950,";
+    h << "SIMD,";                  d << "N,";
+    h << "SIMD len,";              d << "1,";
+    h << "OpenMP,";                d << "Off,";
+    h << "Num threads,";           d << "1,";
+    h << "Permit scatter OpenMP,"; d << "N,";
+    h << "Flux fission,";          d << "N,";
+    h << "CPU,";                   d << device_name << ",";
+    header = h.str();
+    line = d.str();
+}
+
+void write_csv(const std::string &path, const std::string &ident_header, const std::string &ident_line, int levels,
+               const std::vector<std::vector<std::string>> &cells, bool with_total, double total)
+{
+    std::remove(path.c_str());
+    std::ofstream out(path);
+    static const char *cols[MGCFD_NUM_LOOPS] = {"flux", "update", "compute_step", "time_step", "restrict", "prolong", "indirect_rw"};
+    out << ident_header << "ThreadNum,CpuId,";
+    for (int l = 0; l < levels; l++)
+        for (int k = 0; k < MGCFD_NUM_LOOPS; k++) out << cols[k] << l << ",";
+    if (with_total) out << "Total,";
+    out << std::endl;
+    out << ident_line << 0 << "," << sched_getcpu() << ",";
+    for (int l = 0; l < levels; l++)
+        for (int k = 0; k < MGCFD_NUM_LOOPS; k++) out << cells[l][k] << ",";
+    if (with_total) out << total << ",";
+    out << std::endl;
+}
+
+int fail(const char *what)
+{
+    std::fprintf(stderr, "ERROR: %s: %s\n", what, mgcfd_last_error());
+    return EXIT_FAILURE;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    Config conf;
+    if (!parse_arguments(argc, argv, conf)) return 1;
+    if (conf.input_file.empty()) {
+        std::printf("ERROR: input_file not set\n");
+        return 1;
+    }
+
+    mgcfd_mesh *mesh = nullptr;
+    if (mgcfd_mesh_load(conf.input_file.c_str(), conf.input_file_directory.c_str(), conf.mesh_duplicate_count, &mesh) != MGCFD_OK)
+        return fail("reading input");
+    const int levels = mgcfd_mesh_num_levels(mesh);
+    const int mesh_variant = mgcfd_mesh_variant(mesh);
+    const int problem_size = mgcfd_mesh_size(mesh);
+
+    mgcfd_solver *solver = nullptr;
+    if (mgcfd_create_from_mesh(mesh, conf.device, &solver) != MGCFD_OK) return fail("creating the GPU solver");
+    mgcfd_set_option(solver, MGCFD_OPT_EXACT, conf.fast_math ? 0 : 1);
+    mgcfd_set_option(solver, MGCFD_OPT_TIMING, conf.timers ? 1 : 0);
+    mgcfd_set_option(solver, MGCFD_OPT_INDIRECT_RW, (conf.indirect_rw && conf.timers) ? 1 : 0);
+
+    std::string device_name = "unknown GPU";
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, conf.device) == hipSuccess) device_name = prop.name;
+    }
+
+    // ---- compute (src/euler3d_cpu_double.cpp:368-698) ----
+    std::vector<double> rms(static_cast<size_t>(conf.num_cycles > 0 ? conf.num_cycles : 0));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = mgcfd_run_cycles(solver, conf.num_cycles, rms.data());
+    const double total_compute_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int i = 0; i < conf.num_cycles; i++) {
+        std::printf(levels <= 1 ? "\nCycle %d / %d" : "\nMG cycle %d / %d", i + 1, conf.num_cycles);
+        std::printf(" (RMS = %.3e)", rms[static_cast<size_t>(i)]);
+    }
+    std::printf("\n");
+    if (rc == MGCFD_ERR_NAN || rc == MGCFD_ERR_NEG_DENSITY || rc == MGCFD_ERR_NEG_ENERGY) {
+        // check_for_invalid_variables' messages (src/Kernels/validation.cpp:112-134)
+        std::printf(rc == MGCFD_ERR_NAN ? "\nERROR: NaN detected!" :
+                    rc == MGCFD_ERR_NEG_DENSITY ? "\nERROR: Negative density detected!" : "\nERROR: Negative density.energy detected!");
+        std::printf("\n");
+        return EXIT_FAILURE;
+    }
+    if (rc != MGCFD_OK) return fail("running the cycles");
+    std::printf("Total runtime = %g\n", total_compute_time);
+
+    const int64_t nel0 = mgcfd_level_nel(solver, 0);
+    std::vector<double> variables(static_cast<size_t>(nel0) * MGCFD_NVAR);
+
+    // ---- validate (src/euler3d_cpu_double.cpp:704-744) ----
+    std::printf("\n");
+    if (conf.validate_result) {
+        std::printf("Beginning validation of variables[]\n");
+        for (int l = 0; l < levels; l++) {
+            int64_t bad = -1;
+            if (mgcfd_check_for_invalid_variables(solver, l, &bad) != MGCFD_OK) {
+                std::printf("\nERROR: NaN detected!\nCell %ld\n", (long)bad);
+                return EXIT_FAILURE;
+            }
+        }
+        std::printf("  NaN check passed\n");
+        bool passed = true;
+        const std::string sol = solution_filepath(conf, "variables", 0);
+        std::ifstream file(sol);
+        if (!file.is_open()) {
+            std::printf("  could not open variables solution file:\n    %s\n  aborting validation\n", sol.c_str());
+            passed = false;
+        } else {
+            std::vector<double> master(variables.size());
+            for (auto &v : master) file >> v;
+            if (mgcfd_get_array(solver, 0, MGCFD_ARR_VARIABLES, variables.data()) != MGCFD_OK) return fail("reading back variables");
+            std::printf("  scanning variables[] on level 0 for errors\n");
+            int64_t first_bad = -1;
+            if (mgcfd_identify_differences(variables.data(), master.data(), nel0, mesh_variant, &first_bad) != MGCFD_OK) {
+                std::printf("ERROR: Unacceptable error detected at (i=%ld, v=%d)\n", (long)(first_bad / MGCFD_NVAR), int(first_bad % MGCFD_NVAR));
+                std::printf("       - incorrect value = %.23f\n", variables[static_cast<size_t>(first_bad)]);
+                std::printf("       - correct value =   %.23f\n", master[static_cast<size_t>(first_bad)]);
+                return EXIT_FAILURE;
+            }
+        }
+        if (passed) std::printf("PASS: variables[] validated successfully\n");
+        std::printf("\n");
+    }
+
+    // ---- dumps, level 0 only (src/euler3d_cpu_double.cpp:752-772) ----
+    auto dump = [&](int which, const char *name, int ncols) -> int {
+        std::vector<double> a(static_cast<size_t>(nel0) * ncols);
+        if (mgcfd_get_array(solver, 0, which, a.data()) != MGCFD_OK) return fail("reading back an array");
+        const std::string path = output_filepath(conf, name, 0);
+        if (which == MGCFD_ARR_VARIABLES) std::printf("Dumping variables[] to file: %s\n", path.c_str());
+        if (mgcfd_write_array(path.c_str(), a.data(), nel0, ncols) != MGCFD_OK) { fail("writing a dump"); std::exit(EXIT_FAILURE); }
+        return 0;
+    };
+    if (conf.output_variables && dump(MGCFD_ARR_VARIABLES, "variables", MGCFD_NVAR)) return EXIT_FAILURE;
+    if (conf.output_step_factors && dump(MGCFD_ARR_STEP_FACTORS, "step_factors", 1)) return EXIT_FAILURE;
+    if (conf.output_fluxes && dump(MGCFD_ARR_FLUXES, "fluxes", MGCFD_NVAR)) return EXIT_FAILURE;
+    if (conf.output_volumes && dump(MGCFD_ARR_VOLUMES, "volumes", 1)) return EXIT_FAILURE;
+
+    // ---- performance data (src/euler3d_cpu_double.cpp:778-785) ----
+    std::string ih, il;
+    csv_identification(conf, problem_size, mesh_variant, device_name, ih, il);
+    std::vector<std::vector<std::string>> times(static_cast<size_t>(levels)), iters(static_cast<size_t>(levels));
+    for (int l = 0; l < levels; l++) {
+        double t[MGCFD_NUM_LOOPS];
+        int64_t n[MGCFD_NUM_LOOPS];
+        mgcfd_get_loop_times(solver, l, t);
+        mgcfd_get_loop_iters(solver, l, n);
+        for (int k = 0; k < MGCFD_NUM_LOOPS; k++) {
+            std::ostringstream a, b;
+            a << t[k];
+            b << n[k];
+            times[static_cast<size_t>(l)].push_back(a.str());
+            iters[static_cast<size_t>(l)].push_back(b.str());
+        }
+    }
+    const std::string tpath = csv_filepath(conf, "Times.csv"), ipath = csv_filepath(conf, "LoopNumIters.csv");
+    write_csv(tpath, ih, il, levels, times, true, total_compute_time);
+    std::printf("Loop runtimes written to: %s\n", tpath.c_str());
+    write_csv(ipath, ih, il, levels, iters, false, 0.0);
+    std::printf("Loop stats written to: %s\n", ipath.c_str());
+
+    mgcfd_destroy(solver);
+    mgcfd_mesh_free(mesh);
+    return 0;
+}

@@ -208,7 +208,8 @@ struct mgcfd_solver {
     }
     // One whole Runge-Kutta stage in one launch: fluxes of all edge classes from `in`, then
     // time_step into `out` (in != out).  fluxes[] stays logically zero, as after time_step.
-    void op_fused_stage(int l, int j, const double *in, double *out, bool apply_min, bool with_residual)
+    // apply_min: 0 no, 1 from the workgroups' partial minima, 2 from the (all-reduced) scalar
+    void op_fused_stage(int l, int j, const double *in, double *out, int apply_min, bool with_residual)
     {
         DeviceLevel &lv = level(l);
         FusedStep fs;
@@ -216,8 +217,8 @@ struct mgcfd_solver {
         fs.step_factors = lv.step_factors;
         fs.old_variables = lv.old_variables;
         fs.q_out = out;
-        fs.partial_min = apply_min ? lv.partial_min : nullptr;
-        fs.n_partial = static_cast<int>((lv.info.nel + 255) / 256);
+        fs.partial_min = apply_min == 1 ? lv.partial_min : (apply_min == 2 ? lv.min_dt : nullptr);
+        fs.n_partial = apply_min == 2 ? 1 : static_cast<int>((lv.info.nel + 255) / 256);
         fs.volumes = lv.volumes;
         fs.residuals = with_residual ? lv.residuals : nullptr;
         fs.old_of_new = lv.dp.old_of_new;
@@ -669,9 +670,9 @@ static void smooth_once(mgcfd_solver *s, int level)
         // Fused stages: flux + time_step in one launch each.  Stage 0 reads the sweep's start
         // state from old_variables (just copied) so it can write variables in place; the state
         // then ping-pongs variables -> q_alt -> variables.
-        s->op_fused_stage(level, 0, lv.old_variables, lv.q, apply_pending, false);
-        s->op_fused_stage(level, 1, lv.q, lv.q_alt, false, false);
-        s->op_fused_stage(level, 2, lv.q_alt, lv.q, false, true);  // + :508
+        s->op_fused_stage(level, 0, lv.old_variables, lv.q, apply_pending ? 1 : 0, false);
+        s->op_fused_stage(level, 1, lv.q, lv.q_alt, 0, false);
+        s->op_fused_stage(level, 2, lv.q_alt, lv.q, 0, true);      // + :508
         return;
     }
     for (int j = 0; j < MGCFD_RK; j++) {                           // :397-506
@@ -725,6 +726,28 @@ static void run_sweep(mgcfd_solver *s, int level)
     }
     HIP_CHECK(hipGraphLaunch(it->second.exec, s->stream));
     for (int k = 0; k < MGCFD_NUM_LOOPS; k++) lv.iters[k] += it->second.iters[k];
+}
+
+// The same sweep split around the one collective a multi-GPU run needs (see mgcfd.h).
+int mgcfd_sweep_begin(mgcfd_solver *s, int level)
+{
+    OP({
+        DeviceLevel &lv = s->level(level);
+        if (!lv.fluxes_zero) throw std::invalid_argument("sweep_begin needs zero fluxes (as after time_step)");
+        const bool pending = s->op_step_factor(level, true);       // copy + first half, partial minima
+        if (pending) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
+    });
+}
+int mgcfd_sweep_end(mgcfd_solver *s, int level)
+{
+    OP({
+        DeviceLevel &lv = s->level(level);
+        s->settle_fluxes(lv);
+        const int apply = s->mesh_variant == MGCFD_MESH_FVCORR ? 0 : 2;
+        s->op_fused_stage(level, 0, lv.old_variables, lv.q, apply, false);
+        s->op_fused_stage(level, 1, lv.q, lv.q_alt, 0, false);
+        s->op_fused_stage(level, 2, lv.q_alt, lv.q, 0, true);
+    });
 }
 
 int mgcfd_smooth(mgcfd_solver *s, int level, int sweeps)

@@ -1,0 +1,98 @@
+"""Multi-GPU host logic: one process per GPU, one mesh copy (or mesh part) per rank.
+
+The reference has no distributed path; the sharding below is the one its own `-m` mesh
+duplication defines (src/Base/io_enhanced.cpp:89-201): the copies are independent except for
+the GLOBAL minimum time step (src/Kernels/cfd_loops.cpp:137-150) and the RMS that is summed over
+all nodes (src/Kernels/validation.cpp:91-105).  So a sweep needs exactly one all-reduce(MIN) of
+one fp64 and, when the RMS is wanted, one all-reduce(SUM) of one fp64 — issued through
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests) on
+tensors that alias the solver's device scalars, between the two halves of compute_step_factor.
+No other data moves between ranks.
+
+The solver object only has to provide the kernel-granular calls of include/mgcfd.h plus two
+scalar views; the product passes a :class:`mgcfd.api.Solver`, the CPU tests a stand-in.
+"""
+from __future__ import annotations
+
+import math
+
+RK = 3
+
+
+class DevScalarView:
+    """Zero-copy torch view of an fp64 device scalar owned by libmgcfd_hip.so."""
+
+    def __init__(self, ptr: int):
+        self.__cuda_array_interface__ = {"shape": (1,), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+    def tensor(self, device):
+        import torch
+        return torch.as_tensor(self, device=device)
+
+
+class HipSolverAdapter:
+    """Adds the two scalar views to a :class:`mgcfd.api.Solver` (device tensors aliasing library memory)."""
+
+    def __init__(self, solver, device):
+        self.s = solver
+        self.device = device
+        self._min = {}
+
+    def __getattr__(self, name):
+        return getattr(self.s, name)
+
+    def min_tensor(self, level):
+        if level not in self._min:
+            self._min[level] = DevScalarView(self.s.step_factor_min_devptr(level)).tensor(self.device)
+        return self._min[level]
+
+    def sumsq_tensor(self, level):
+        # launches the reduction; the returned tensor aliases its device result
+        return DevScalarView(self.s.residual_sumsq_devptr(level)).tensor(self.device)
+
+
+class ShardedSweep:
+    """Smoothing sweeps on per-rank mesh copies coupled through the global-min time step."""
+
+    def __init__(self, solver, dist=None, global_time_step: bool = True, fused: bool = True):
+        self.solver = solver
+        self.fused = fused and hasattr(solver, "sweep_begin")   # one launch per RK stage (mgcfd_sweep_begin/_end)
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.global_time_step = global_time_step      # False for mesh_name = fvcorr (local time step)
+
+    @property
+    def world(self) -> int:
+        return self.dist.get_world_size() if self.dist else 1
+
+    def sweep(self, level: int = 0):
+        """copy, compute_step_factor (global min over ALL ranks), RK x (fluxes, time_step), residual:
+        the per-level body of the reference's cycle loop, src/euler3d_cpu_double.cpp:383-508."""
+        s = self.solver
+        if self.fused:
+            # fused kernels: everything before the collective, the collective, everything after
+            s.sweep_begin(level)
+            if self.global_time_step and self.dist:
+                self.dist.all_reduce(s.min_tensor(level), op=self.dist.ReduceOp.MIN)
+            s.sweep_end(level)
+            return
+        s.copy_old_variables(level)
+        if self.global_time_step:
+            s.step_factor_local(level)
+            if self.dist:
+                self.dist.all_reduce(s.min_tensor(level), op=self.dist.ReduceOp.MIN)
+            s.step_factor_apply(level)
+        else:
+            s.compute_step_factor(level)
+        for j in range(RK):
+            s.compute_fluxes(level)
+            s.time_step(level, j)
+        s.residual(level)
+
+    def rms(self, level: int, nel_local: int) -> float:
+        """calc_rms over every rank's nodes: sqrt(sum of squares / total nel)."""
+        t = self.solver.sumsq_tensor(level)
+        if self.dist:
+            t = t.clone()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return math.sqrt(float(t.item()) / (nel_local * self.world))

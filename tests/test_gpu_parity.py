@@ -200,3 +200,210 @@ def test_invalid_state_is_reported(setup, oracle):
     assert (rc, bad) == (5, 17)
     solver.set(0, "variables", perturbed_state(case.levels[0].nel, ff.var, seed=1))
     assert solver.check_for_invalid_variables(0)[0] == 0
+
+
+# ------------------------------------------------------------------------------------------
+# Golden fixtures (outputs of the REAL reference, tests/golden/) through the product
+# ------------------------------------------------------------------------------------------
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+GOLDEN_CASES = ["m6_2lvl", "m6_3lvl", "m6_2lvl_dup2", "fvcorr_1lvl"]
+
+
+def _case(name):
+    d = os.path.join(GOLDEN, name)
+    meta = dict(l.strip().split(" = ") for l in open(os.path.join(d, "case.txt")))
+    return d, int(meta["cycles"]), int(meta["duplicate"])
+
+
+def _csv_row(path):
+    rows = [l.rstrip(",\n").split(",") for l in open(path) if l.strip()]
+    return dict(zip(rows[0], rows[1]))
+
+
+@pytest.mark.parametrize("mode", ["timers", "no-timers"])
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_driver_reproduces_reference_binary(case, mode, tmp_path):
+    """euler3d_gpu_double with the reference's command line: the variables dump must be
+    byte-identical to the reference's, LoopNumIters.csv must carry the same counts."""
+    d, cycles, dup = _case(case)
+    exe = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
+    cmd = [exe, "-i", "input.dat", "-d", os.path.join(d, "input"), "-o", str(tmp_path) + "/", "-g", str(cycles),
+           "-m", str(dup), "--output-variables"]
+    if mode == "no-timers":
+        cmd.append("--no-timers")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    dump = tmp_path / f"variables.size={dup}x.cycles={cycles}.level=0"
+    assert dump.read_bytes() == open(os.path.join(d, "variables.level0.txt"), "rb").read()
+    want_lines = [l.strip() for l in open(os.path.join(d, "stdout.txt")) if "RMS" in l]
+    got_lines = [l.strip() for l in r.stdout.splitlines() if "RMS" in l]
+    assert got_lines == want_lines
+    assert "Total runtime = " in r.stdout and "Loop stats written to:" in r.stdout
+    want, got = _csv_row(os.path.join(d, "LoopNumIters.csv")), _csv_row(tmp_path / "LoopNumIters.csv")
+    assert list(got.keys()) == list(want.keys())                      # same schema, same column order
+    for k in want:
+        if k[:-1] in ("flux", "update", "compute_step", "time_step", "restrict", "prolong") or k in ("Size", "Mesh", "MG cycles"):
+            assert got[k] == want[k], k
+        if k.startswith("indirect_rw"):
+            assert got[k] == (want[k] if mode == "timers" else "0")    # the probe is skipped on the fast path
+    t = _csv_row(tmp_path / "Times.csv")
+    assert list(t.keys())[:18] == list(want.keys())[:18] and "Total" in t
+    if mode == "timers":
+        assert float(t["flux0"]) > 0 and float(t["time_step0"]) > 0 and float(t["compute_step0"]) > 0
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_kernels_reproduce_reference_vectors(case):
+    import mgcfd
+    d, cycles, dup = _case(case)
+    g = np.load(os.path.join(d, "kernels.npz"))
+    mesh = mgcfd.Mesh("input.dat", os.path.join(d, "input"))
+    s = mgcfd.Solver.from_mesh(mesh)
+    assert np.array_equal(s.far_field(), g["far_field"])
+    for l in range(s.num_levels):
+        assert np.array_equal(s.get_edges(l, len(g[f"L{l}_edges"])), g[f"L{l}_edges"])
+        s.set(l, "variables", g[f"L{l}_q"])
+        s.set(l, "fluxes", g[f"L{l}_flux_in"])
+        s.compute_flux_edge(l)
+        _assert_close(s.get(l, "fluxes"), g[f"L{l}_flux_internal"], True, "internal flux")
+        s.compute_boundary_flux_edge(l)
+        _assert_close(s.get(l, "fluxes"), g[f"L{l}_flux_boundary"], True, "boundary flux")
+        s.compute_wall_flux_edge(l)
+        _assert_close(s.get(l, "fluxes"), g[f"L{l}_flux_wall"], True, "wall flux")
+        s.zero_fluxes(l)
+        s.indirect_rw(l)
+        _assert_close(s.get(l, "fluxes"), g[f"L{l}_indirect_rw"], True, "indirect_rw")
+        s.compute_step_factor(l)
+        _assert_close(s.get(l, "step_factors"), g[f"L{l}_step_factors"], True, "step factors")
+        for j in range(3):
+            s.set(l, "fluxes", g[f"L{l}_ts_flux"])
+            s.set(l, "old_variables", g[f"L{l}_ts_old"])
+            s.time_step(l, j)
+            _assert_close(s.get(l, "variables"), g[f"L{l}_ts_j{j}"], True, f"time_step {j}")
+        s.set(l, "variables", g[f"L{l}_q"])
+        s.residual(l)
+        _assert_close(s.get(l, "residuals"), g[f"L{l}_residual"], True, "residual")
+        assert abs(s.calc_rms(l) - g[f"L{l}_rms"][0]) <= 1e-13 * g[f"L{l}_rms"][0]
+    for l in range(s.num_levels - 1):
+        s.set(l, "variables", g[f"T{l}_qf"])
+        s.set(l + 1, "variables", g[f"T{l}_qc"])
+        s.restrict(l)
+        _assert_close(s.get(l + 1, "variables"), g[f"T{l}_restrict"], True, "restrict")
+        s.set(l, "variables", g[f"T{l}_qf"])
+        s.set(l, "residuals", g[f"T{l}_rf"])
+        s.set(l + 1, "residuals", g[f"T{l}_rc"])
+        s.prolong(l)
+        _assert_close(s.get(l, "variables"), g[f"T{l}_prolong"], True, "prolong")
+    s.close()
+
+
+def test_sharded_sweep_hooks_equal_smooth(mesh3_dir):
+    """The multi-GPU sweep (split around the all-reduce) run on one rank must equal mgcfd_smooth."""
+    import torch
+    import mgcfd
+    from mgcfd.distributed import HipSolverAdapter, ShardedSweep
+    mesh = mgcfd.Mesh("input.dat", mesh3_dir)
+    results = []
+    for mode in ("smooth", "sharded-fused", "sharded-unfused"):
+        s = mgcfd.Solver.from_mesh(mesh)
+        q = perturbed_state(s.nel(0), s.far_field()[:5], seed=77)
+        s.set(0, "variables", q)
+        if mode == "smooth":
+            s.smooth(0, 3)
+            rms = s.calc_rms(0)
+        else:
+            s.set_stream(torch.cuda.current_stream().cuda_stream)
+            sw = ShardedSweep(HipSolverAdapter(s, torch.device("cuda", 0)), None, fused=(mode == "sharded-fused"))
+            for _ in range(3):
+                sw.sweep(0)
+            rms = sw.rms(0, s.nel(0))
+        results.append((s.get(0, "variables"), s.get(0, "residuals"), s.get(0, "step_factors"), rms))
+        s.close()
+    for other in results[1:]:
+        for a, b in zip(results[0][:3], other[:3]):
+            assert np.array_equal(a.view(np.int64), b.view(np.int64))
+        assert abs(other[3] - results[0][3]) <= 1e-13 * results[0][3]
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE-size level (67^3 = 300,763 nodes / 888,822 edges): size-independent properties
+# ------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big():
+    import bench
+    import mgcfd
+    mg, levels = bench.build_workload(67)
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    q = bench.perturbed_state(s.nel(0), s.far_field()[:5])
+    yield mgcfd, s, q, levels
+    s.close()
+
+
+def test_full_size_internal_flux_is_conservative(big):
+    """Every internal edge adds F to one end and -F to the other (flux_kernel.elemfunc.c:142-189),
+    so the internal fluxes of all nodes sum to zero up to rounding."""
+    mgcfd, s, q, levels = big
+    s.set(0, "variables", q)
+    s.zero_fluxes(0)
+    s.compute_flux_edge(0)
+    f = s.get(0, "fluxes")
+    assert np.isfinite(f).all()
+    assert np.all(np.abs(f.sum(axis=0)) <= 1e-12 * np.abs(f).sum(axis=0))
+    assert s.loop_iters(0)["flux"] % levels[0]["n_internal"] == 0
+
+
+def test_full_size_deterministic_and_modes_agree(big):
+    mgcfd, s, q, levels = big
+    runs = {}
+    for name, opts in {"fused": dict(fuse_update=1, graph=1), "fused-again": dict(fuse_update=1, graph=1),
+                       "eager": dict(fuse_update=1, graph=0), "unfused": dict(fuse_update=0, graph=0),
+                       "fast": dict(fuse_update=1, graph=1, exact=0)}.items():
+        s.set_option("exact", opts.get("exact", 1))
+        s.set_option("fuse_update", opts["fuse_update"])
+        s.set_option("graph", opts["graph"])
+        s.set(0, "variables", q)
+        s.zero_fluxes(0)
+        s.smooth(0, 4)
+        runs[name] = (s.get(0, "variables"), s.get(0, "residuals"))
+        assert s.check_for_invalid_variables(0)[0] == 0
+    s.set_option("exact", 1)
+    for other in ("fused-again", "eager", "unfused"):          # no atomics, fixed order: bit-reproducible
+        for a, b in zip(runs["fused"], runs[other]):
+            assert np.array_equal(a.view(np.int64), b.view(np.int64)), other
+    for a, b in zip(runs["fused"], runs["fast"]):                # FMA contraction only
+        assert np.abs(a - b).max() <= REL_FAST * np.abs(a).max()
+    assert not np.array_equal(runs["fused"][0], q)               # the sweeps did change the state
+
+
+def test_full_size_matches_oracle_on_one_sweep(big, oracle):
+    """One whole sweep on the 300K-node level against the oracle (about a second of CPU)."""
+    import ctypes as C
+    mgcfd, s, q, levels = big
+    L = levels[0]
+    lib = oracle.load()
+    edges = np.ascontiguousarray(L["edges"]).copy()
+    coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+    lib.ora_adjust_ewt(oracle.ptr(coords), len(edges), oracle.ptr(edges))
+    lib.ora_dampen_ewt(len(edges), oracle.ptr(edges), 5e-8)
+    ff = oracle.farfield()
+    nel, ni, nb, nw = L["nel"], L["n_internal"], L["n_boundary"], L["n_wall"]
+    v, old, f, sf = q.copy(), q.copy(), np.zeros_like(q), np.zeros(nel)
+    vol = np.ascontiguousarray(L["volumes"], dtype=np.float64)
+    lib.ora_compute_step_factor(nel, oracle.ptr(v), oracle.ptr(vol), oracle.ptr(sf))
+    for j in range(3):
+        lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f))
+        lib.ora_compute_boundary_flux_edge(ni, nb, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f))
+        lib.ora_compute_wall_flux_edge(ni + nb, nw, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f), C.byref(ff))
+        lib.ora_time_step(j, nel, oracle.ptr(sf), oracle.ptr(f), oracle.ptr(old), oracle.ptr(v))
+    s.set_option("exact", 1)
+    s.set_option("fuse_update", 1)
+    s.set_option("graph", 1)
+    s.set(0, "variables", q)
+    s.zero_fluxes(0)
+    s.smooth(0, 1)
+    _assert_close(s.get(0, "variables"), v, True, "300K-node sweep")
+    _assert_close(s.get(0, "step_factors"), sf, True, "300K-node step factors")

@@ -18,8 +18,11 @@ the K timed steps, max over ranks, summed over ranks (weak scaling: every rank o
 copy, coupled through the global-min time step exactly like the reference's -m duplication:
 one all-reduce(MIN) of one fp64 per sweep over RCCL).
 
-roofline: the flux gather kernel, ALGORITHMIC bytes 40*E + 80*N per launch
-over its mean duration measured with hipEvents on the launch stream, against 8 TB/s.
+roofline: the dominant kernel, k_flux_tile — in the sweep it is launched as one whole
+Runge-Kutta stage (fluxes of all three edge classes + time_step).  It is priced with the
+ALGORITHMIC bytes of compute_flux_edge alone, 40*E + 80*N per launch, over its
+mean duration measured with hipEvent pairs on the launch stream during the timed region (the
+flux launches of every 8th sweep are bracketed; the other sweeps replay a hipGraph), vs 8 TB/s.
 cpu_baseline: the reference's own compute_flux_edge (oracle/_ref, built from the reference
 sources) — or the C oracle port when that build is absent — timed on one host core on the
 same mesh for a bounded number of passes.
@@ -190,7 +193,7 @@ def main():
             "flux_kernel_medges_per_s": round(n_int / flux_avg / 1e6, 1) if flux_avg > 0 else None,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "k_flux_gather", "launches": flux_launches,
+                         "kernel": "k_flux_tile (one RK stage: fluxes of all edge classes + time_step)", "launches": flux_launches,
                          "avg_kernel_us": round(flux_avg * 1e6, 3), "algorithmic_bytes_per_launch": algo_bytes},
         }
         if args.cpu_seconds > 0 and world == 1:

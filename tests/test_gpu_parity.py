@@ -329,6 +329,28 @@ def test_sharded_sweep_hooks_equal_smooth(mesh3_dir):
         assert abs(other[3] - results[0][3]) <= 1e-13 * results[0][3]
 
 
+def test_min_scalar_aliases_device_memory(mesh3_dir):
+    """The all-reduce acts on a torch tensor that must alias the library's device scalar."""
+    import torch
+    import mgcfd
+    from mgcfd.distributed import HipSolverAdapter
+    s = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", mesh3_dir))
+    s.set_stream(torch.cuda.current_stream().cuda_stream)
+    s.set(0, "variables", perturbed_state(s.nel(0), s.far_field()[:5], seed=3))
+    ad = HipSolverAdapter(s, torch.device("cuda", 0))
+    s.step_factor_local(0)
+    t = ad.min_tensor(0)
+    assert t.dtype == torch.float64 and t.is_cuda and t.numel() == 1
+    m = float(t.item())
+    s.step_factor_apply(0)
+    vol = s.get(0, "volumes")
+    assert np.array_equal(s.get(0, "step_factors"), m / vol)
+    t.fill_(0.25 * m)                      # what an all-reduce(MIN) with a smaller remote value does
+    s.step_factor_apply(0)
+    assert np.array_equal(s.get(0, "step_factors"), (0.25 * m) / vol)
+    s.close()
+
+
 # ------------------------------------------------------------------------------------------
 # BASELINE-size level (67^3 = 300,763 nodes / 888,822 edges): size-independent properties
 # ------------------------------------------------------------------------------------------

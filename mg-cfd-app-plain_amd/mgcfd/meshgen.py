@@ -142,6 +142,35 @@ def make_box_level(n: int, *, seed: int = 0, cavity_radius: float = 0.0, jitter:
                      nbr_idx=new_nb[order].copy(), nbr_w=w[order].copy())
 
 
+def make_random_graph_level(nel: int, *, degree: int = 6, seed: int = 0, boundary_fraction: float = 0.1) -> LevelMesh:
+    """A deliberately NON-geometric level: every node is joined to `degree` random others, so no
+    numbering has locality and any 256-node cluster touches far more outside nodes than an LDS
+    tile holds.  Exercises the overflow path of the flux kernel and the robustness of the
+    renumbering; physically meaningless (random weights, far-field faces on some nodes)."""
+    rng = np.random.default_rng(seed)
+    a = np.repeat(np.arange(nel, dtype=np.int64), degree // 2)
+    b = rng.integers(0, nel, len(a))
+    keep = a != b
+    a, b = a[keep], b[keep]
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    pairs = np.unique(np.stack([lo, hi], axis=1), axis=0)
+    lo, hi = pairs[:, 0], pairs[:, 1]
+    w = rng.normal(size=(len(lo), 3)) * 1e-3
+    n_bnd = int(boundary_fraction * nel)
+    bnodes = rng.choice(nel, n_bnd, replace=False).astype(np.int64)
+    bcode = np.where(rng.random(n_bnd) < 0.3, -1, -2).astype(np.int64)
+    bw = rng.normal(size=(n_bnd, 3)) * 1e-3
+    src = np.concatenate([lo, hi, bnodes])
+    nb = np.concatenate([hi, lo, bcode])
+    ww = np.concatenate([w, -w, bw])
+    order = np.lexsort((rng.random(len(src)), src))
+    counts = np.bincount(src, minlength=nel)
+    ptr = np.zeros(nel + 1, dtype=np.int64)
+    np.cumsum(counts, out=ptr[1:])
+    return LevelMesh(nel=nel, volumes=rng.uniform(0.5e-6, 2e-6, nel), coords=rng.random((nel, 3)), nbr_ptr=ptr,
+                     nbr_idx=nb[order].copy(), nbr_w=ww[order].copy())
+
+
 def nearest_map(fine: LevelMesh, coarse: LevelMesh) -> np.ndarray:
     from scipy.spatial import cKDTree
     _, idx = cKDTree(coarse.coords).query(fine.coords, k=1)

@@ -329,6 +329,64 @@ def test_sharded_sweep_hooks_equal_smooth(mesh3_dir):
         assert abs(other[3] - results[0][3]) <= 1e-13 * results[0][3]
 
 
+@pytest.mark.parametrize("exact", [True, False])
+def test_ragged_tiles_overflow_the_lds_halo(oracle, exact):
+    """A random (non-geometric) graph: every tile's halo is far larger than the LDS tile holds, so
+    most neighbour reads take the overflow path (straight from HBM).  Also a level with isolated
+    nodes, nodes with many faces, and a fine->coarse map that leaves coarse nodes without children."""
+    import ctypes as C
+    import mgcfd
+    from mgcfd import meshgen
+    fine = meshgen.make_random_graph_level(3000, degree=8, seed=1)
+    coarse = meshgen.make_random_graph_level(500, degree=6, seed=2)
+    fine.mg_map = (np.random.default_rng(3).integers(0, 400, fine.nel)).astype(np.int64)   # coarse 400..499 unmapped
+    mg = meshgen.MultigridMesh(mesh_name="m6wing", levels=[fine, coarse])
+    levels = mgcfd.generated_to_levels(mg)
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    s.set_option("exact", int(exact))
+    lib = oracle.load()
+    ff = oracle.farfield()
+    for l, L in enumerate(levels):
+        edges = np.ascontiguousarray(L["edges"]).copy()
+        coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+        lib.ora_adjust_ewt(oracle.ptr(coords), len(edges), oracle.ptr(edges))
+        lib.ora_dampen_ewt(len(edges), oracle.ptr(edges), 5e-8)
+        assert np.array_equal(s.get_edges(l, len(edges)), edges)
+        ni, nb, nw = L["n_internal"], L["n_boundary"], L["n_wall"]
+        q = perturbed_state(L["nel"], ff.var, seed=40 + l)
+        want = np.zeros_like(q)
+        lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(want))
+        lib.ora_compute_boundary_flux_edge(ni, nb, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(want))
+        lib.ora_compute_wall_flux_edge(ni + nb, nw, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(want), C.byref(ff))
+        s.set(l, "variables", q)
+        s.zero_fluxes(l)
+        s.compute_fluxes(l)
+        _assert_close(s.get(l, "fluxes"), want, exact, f"random-graph level {l} fluxes")
+    # restriction with unmapped coarse nodes keeps their value (mg_loops.cpp:63-78,174-189)
+    qf = perturbed_state(fine.nel, ff.var, seed=50)
+    qc = perturbed_state(coarse.nel, ff.var, seed=51)
+    want = qc.copy()
+    scratch = np.zeros(coarse.nel, dtype=np.int64)
+    lib.ora_mg_restrict(oracle.ptr(qf), oracle.ptr(want), coarse.nel, oracle.ptr(fine.mg_map), oracle.ptr(scratch), fine.nel)
+    s.set(0, "variables", qf)
+    s.set(1, "variables", qc)
+    s.restrict(0)
+    got = s.get(1, "variables")
+    _assert_close(got, want, exact, "restrict with unmapped coarse nodes")
+    assert np.array_equal(got[400:], qc[400:])
+    # a fused sweep on the ragged level equals the kernel-granular one
+    for fuse in (1, 0):
+        s.set_option("fuse_update", fuse)
+        s.set(0, "variables", qf)
+        s.zero_fluxes(0)
+        s.smooth(0, 2)
+        if fuse:
+            ref_v = s.get(0, "variables")
+        else:
+            assert np.array_equal(s.get(0, "variables").view(np.int64), ref_v.view(np.int64))
+    s.close()
+
+
 def test_min_scalar_aliases_device_memory(mesh3_dir):
     """The all-reduce acts on a torch tensor that must alias the library's device scalar."""
     import torch

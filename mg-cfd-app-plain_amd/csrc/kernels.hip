@@ -683,24 +683,28 @@ k_prolong(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t *__r
     const int32_t n_int = rows_int[slice];
     const int32_t parent = pro_parent[ii];
     const int64_t sc = stride_coarse;
+    // The node's own parent appears in every entry (and, through the reference's b1-for-a1 quirk,
+    // as BOTH terms of every entry in which this node is the edge's 'b' end): fetch it once.
+    const int64_t own = parent < 0 ? int64_t(~parent) : int64_t(parent);
+    const double o0 = coarse_residuals[own], o1 = coarse_residuals[sc + own], o2 = coarse_residuals[2 * sc + own],
+                 o3 = coarse_residuals[3 * sc + own], o4 = coarse_residuals[4 * sc + own];
     double r0, r1, r2, r3, r4;
     if (parent < 0) {
-        const int64_t p = ~parent;
-        r0 = coarse_residuals[p]; r1 = coarse_residuals[sc + p]; r2 = coarse_residuals[2 * sc + p];
-        r3 = coarse_residuals[3 * sc + p]; r4 = coarse_residuals[4 * sc + p];
+        r0 = o0; r1 = o1; r2 = o2; r3 = o3; r4 = o4;
     } else {
         r0 = r1 = r2 = r3 = r4 = 0.0;
         int64_t e = (int64_t(row0) << 6) + lane;
         for (int32_t r = 0; r < n_int; r++, e += 64) {
             const ProlongW pw = pro[e];
             if (pw.w_own == 0.0 && pw.w_other == 0.0) continue;      // ELL padding
-            const int64_t po = pw.p_own, px = pw.p_other;
-            r0 += pw.w_own * coarse_residuals[po]; r1 += pw.w_own * coarse_residuals[sc + po];
-            r2 += pw.w_own * coarse_residuals[2 * sc + po]; r3 += pw.w_own * coarse_residuals[3 * sc + po];
-            r4 += pw.w_own * coarse_residuals[4 * sc + po];
-            r0 += pw.w_other * coarse_residuals[px]; r1 += pw.w_other * coarse_residuals[sc + px];
-            r2 += pw.w_other * coarse_residuals[2 * sc + px]; r3 += pw.w_other * coarse_residuals[3 * sc + px];
-            r4 += pw.w_other * coarse_residuals[4 * sc + px];
+            r0 += pw.w_own * o0; r1 += pw.w_own * o1; r2 += pw.w_own * o2; r3 += pw.w_own * o3; r4 += pw.w_own * o4;
+            double x0 = o0, x1 = o1, x2 = o2, x3 = o3, x4 = o4;
+            if (pw.p_other != parent) {                                // the other end's parent: gather
+                const int64_t px = pw.p_other;
+                x0 = coarse_residuals[px]; x1 = coarse_residuals[sc + px]; x2 = coarse_residuals[2 * sc + px];
+                x3 = coarse_residuals[3 * sc + px]; x4 = coarse_residuals[4 * sc + px];
+            }
+            r0 += pw.w_other * x0; r1 += pw.w_other * x1; r2 += pw.w_other * x2; r3 += pw.w_other * x3; r4 += pw.w_other * x4;
         }
     }
     if (!active) return;

@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--lattice", type=int, default=LATTICE, help="nodes per side of the synthetic M6-L0-like level")
     ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
+    ap.add_argument("--variant", type=int, default=0, help="MGCFD_OPT_FLUX_VARIANT (0 stream k, 1 recompute k)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (0 disables)")
     args = ap.parse_args()
 
@@ -129,6 +130,7 @@ def main():
     stream = torch.cuda.current_stream()
     solver.set_stream(stream.cuda_stream)
     solver.set_option("exact", 0 if args.fast else 1)
+    solver.set_option("flux_variant", args.variant)
     nel, n_int = solver.nel(0), solver.num_internal_edges(0)
     solver.set(0, "variables", perturbed_state(nel, solver.far_field()[:5]))
 

@@ -265,8 +265,8 @@ k_step_factor_legacy(int64_t nel, int64_t stride, const double *__restrict__ q, 
 // reproduces the reference's floating-point result bit for bit (exact build).
 //
 // `classes` selects the edge classes (bit0 internal, bit1 solid wall "-1", bit2 far field
-// "-2"); `accumulate` != 0 starts from the value already in `fluxes` (the reference's "+=" when
-// the array is not known to be zero).  Halo nodes beyond the LDS capacity (ragged clusters
+// "-2"); ACC starts from the value already in `fluxes` (the reference's "+=" when the array is
+// not known to be zero).  Halo nodes beyond the LDS capacity (ragged clusters
 // only) are listed in a per-tile overflow table and read straight from HBM.
 // ------------------------------------------------------------------------------------------
 struct EdgeRow { uint32_t code; double fx, fy, fz, k; };
@@ -324,14 +324,14 @@ __device__ __forceinline__ Flux5 edge_flux(const NodeQ &me, const FluxC &fm, con
     return f;
 }
 
-template <int MINW, bool LOADK, bool FUSE>
+template <int MINW, bool LOADK, bool FUSE, bool ACC>
 __global__ void __launch_bounds__(kBlock, MINW)
 k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
             const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
             const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
             const int32_t *__restrict__ tile_halo_ptr, const int32_t *__restrict__ tile_halo,
             const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
-            double *__restrict__ fluxes, int classes, int accumulate, FusedStep fs)
+            double *__restrict__ fluxes, int classes, FusedStep fs)
 {
     __shared__ double2 tile[kTileCap * kLdsRecD2];
 
@@ -372,17 +372,9 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
     for (int32_t h = tid + kBlock; h < n_halo; h += kBlock)            // halo larger than the workgroup (rare)
         lds_store_record(&tile[(kTile + h) * kLdsRecD2], load_and_derive(q, stride, tile_halo[h0 + h]));
 
-    // FUSE: the time_step operands are independent of the flux — fetch them now, under the row loop
-    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, sf_in = 0.0;
-    if (FUSE) {
-        r0 = fs.old_variables[i]; r1 = fs.old_variables[stride + i]; r2 = fs.old_variables[2 * stride + i];
-        r3 = fs.old_variables[3 * stride + i]; r4 = fs.old_variables[4 * stride + i];
-        sf_in = fs.partial_min ? fs.volumes[i] : fs.step_factors[i];
-    }
-
-    const FluxC fm = flux_contribution(me);
+    const FluxC fm_pre = flux_contribution(me);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
-    if (accumulate) {
+    if (ACC) {
         a0 = fluxes[i]; a1 = fluxes[stride + i]; a2 = fluxes[2 * stride + i];
         a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
     }
@@ -410,13 +402,35 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
             n0 = lds_load_record(&tile[(v0 ? s0 : uint32_t(tid)) * kLdsRecD2]);
             n1 = lds_load_record(&tile[(v1 ? s1 : uint32_t(tid)) * kLdsRecD2]);
         }
-        const Flux5 f0 = edge_flux<LOADK>(me, fm, n0, e0);
-        const Flux5 f1 = edge_flux<LOADK>(me, fm, n1, e1);
+        Flux5 f0, f1;
+        if (FUSE) {
+            // The fused stage also holds the time_step operands: recompute this node's 9 flux
+            // contributions per row pair (13 flops) instead of keeping 18 more registers live
+            // across the loop, which would spill at 3 waves per SIMD.
+            double vx = me.vx;
+            asm volatile("" : "+v"(vx));
+            NodeQ m2 = me;
+            m2.vx = vx;
+            const FluxC fm2 = flux_contribution(m2);
+            f0 = edge_flux<LOADK>(me, fm2, n0, e0);
+            f1 = edge_flux<LOADK>(me, fm2, n1, e1);
+        } else {
+            f0 = edge_flux<LOADK>(me, fm_pre, n0, e0);
+            f1 = edge_flux<LOADK>(me, fm_pre, n1, e1);
+        }
         // accumulate strictly in row order (the reference's summation order)
-        a0 = v0 ? a0 + f0.d : a0;   a1 = v0 ? a1 + f0.mx : a1;   a2 = v0 ? a2 + f0.my : a2;
-        a3 = v0 ? a3 + f0.mz : a3;  a4 = v0 ? a4 + f0.en : a4;
-        a0 = v1 ? a0 + f1.d : a0;   a1 = v1 ? a1 + f1.mx : a1;   a2 = v1 ? a2 + f1.my : a2;
-        a3 = v1 ? a3 + f1.mz : a3;  a4 = v1 ? a4 + f1.en : a4;
+        if (ACC) {
+            // the sum may start from -0.0 read from memory: padding must leave it untouched
+            a0 = v0 ? a0 + f0.d : a0;   a1 = v0 ? a1 + f0.mx : a1;   a2 = v0 ? a2 + f0.my : a2;
+            a3 = v0 ? a3 + f0.mz : a3;  a4 = v0 ? a4 + f0.en : a4;
+            a0 = v1 ? a0 + f1.d : a0;   a1 = v1 ? a1 + f1.mx : a1;   a2 = v1 ? a2 + f1.my : a2;
+            a3 = v1 ? a3 + f1.mz : a3;  a4 = v1 ? a4 + f1.en : a4;
+        } else {
+            // ELL padding carries zero weights, so its contribution is +-0.0, and a sum that started
+            // at +0.0 can never be -0.0 (x + y = -0.0 only if both are): adding it changes no bit.
+            a0 += f0.d; a1 += f0.mx; a2 += f0.my; a3 += f0.mz; a4 += f0.en;
+            a0 += f1.d; a1 += f1.mx; a2 += f1.my; a3 += f1.mz; a4 += f1.en;
+        }
         e0 = e2; e1 = e3;
     }
 
@@ -424,6 +438,14 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
         // The reference runs ALL solid-wall faces, then ALL far-field faces; the plan lists a
         // node's faces in exactly that order, so one walk over the rows keeps the per-node order.
         const int32_t first_bnd = rows_int[slice];
+        FluxC fm = fm_pre;
+        if (FUSE) {                                  // see the row loop: keep fm out of the loop's live set
+            double vx = me.vx;
+            asm volatile("" : "+v"(vx));
+            NodeQ m2 = me;
+            m2.vx = vx;
+            fm = flux_contribution(m2);
+        }
         for (int32_t r = 0; r < n_bnd; r++) {
             const EdgeRow e = load_row<false>(nbr16, w, int64_t(row0) + first_bnd + r, lane);
             const double fx = e.fx, fy = e.fy, fz = e.fz;
@@ -452,10 +474,16 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
         return;
     }
     // ---- fused time_step: same operations as k_time_step on the flux just summed ----
-    double sf = sf_in;
+    // (operands fetched here, not under the row loop: the loop already sits at the register budget
+    //  of 3 waves per SIMD and hoisting these twelve registers makes it spill)
+    const double r0 = fs.old_variables[i], r1 = fs.old_variables[stride + i], r2 = fs.old_variables[2 * stride + i],
+                 r3 = fs.old_variables[3 * stride + i], r4 = fs.old_variables[4 * stride + i];
+    double sf;
     if (fs.partial_min) {                       // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
-        sf = min_dt / sf_in;                    // sf_in holds volumes[i] here
+        sf = min_dt / fs.volumes[i];
         fs.step_factors[i] = sf;
+    } else {
+        sf = fs.step_factors[i];
     }
     const double factor = sf / fs.rk_div;
     const double rho = r0 + factor * a0, mx = r1 + factor * a1, my = r2 + factor * a2, mz = r3 + factor * a3,
@@ -746,18 +774,18 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     const dim3 grid(p.n_tiles), block(kBlock);
     FusedStep fs{};
     if (fused) fs = *fused;
-#define MGCFD_TILE_LAUNCH(MINW, LOADK, FUSE)                                                                   \
-    hipLaunchKernelGGL((k_flux_tile<MINW, LOADK, FUSE>), grid, block, 0, st, p.nel, p.stride, q, p.slice_row0, \
-                       p.rows_int, p.rows_bnd, p.nbr16, p.w, p.tile_halo_ptr, p.tile_halo, p.tile_ovf_ptr,     \
-                       p.tile_ovf, ff, fluxes, classes, accumulate, fs)
+    // 3 tiles of 52.5 KiB LDS fit a CU => at least 3 waves per SIMD wanted
+#define MGCFD_TILE_LAUNCH(LOADK, FUSE, ACC)                                                                    \
+    hipLaunchKernelGGL((k_flux_tile<3, LOADK, FUSE, ACC>), grid, block, 0, st, p.nel, p.stride, q,             \
+                       p.slice_row0, p.rows_int, p.rows_bnd, p.nbr16, p.w, p.tile_halo_ptr, p.tile_halo,       \
+                       p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs)
+    const bool loadk = variant != 1;            // variant 1: recompute k = -|e|*s*0.5 from the weights
     if (fused) {
-        if (variant == 1) MGCFD_TILE_LAUNCH(3, false, true);
-        else MGCFD_TILE_LAUNCH(3, true, true);
-        return;
-    }
-    switch (variant) {
-        case 1: MGCFD_TILE_LAUNCH(3, false, false); break;    // recompute k = -|e|*s*0.5 from the weights
-        default: MGCFD_TILE_LAUNCH(3, true, false); break;    // 3 tiles of 52.5 KiB LDS fit a CU
+        if (loadk) MGCFD_TILE_LAUNCH(true, true, false); else MGCFD_TILE_LAUNCH(false, true, false);
+    } else if (accumulate) {
+        if (loadk) MGCFD_TILE_LAUNCH(true, false, true); else MGCFD_TILE_LAUNCH(false, false, true);
+    } else {
+        if (loadk) MGCFD_TILE_LAUNCH(true, false, false); else MGCFD_TILE_LAUNCH(false, false, false);
     }
 #undef MGCFD_TILE_LAUNCH
 }

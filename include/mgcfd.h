@@ -218,8 +218,12 @@ int mgcfd_step_factor_apply(mgcfd_solver *s, int level);
 /* One smoothing sweep (as mgcfd_smooth) split around that all-reduce, with the fused stage
  * kernels: sweep_begin = copy + first half of compute_step_factor + reduction to the scalar
  * behind mgcfd_step_factor_min_devptr; [all-reduce MIN that scalar across ranks];
- * sweep_end = the RK stages (fluxes + time_step fused, "/ volume" applied in the first) + residual. */
+ * sweep_end = the RK stages (fluxes + time_step fused, "/ volume" applied in the first) + residual.
+ * Optional, to HIDE the all-reduce: sweep_flux0 computes the first stage's fluxes, which do not
+ * depend on the time step, and may run while the collective is in flight; sweep_end then starts
+ * with time_step on them. */
 int mgcfd_sweep_begin(mgcfd_solver *s, int level);
+int mgcfd_sweep_flux0(mgcfd_solver *s, int level);
 int mgcfd_sweep_end(mgcfd_solver *s, int level);
 /* Sum of squared residuals of the level, left in a device scalar (all-reduce SUM, then
  * rms = sqrt(sum / global_nel)). */

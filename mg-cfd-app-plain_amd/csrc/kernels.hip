@@ -798,11 +798,11 @@ void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, do
 
 void launch_time_step(hipStream_t st, int64_t nel, int64_t stride, int j, double *sf, double *fluxes,
                       const double *old_variables, double *q, const int32_t *old_of_new, unsigned long long *err, int check,
-                      const double *partial_min, const double *volumes, double *residuals, int zero_fluxes)
+                      const double *partial_min, int n_partial, const double *volumes, double *residuals, int zero_fluxes)
 {
     const double rk_div = double(3 + 1 - j);    // double(RK+1-j), cfd_loops.cpp:243
     hipLaunchKernelGGL(k_time_step, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, rk_div, sf, fluxes,
-                       old_variables, q, old_of_new, err, check, partial_min, int(grid_for(nel)), volumes, residuals,
+                       old_variables, q, old_of_new, err, check, partial_min, n_partial, volumes, residuals,
                        zero_fluxes);
 }
 

@@ -18,7 +18,7 @@
     void launch_indirect_rw(hipStream_t, const DevicePlan &, const double *q, double *fluxes);                       \
     void launch_time_step(hipStream_t, int64_t nel, int64_t stride, int j, double *sf, double *fluxes,               \
                           const double *old_variables, double *q, const int32_t *old_of_new,                         \
-                          unsigned long long *err, int check, const double *partial_min,                             \
+                          unsigned long long *err, int check, const double *partial_min, int n_partial,              \
                           const double *volumes, double *residuals, int zero_fluxes);                                \
     void launch_check_invalid(hipStream_t, int64_t nel, int64_t stride, const double *q,                             \
                               const int32_t *old_of_new, unsigned long long *err);                                   \

@@ -67,6 +67,7 @@ struct DeviceLevel {
     int n_partials = 0;
     bool fluxes_zero = true;             // fluxes[] is logically zero (the flux launch need not read it)
     bool fluxes_stale = false;           // ... but its memory has not been zeroed (lazy zero after a fused time_step)
+    bool sweep_flux0_done = false;       // mgcfd_sweep_flux0 ran since mgcfd_sweep_begin
     bool has_transfer = false;           // plan to the next-coarser level present
     int64_t iters[MGCFD_NUM_LOOPS] = {0};
     double times[MGCFD_NUM_LOOPS] = {0};
@@ -253,16 +254,18 @@ struct mgcfd_solver {
         lv.fluxes_zero = true;
         lv.fluxes_stale = false;
     }
-    void op_time_step(int l, int j, bool apply_min = false, bool with_residual = false, bool lazy_zero = false)
+    // apply_min: 0 no, 1 from the workgroups' partial minima, 2 from the (all-reduced) scalar
+    void op_time_step(int l, int j, int apply_min = 0, bool with_residual = false, bool lazy_zero = false)
     {
         if (j < 0 || j >= MGCFD_RK) throw std::invalid_argument("RK stage out of range");
         DeviceLevel &lv = level(l);
         settle_fluxes(lv);
         Timed t(this, l, MGCFD_LOOP_TIME_STEP);
-        const double *pm = apply_min ? lv.partial_min : nullptr;
+        const double *pm = apply_min == 1 ? lv.partial_min : (apply_min == 2 ? lv.min_dt : nullptr);
+        const int n_pm = apply_min == 2 ? 1 : static_cast<int>((lv.info.nel + 255) / 256);
         double *res = with_residual ? lv.residuals : nullptr;
-        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, pm, lv.volumes, res, lazy_zero ? 0 : 1);
-        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, pm, lv.volumes, res, lazy_zero ? 0 : 1);
+        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, pm, n_pm, lv.volumes, res, lazy_zero ? 0 : 1);
+        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, pm, n_pm, lv.volumes, res, lazy_zero ? 0 : 1);
         lv.fluxes_stale = lazy_zero;
         lv.fluxes_zero = true;
         lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
@@ -685,7 +688,7 @@ static void smooth_once(mgcfd_solver *s, int level)
     for (int j = 0; j < MGCFD_RK; j++) {                           // :397-506
         s->op_flux(level, 7);
         // the indirect_rw probe reads fluxes[] right after, so zero for real when it is on
-        s->op_time_step(level, j, apply_pending && j == 0, j == MGCFD_RK - 1, !s->opt_indirect_rw);   // + :508 on the last stage
+        s->op_time_step(level, j, (apply_pending && j == 0) ? 1 : 0, j == MGCFD_RK - 1, !s->opt_indirect_rw);   // + :508 on the last stage
         if (s->opt_indirect_rw) { s->op_indirect_rw(level); s->op_zero_fluxes(level); }
     }
 }
@@ -741,17 +744,32 @@ int mgcfd_sweep_begin(mgcfd_solver *s, int level)
     OP({
         DeviceLevel &lv = s->level(level);
         if (!lv.fluxes_zero) throw std::invalid_argument("sweep_begin needs zero fluxes (as after time_step)");
+        lv.sweep_flux0_done = false;
         const bool pending = s->op_step_factor(level, true);       // copy + first half, partial minima
         if (pending) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
+    });
+}
+int mgcfd_sweep_flux0(mgcfd_solver *s, int level)
+{
+    OP({
+        DeviceLevel &lv = s->level(level);
+        if (!lv.fluxes_zero) throw std::invalid_argument("sweep_flux0 must follow sweep_begin");
+        s->op_flux(level, 7);                      // stage-0 fluxes: independent of the time step
+        lv.sweep_flux0_done = true;
     });
 }
 int mgcfd_sweep_end(mgcfd_solver *s, int level)
 {
     OP({
         DeviceLevel &lv = s->level(level);
-        s->settle_fluxes(lv);
         const int apply = s->mesh_variant == MGCFD_MESH_FVCORR ? 0 : 2;
-        s->op_fused_stage(level, 0, lv.old_variables, lv.q, apply, false);
+        if (lv.sweep_flux0_done) {
+            s->op_time_step(level, 0, apply, false, true);         // time_step on the fluxes of sweep_flux0
+            lv.sweep_flux0_done = false;
+        } else {
+            s->settle_fluxes(lv);
+            s->op_fused_stage(level, 0, lv.old_variables, lv.q, apply, false);
+        }
         s->op_fused_stage(level, 1, lv.q, lv.q_alt, 0, false);
         s->op_fused_stage(level, 2, lv.q_alt, lv.q, 0, true);
     });

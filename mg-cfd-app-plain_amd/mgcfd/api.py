@@ -93,6 +93,7 @@ _SIGNATURES = [
     ("mgcfd_step_factor_min_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_step_factor_apply", C.c_int, [_vp, C.c_int]),
     ("mgcfd_sweep_begin", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_sweep_flux0", C.c_int, [_vp, C.c_int]),
     ("mgcfd_sweep_end", C.c_int, [_vp, C.c_int]),
     ("mgcfd_residual_sumsq", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
 ]
@@ -353,6 +354,7 @@ class Solver:
     def step_factor_apply(self, l): self._c(self.lib.mgcfd_step_factor_apply(self.handle, l))
 
     def sweep_begin(self, l): self._c(self.lib.mgcfd_sweep_begin(self.handle, l))
+    def sweep_flux0(self, l): self._c(self.lib.mgcfd_sweep_flux0(self.handle, l))
     def sweep_end(self, l): self._c(self.lib.mgcfd_sweep_end(self.handle, l))
 
     def step_factor_min_devptr(self, l) -> int:

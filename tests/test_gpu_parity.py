@@ -308,7 +308,7 @@ def test_sharded_sweep_hooks_equal_smooth(mesh3_dir):
     from mgcfd.distributed import HipSolverAdapter, ShardedSweep
     mesh = mgcfd.Mesh("input.dat", mesh3_dir)
     results = []
-    for mode in ("smooth", "sharded-fused", "sharded-unfused"):
+    for mode in ("smooth", "sharded-fused", "sharded-fused-overlap", "sharded-unfused"):
         s = mgcfd.Solver.from_mesh(mesh)
         q = perturbed_state(s.nel(0), s.far_field()[:5], seed=77)
         s.set(0, "variables", q)
@@ -317,7 +317,8 @@ def test_sharded_sweep_hooks_equal_smooth(mesh3_dir):
             rms = s.calc_rms(0)
         else:
             s.set_stream(torch.cuda.current_stream().cuda_stream)
-            sw = ShardedSweep(HipSolverAdapter(s, torch.device("cuda", 0)), None, fused=(mode == "sharded-fused"))
+            sw = ShardedSweep(HipSolverAdapter(s, torch.device("cuda", 0)), None, fused=mode.startswith("sharded-fused"))
+            sw.overlap_even_alone = mode.endswith("overlap")      # the path a multi-rank run takes
             for _ in range(3):
                 sw.sweep(0)
             rms = sw.rms(0, s.nel(0))

@@ -177,6 +177,15 @@ def main():
     # launches between one hipEvent pair on the same stream
     flux_only = solver.bench_flux(0, 50)
 
+    # HBM-side traffic per launch from the committed PMC profile of this same command (bench.py
+    # cannot collect hardware counters itself); None when the workload differs from the profiled one
+    traffic = {}
+    try:
+        if args.lattice == LATTICE and not args.fast and args.variant == 0:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+    except (OSError, ValueError):
+        traffic = {}
+
     if rank == 0:
         edges_total = 3 * n_int * args.steps * world
         # ALGORITHMIC bytes: compute_flux_edge 40*E + 80*N; time_step 168 B/node.
@@ -205,7 +214,8 @@ def main():
                        "numerics": "fast (FMA contraction)" if args.fast else "exact (bit-identical to the reference)",
                        "parallelism": f"{world} mesh copies, all-reduce(min dt) per sweep" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic.get("k_flux_tile_fused_stage", {}).get("bytes"),
                          "kernel": "k_flux_tile<FUSE>: one RK stage per launch = compute_flux_edge + boundary + wall fluxes + time_step",
                          "launches": flux_launches, "avg_kernel_us": round(flux_avg * 1e6, 3),
                          "algorithmic_bytes_per_launch": algo_bytes,
@@ -215,6 +225,7 @@ def main():
                                                "avg_kernel_us": round(flux_only * 1e6, 3), "launches": 50,
                                                "algorithmic_bytes_per_launch": bytes_flux,
                                                "achieved": round(achieved_flux_only, 1),
+                                               "traffic": traffic.get("k_flux_tile_flux_only", {}).get("bytes"),
                                                "frac": round(achieved_flux_only / HBM_PEAK_GBS, 4),
                                                "medges_per_s": round(n_int / flux_only / 1e6, 1) if flux_only > 0 else None}},
         }

@@ -666,6 +666,16 @@ k_sum_partials(int n, const double *__restrict__ partial, double *__restrict__ o
     }
 }
 
+// rms history: append a device scalar to a ring (lets a whole multigrid cycle live in one hipGraph)
+__global__ void k_append_scalar(const double *__restrict__ src, double *__restrict__ ring, int *__restrict__ count, int cap)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int k = *count;
+        if (k < cap) ring[k] = src[0];
+        *count = k + 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // mg_restrict (mg_loops.cpp:30-202) as a coarse-centred gather: coarse = (sum of children in
 // ascending fine id) * (1/count); coarse nodes without children keep their value.
@@ -818,6 +828,9 @@ void launch_sumsq(hipStream_t st, int64_t nel, int64_t stride, const double *x, 
     hipLaunchKernelGGL(k_sumsq, dim3(n_partial), dim3(kBlock), 0, st, nel, stride, x, partial);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, n_partial, partial, out);
 }
+
+void launch_append_scalar(hipStream_t st, const double *src, double *ring, int *count, int cap)
+{ hipLaunchKernelGGL(k_append_scalar, dim3(1), dim3(64), 0, st, src, ring, count, cap); }
 
 void launch_restrict(hipStream_t st, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,
                      const int32_t *child_ptr, const int32_t *child, const double *fine_q, double *coarse_q)

@@ -26,6 +26,7 @@
                          double *residuals);                                                                         \
     void launch_sumsq(hipStream_t, int64_t nel, int64_t stride, const double *x, double *partial, int n_partial,     \
                       double *out);                                                                                  \
+    void launch_append_scalar(hipStream_t, const double *src, double *ring, int *count, int cap);                    \
     void launch_restrict(hipStream_t, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,                \
                          const int32_t *child_ptr, const int32_t *child, const double *fine_q, double *coarse_q);    \
     void launch_prolong(hipStream_t, const DevicePlan &, int64_t stride_coarse, const double *coarse_residuals,      \

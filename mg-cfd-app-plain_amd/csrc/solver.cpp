@@ -6,6 +6,7 @@
 // V-cycle state machine (src/euler3d_cpu_double.cpp:371-694).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -95,6 +96,11 @@ struct mgcfd_solver {
     bool in_timed_group = false;
     struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; };
     std::map<uint64_t, SweepGraph> sweep_graphs;   // captured smoothing sweeps, keyed by (level, options)
+    struct CycleGraph { hipGraphExec_t exec = nullptr; std::vector<std::vector<int64_t>> iters; };
+    std::map<uint64_t, CycleGraph> cycle_graphs;   // captured whole multigrid cycles, keyed by options
+    static constexpr int kRmsRing = 4096;
+    double *rms_ring = nullptr;                    // level-0 sum of squares of the cycles run since the last read-back
+    int *rms_count = nullptr;
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> free_events;
 
@@ -325,6 +331,9 @@ mgcfd_solver::~mgcfd_solver()
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto &g : sweep_graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+    for (auto &g : cycle_graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+    if (rms_ring) (void)hipFree(rms_ring);
+    if (rms_count) (void)hipFree(rms_count);
     for (auto &p : pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto e : free_events) (void)hipEventDestroy(e);
     for (auto &lv : L) {
@@ -784,37 +793,86 @@ int mgcfd_smooth(mgcfd_solver *s, int level, int sweeps)
 }
 
 // ---- cycle driver: src/euler3d_cpu_double.cpp:371-694 ----
+// One multigrid cycle of the reference's state machine, unrolled: sweeps on levels
+// 0,1,..,n-1,n-2,..,1 with restrictions on the way up and prolongations on the way down
+// (src/euler3d_cpu_double.cpp:371-694); the level-0 sum of squares is appended to the rms ring.
+static void cycle_once(mgcfd_solver *s, bool capturing)
+{
+    const int n = static_cast<int>(s->L.size());
+    auto sweep = [&](int l) { if (capturing) smooth_once(s, l); else run_sweep(s, l); };
+    for (int l = 0; l < n; l++) {
+        sweep(l);                                                          // :383-508
+        if (l == 0) {                                                      // :509-512
+            s->op_sumsq(0);
+            exact::launch_append_scalar(s->stream, s->L[0].sumsq, s->rms_ring, s->rms_count, mgcfd_solver::kRmsRing);
+        }
+        if (l + 1 < n) s->op_restrict(l);                                  // :527-559
+    }
+    for (int l = n - 2; l >= 0; l--) {
+        s->op_prolong(l);                                                  // :560-688
+        if (l > 0) sweep(l);
+    }
+}
+
 int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
 {
     REQUIRE(s);
     int code = MGCFD_OK;
     int rc = guarded([&] {
         s->use_device();
-        const int nlevels = static_cast<int>(s->L.size());
-        double *rms_dev = cycles > 0 ? dev_alloc<double>(static_cast<size_t>(cycles)) : nullptr;
-        int level = 0;
-        bool going_up = true;
-        for (int cyc = 0; cyc < cycles;) {
-            run_sweep(s, level);                                    // :383-508
-            if (level == 0) {                                              // :509-512
-                s->op_sumsq(0);
-                HIP_CHECK(hipMemcpyAsync(rms_dev + cyc, s->L[0].sumsq, sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-            }
-            if (nlevels <= 1) { cyc++; continue; }
-            if (going_up) {                                                // :527-559
-                level++;
-                s->op_restrict(level - 1);
-                if (level == nlevels - 1) going_up = false;
-            } else {                                                       // :560-688
-                level--;
-                s->op_prolong(level);
-                if (level == 0) { going_up = true; cyc++; }
-            }
+        if (!s->rms_ring) {
+            s->rms_ring = dev_alloc<double>(mgcfd_solver::kRmsRing);
+            s->rms_count = dev_alloc<int>(1);
         }
-        std::vector<double> sums(static_cast<size_t>(cycles > 0 ? cycles : 0));
-        if (cycles > 0) HIP_CHECK(hipMemcpyAsync(sums.data(), rms_dev, sizeof(double) * cycles, hipMemcpyDeviceToHost, s->stream));
+        const size_t nl = s->L.size();
+        std::vector<double> sums;
+        sums.reserve(static_cast<size_t>(cycles > 0 ? cycles : 0));
+        for (int done = 0; done < cycles;) {
+            const int chunk = std::min(cycles - done, mgcfd_solver::kRmsRing);
+            HIP_CHECK(hipMemsetAsync(s->rms_count, 0, sizeof(int), s->stream));
+            bool graphable = s->opt_graph && s->opt_fuse && !s->opt_indirect_rw && s->opt_timing == 0;
+            for (auto &lv : s->L) graphable = graphable && lv.fluxes_zero && !lv.fluxes_stale;
+            if (graphable) {
+                // the whole cycle — every sweep and transfer of every level — as ONE graph replay
+                const uint64_t key = (uint64_t(s->opt_exact) << 16) | (uint64_t(s->opt_check) << 8) | uint64_t(s->opt_variant & 0xFF);
+                auto it = s->cycle_graphs.find(key);
+                if (it == s->cycle_graphs.end()) {
+                    mgcfd_solver::CycleGraph g;
+                    std::vector<std::vector<int64_t>> before(nl);
+                    for (size_t l = 0; l < nl; l++) before[l].assign(s->L[l].iters, s->L[l].iters + MGCFD_NUM_LOOPS);
+                    hipGraph_t graph = nullptr;
+                    HIP_CHECK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+                    try {
+                        cycle_once(s, true);
+                    } catch (...) {
+                        (void)hipStreamEndCapture(s->stream, &graph);
+                        if (graph) (void)hipGraphDestroy(graph);
+                        throw;
+                    }
+                    HIP_CHECK(hipStreamEndCapture(s->stream, &graph));
+                    HIP_CHECK(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+                    HIP_CHECK(hipGraphDestroy(graph));
+                    g.iters.resize(nl);
+                    for (size_t l = 0; l < nl; l++)
+                        for (int k = 0; k < MGCFD_NUM_LOOPS; k++) {
+                            g.iters[l].push_back(s->L[l].iters[k] - before[l][static_cast<size_t>(k)]);
+                            s->L[l].iters[k] = before[l][static_cast<size_t>(k)];
+                        }
+                    it = s->cycle_graphs.emplace(key, std::move(g)).first;
+                }
+                for (int c = 0; c < chunk; c++) HIP_CHECK(hipGraphLaunch(it->second.exec, s->stream));
+                for (size_t l = 0; l < nl; l++)
+                    for (int k = 0; k < MGCFD_NUM_LOOPS; k++) s->L[l].iters[k] += it->second.iters[l][static_cast<size_t>(k)] * chunk;
+            } else {
+                for (int c = 0; c < chunk; c++) cycle_once(s, false);
+            }
+            const size_t at = sums.size();
+            sums.resize(at + static_cast<size_t>(chunk));
+            HIP_CHECK(hipMemcpyAsync(sums.data() + at, s->rms_ring, sizeof(double) * chunk, hipMemcpyDeviceToHost, s->stream));
+            HIP_CHECK(hipStreamSynchronize(s->stream));
+            done += chunk;
+        }
         code = s->read_error(nullptr);                                     // synchronises
-        if (rms_dev) HIP_CHECK(hipFree(rms_dev));
         if (rms_out)
             for (int c = 0; c < cycles; c++) rms_out[c] = std::sqrt(sums[static_cast<size_t>(c)] / double(s->L[0].info.nel));
         HIP_CHECK(hipGetLastError());

@@ -122,6 +122,13 @@ int mgcfd_identify_differences(const double *test_values, const double *master_v
 int mgcfd_create(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device,
                  mgcfd_solver **out);
 int mgcfd_create_from_mesh(const mgcfd_mesh *m, int device, mgcfd_solver **out);
+/* A level PARTITIONED over ranks (multi-GPU "within a level"): every rank passes its own part —
+ * its owned nodes numbered first, then ghost copies of the other ranks' nodes its edges touch, and
+ * every edge with at least one owned end point (relative order as in the whole mesh, so sums keep
+ * the reference's order).  n_owned[l] = number of owned nodes of level l (nodes with id >= n_owned
+ * are ghosts: gathered from, never updated; excluded from the RMS).  Single level for now. */
+int mgcfd_create_partitioned(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device,
+                             const int64_t *n_owned, mgcfd_solver **out);
 void mgcfd_destroy(mgcfd_solver *s);
 int mgcfd_set_option(mgcfd_solver *s, int option, int value);
 int mgcfd_get_option(const mgcfd_solver *s, int option, int *value);
@@ -225,6 +232,14 @@ int mgcfd_step_factor_apply(mgcfd_solver *s, int level);
 int mgcfd_sweep_begin(mgcfd_solver *s, int level);
 int mgcfd_sweep_flux0(mgcfd_solver *s, int level);
 int mgcfd_sweep_end(mgcfd_solver *s, int level);
+/* Halo exchange of a partitioned level.  A plan is a list of local node ids (the nodes this rank
+ * sends to one peer, or the ghosts it receives from it, in an order both sides agree on);
+ * pack copies their 5 values of array `which` (MGCFD_ARR_*) into a contiguous [n][5] fp64 message
+ * in DEVICE memory, unpack writes a received message into them.  The message itself moves by
+ * RCCL send/recv (torch.distributed) between the two calls. */
+int mgcfd_halo_plan(mgcfd_solver *s, int level, int64_t n, const int64_t *node_ids, int *plan);
+int mgcfd_halo_pack(mgcfd_solver *s, int level, int plan, int which, void *dev_buf);
+int mgcfd_halo_unpack(mgcfd_solver *s, int level, int plan, int which, const void *dev_buf);
 /* Sum of squared residuals of the level, left in a device scalar (all-reduce SUM, then
  * rms = sqrt(sum / global_nel)). */
 int mgcfd_residual_sumsq(mgcfd_solver *s, int level, void **devptr);

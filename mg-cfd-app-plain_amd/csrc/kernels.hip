@@ -634,12 +634,15 @@ k_residual(int64_t n, const double *__restrict__ old_variables, const double *__
 // sum of squares for calc_rms (validation.cpp:91-105) over the nel real entries of 5 fields.
 // Tree order differs from the reference's serial sum; the value is only ever printed with %.3e.
 __global__ void __launch_bounds__(kBlock)
-k_sumsq(int64_t nel, int64_t stride, const double *__restrict__ x, double *__restrict__ partial)
+k_sumsq(int64_t nel, int64_t stride, const double *__restrict__ x, double *__restrict__ partial,
+        const int32_t *__restrict__ old_of_new, int64_t n_owned)
 {
     __shared__ double s[kBlock / 64];
     double acc = 0.0;
-    for (int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x; i < nel; i += int64_t(gridDim.x) * kBlock)
+    for (int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x; i < nel; i += int64_t(gridDim.x) * kBlock) {
+        if (old_of_new && old_of_new[i] >= n_owned) continue;        // ghost of a partitioned level: counted by its owner
         for (int f = 0; f < 5; f++) { const double v = x[f * stride + i]; acc += v * v; }
+    }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -664,6 +667,28 @@ k_sum_partials(int n, const double *__restrict__ partial, double *__restrict__ o
         for (int w = 0; w < kBlock / 64; w++) t += s[w];
         out[0] = t;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Halo exchange of a partitioned level: pack n nodes' 5 values into a contiguous [n][5] message
+// (what an RCCL send/recv moves) and unpack a received message into the ghost nodes.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_halo_pack(int64_t n, int64_t stride, const int32_t *__restrict__ idx, const double *__restrict__ field, double *__restrict__ msg)
+{
+    const int64_t k = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    if (k >= n) return;
+    const int64_t i = idx[k];
+    for (int f = 0; f < 5; f++) msg[k * 5 + f] = field[f * stride + i];
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_halo_unpack(int64_t n, int64_t stride, const int32_t *__restrict__ idx, const double *__restrict__ msg, double *__restrict__ field)
+{
+    const int64_t k = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    if (k >= n) return;
+    const int64_t i = idx[k];
+    for (int f = 0; f < 5; f++) field[f * stride + i] = msg[k * 5 + f];
 }
 
 // rms history: append a device scalar to a ring (lets a whole multigrid cycle live in one hipGraph)
@@ -823,11 +848,19 @@ void launch_check_invalid(hipStream_t st, int64_t nel, int64_t stride, const dou
 void launch_residual(hipStream_t st, int64_t stride, const double *old_variables, const double *q, double *residuals)
 { hipLaunchKernelGGL(k_residual, dim3(grid_for(stride * 5)), dim3(kBlock), 0, st, stride * 5, old_variables, q, residuals); }
 
-void launch_sumsq(hipStream_t st, int64_t nel, int64_t stride, const double *x, double *partial, int n_partial, double *out)
+void launch_sumsq(hipStream_t st, int64_t nel, int64_t stride, const double *x, double *partial, int n_partial, double *out,
+                  const int32_t *old_of_new, int64_t n_owned)
 {
-    hipLaunchKernelGGL(k_sumsq, dim3(n_partial), dim3(kBlock), 0, st, nel, stride, x, partial);
+    hipLaunchKernelGGL(k_sumsq, dim3(n_partial), dim3(kBlock), 0, st, nel, stride, x, partial,
+                       n_owned < nel ? old_of_new : nullptr, n_owned);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, n_partial, partial, out);
 }
+
+void launch_halo_pack(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const double *field, double *msg)
+{ if (n > 0) hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, field, msg); }
+
+void launch_halo_unpack(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const double *msg, double *field)
+{ if (n > 0) hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, msg, field); }
 
 void launch_append_scalar(hipStream_t st, const double *src, double *ring, int *count, int cap)
 { hipLaunchKernelGGL(k_append_scalar, dim3(1), dim3(64), 0, st, src, ring, count, cap); }

@@ -25,7 +25,11 @@
     void launch_residual(hipStream_t, int64_t stride, const double *old_variables, const double *q,                  \
                          double *residuals);                                                                         \
     void launch_sumsq(hipStream_t, int64_t nel, int64_t stride, const double *x, double *partial, int n_partial,     \
-                      double *out);                                                                                  \
+                      double *out, const int32_t *old_of_new, int64_t n_owned);                                      \
+    void launch_halo_pack(hipStream_t, int64_t n, int64_t stride, const int32_t *idx, const double *field,           \
+                          double *msg);                                                                              \
+    void launch_halo_unpack(hipStream_t, int64_t n, int64_t stride, const int32_t *idx, const double *msg,           \
+                            double *field);                                                                          \
     void launch_append_scalar(hipStream_t, const double *src, double *ring, int *count, int cap);                    \
     void launch_restrict(hipStream_t, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,                \
                          const int32_t *child_ptr, const int32_t *child, const double *fine_q, double *coarse_q);    \

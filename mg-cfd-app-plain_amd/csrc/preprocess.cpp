@@ -222,6 +222,12 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
 
     P.nel = nel;
     const Adjacency g = build_adjacency(nel, edges.data(), L.internal_start, L.n_internal);
+    const int64_t n_owned = (opt.n_owned < 0 || opt.n_owned > nel) ? nel : opt.n_owned;
+    auto owned = [&](int64_t original_id) { return original_id < n_owned; };
+    // incidence rows a node will actually hold (ghosts hold none)
+    auto rows_of = [&](int32_t v) -> int32_t {
+        return owned(v) ? g.ptr[static_cast<size_t>(v) + 1] - g.ptr[static_cast<size_t>(v)] : 0;
+    };
 
     // ---- node order ----
     std::vector<int32_t> order;
@@ -229,8 +235,8 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     else if (opt.ordering == 1) order = cuthill_mckee(g, nel);
     else { order.resize(static_cast<size_t>(nel)); std::iota(order.begin(), order.end(), 0); }
     std::vector<int32_t> bnd_count(static_cast<size_t>(nel), 0);
-    for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++) bnd_count[static_cast<size_t>(edges[e].b)]++;
-    for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++) bnd_count[static_cast<size_t>(edges[e].b)]++;
+    for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++) if (owned(edges[e].b)) bnd_count[static_cast<size_t>(edges[e].b)]++;
+    for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++) if (owned(edges[e].b)) bnd_count[static_cast<size_t>(edges[e].b)]++;
     if (opt.degree_sort) {
         // Inside each tile sort by (internal degree, boundary faces) so the 64 nodes of a
         // slice have equal row counts and ELL padding stays small; tile membership is kept.
@@ -238,8 +244,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         for (int64_t s = 0; s < nel; s += W) {
             auto b = order.begin() + s, e = order.begin() + std::min(nel, s + W);
             std::stable_sort(b, e, [&](int32_t x, int32_t y) {
-                int dx = g.ptr[static_cast<size_t>(x) + 1] - g.ptr[static_cast<size_t>(x)];
-                int dy = g.ptr[static_cast<size_t>(y) + 1] - g.ptr[static_cast<size_t>(y)];
+                int dx = rows_of(x), dy = rows_of(y);
                 if (dx != dy) return dx > dy;
                 return bnd_count[static_cast<size_t>(x)] > bnd_count[static_cast<size_t>(y)];
             });
@@ -257,7 +262,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     for (int64_t n = 0; n < nel; n++) {
         const int32_t old = order[static_cast<size_t>(n)];
         const int32_t s = static_cast<int32_t>(n / kSlice);
-        const int32_t d = g.ptr[static_cast<size_t>(old) + 1] - g.ptr[static_cast<size_t>(old)];
+        const int32_t d = rows_of(old);
         P.rows_int[static_cast<size_t>(s)] = std::max(P.rows_int[static_cast<size_t>(s)], d);
         P.rows_bnd[static_cast<size_t>(s)] = std::max(P.rows_bnd[static_cast<size_t>(s)], bnd_count[static_cast<size_t>(old)]);
     }
@@ -282,15 +287,21 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         const double ewt = std::sqrt(E.x * E.x + E.y * E.y + E.z * E.z);      // flux_kernel.elemfunc.c:27
         const double k = -ewt * kSmoothing * 0.5;                              // prefix of :130
         const double fx = -0.5 * E.x, fy = -0.5 * E.y, fz = -0.5 * E.z;       // :138-140
-        int64_t ia = entry_index(a, fill_int[static_cast<size_t>(a)]++);
-        P.nbr[static_cast<size_t>(ia)] = b;                                    // this node is 'a'
-        P.w[static_cast<size_t>(ia)] = EdgeW{fx, fy, fz, k};
-        int64_t ib = entry_index(b, fill_int[static_cast<size_t>(b)]++);
-        P.nbr[static_cast<size_t>(ib)] = a | kRoleB;                           // this node is 'b'
-        P.w[static_cast<size_t>(ib)] = EdgeW{-fx, -fy, -fz, k};                // x - f*y == x + (-f)*y exactly
-        useful += 2;
+        if (owned(E.a)) {
+            int64_t ia = entry_index(a, fill_int[static_cast<size_t>(a)]++);
+            P.nbr[static_cast<size_t>(ia)] = b;                                // this node is 'a'
+            P.w[static_cast<size_t>(ia)] = EdgeW{fx, fy, fz, k};
+            useful++;
+        }
+        if (owned(E.b)) {
+            int64_t ib = entry_index(b, fill_int[static_cast<size_t>(b)]++);
+            P.nbr[static_cast<size_t>(ib)] = a | kRoleB;                       // this node is 'b'
+            P.w[static_cast<size_t>(ib)] = EdgeW{-fx, -fy, -fz, k};            // x - f*y == x + (-f)*y exactly
+            useful++;
+        }
     }
     auto add_face = [&](const mgcfd_edge &E, int32_t code, double scale) {
+        if (!owned(E.b)) return;
         const int32_t b = P.new_of_old[static_cast<size_t>(E.b)];
         const int32_t s = b / kSlice;
         int64_t i = entry_index(b, P.rows_int[static_cast<size_t>(s)] + fill_bnd[static_cast<size_t>(b)]++);

@@ -76,11 +76,16 @@ struct LevelPlan {
     std::vector<double> pro_wsum;      // [nel] sum of weights in reference order (1.0 when coincident)
 };
 
+// n_owned < nel marks the nodes with ORIGINAL id >= n_owned as ghosts of a partitioned level:
+// read-only copies of nodes another rank owns.  They are staged and gathered like any node but
+// get no incidence rows of their own (their flux stays zero, time_step leaves them unchanged, and
+// the halo exchange overwrites them).
 struct PlanOptions {
     // 0: keep the caller's numbering; 1: breadth-first (Cuthill-McKee) bands; 2: compact clusters of
     // kTile nodes grown greedily over the mesh graph (smallest halo per tile; default)
     int ordering = 2;
     bool degree_sort = true;           // inside each tile, sort nodes by degree (less ELL padding per slice)
+    int64_t n_owned = -1;              // -1: every node is owned
 };
 
 // `edges` are the level's final edge weights (after adjust/dampen).  coarse_new_of_old is

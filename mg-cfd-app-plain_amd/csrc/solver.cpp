@@ -69,6 +69,8 @@ struct DeviceLevel {
     bool fluxes_zero = true;             // fluxes[] is logically zero (the flux launch need not read it)
     bool fluxes_stale = false;           // ... but its memory has not been zeroed (lazy zero after a fused time_step)
     bool sweep_flux0_done = false;       // mgcfd_sweep_flux0 ran since mgcfd_sweep_begin
+    int64_t n_owned = 0;                 // < nel on a partitioned level: original ids >= n_owned are ghosts
+    std::vector<std::pair<int32_t *, int64_t>> halo_plans;   // device id lists of the halo messages
     bool has_transfer = false;           // plan to the next-coarser level present
     int64_t iters[MGCFD_NUM_LOOPS] = {0};
     double times[MGCFD_NUM_LOOPS] = {0};
@@ -285,8 +287,8 @@ struct mgcfd_solver {
     void op_sumsq(int l)
     {
         DeviceLevel &lv = level(l);
-        if (opt_exact) exact::launch_sumsq(stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq);
-        else fast::launch_sumsq(stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq);
+        if (opt_exact) exact::launch_sumsq(stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
+        else fast::launch_sumsq(stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
     }
     void op_restrict(int fine)
     {
@@ -342,6 +344,7 @@ mgcfd_solver::~mgcfd_solver()
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.pro,
                         lv.dp.pro_parent, lv.dp.pro_wsum};
         for (void *p : ptrs) if (p) (void)hipFree(p);
+        for (auto &hp : lv.halo_plans) if (hp.first) (void)hipFree(hp.first);
     }
     if (err) (void)hipFree(err);
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -350,7 +353,8 @@ mgcfd_solver::~mgcfd_solver()
 // ------------------------------------------------------------------------------------------
 // construction
 // ------------------------------------------------------------------------------------------
-static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device)
+static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device,
+                                                  const int64_t *n_owned = nullptr)
 {
     if (!levels || nlevels <= 0) throw std::invalid_argument("no levels given");
     if (mesh_variant != MGCFD_MESH_FVCORR && mesh_variant != MGCFD_MESH_M6_WING &&
@@ -389,6 +393,13 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
             throw std::invalid_argument("edge class ranges exceed n_edges");
         lv.edges.assign(d.edges, d.edges + d.n_edges);
         adjust_and_dampen(d, mesh_variant, lv.edges);
+        lv.n_owned = d.nel;
+        popt.n_owned = -1;
+        if (n_owned && n_owned[l] >= 0 && n_owned[l] < d.nel) {
+            if (nlevels > 1) throw std::invalid_argument("partitioned (ghosted) levels are single-level for now: no multigrid transfer across partitions");
+            lv.n_owned = n_owned[l];
+            popt.n_owned = n_owned[l];
+        }
         build_level_plan(d, lv.edges, popt, lv.plan);
         if (std::getenv("MGCFD_VERBOSE"))
             std::fprintf(stderr, "[mgcfd] level %d: %ld nodes, %d tiles, halo mean %.0f max %d (cap %d), overflow refs %ld, ELL padding %.1f%%\n",
@@ -549,6 +560,12 @@ int mgcfd_create(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, 
 {
     REQUIRE(out);
     return guarded([&] { *out = build_solver(levels, nlevels, mesh_variant, device).release(); });
+}
+int mgcfd_create_partitioned(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device,
+                             const int64_t *n_owned, mgcfd_solver **out)
+{
+    REQUIRE(out); REQUIRE(n_owned);
+    return guarded([&] { *out = build_solver(levels, nlevels, mesh_variant, device, n_owned).release(); });
 }
 int mgcfd_create_from_mesh(const mgcfd_mesh *m, int device, mgcfd_solver **out)
 {
@@ -946,6 +963,42 @@ int mgcfd_get_edges(mgcfd_solver *s, int level, mgcfd_edge *out)
         std::memcpy(out, lv.edges.data(), lv.edges.size() * sizeof(mgcfd_edge));
     });
 }
+
+// ---- halo exchange of a partitioned level ----
+int mgcfd_halo_plan(mgcfd_solver *s, int level, int64_t n, const int64_t *node_ids, int *plan)
+{
+    REQUIRE(s); REQUIRE(plan);
+    if (n > 0) REQUIRE(node_ids);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        std::vector<int32_t> ids(static_cast<size_t>(n));
+        for (int64_t k = 0; k < n; k++) {
+            if (node_ids[k] < 0 || node_ids[k] >= lv.info.nel) throw std::invalid_argument("halo node id out of range");
+            ids[static_cast<size_t>(k)] = lv.plan.new_of_old[static_cast<size_t>(node_ids[k])];
+        }
+        lv.halo_plans.emplace_back(dev_upload(ids), n);
+        *plan = static_cast<int>(lv.halo_plans.size()) - 1;
+    });
+}
+static void halo_move(mgcfd_solver *s, int level, int plan, int which, void *dev_buf, bool pack)
+{
+    s->use_device();
+    DeviceLevel &lv = s->level(level);
+    if (plan < 0 || plan >= static_cast<int>(lv.halo_plans.size())) throw std::invalid_argument("unknown halo plan");
+    int nc = 0;
+    double *field = array_ptr(lv, which, &nc);
+    if (nc != 5) throw std::invalid_argument("halo messages carry 5-component node arrays");
+    if (which == MGCFD_ARR_FLUXES) { if (pack) s->settle_fluxes(lv); else { lv.fluxes_zero = false; lv.fluxes_stale = false; } }
+    const auto &hp = lv.halo_plans[static_cast<size_t>(plan)];
+    if (hp.second > 0 && !dev_buf) throw std::invalid_argument("null message buffer");
+    if (pack) exact::launch_halo_pack(s->stream, hp.second, lv.dp.stride, hp.first, field, static_cast<double *>(dev_buf));
+    else exact::launch_halo_unpack(s->stream, hp.second, lv.dp.stride, hp.first, static_cast<const double *>(dev_buf), field);
+}
+int mgcfd_halo_pack(mgcfd_solver *s, int level, int plan, int which, void *dev_buf)
+{ REQUIRE(s); return guarded([&] { halo_move(s, level, plan, which, dev_buf, true); }); }
+int mgcfd_halo_unpack(mgcfd_solver *s, int level, int plan, int which, const void *dev_buf)
+{ REQUIRE(s); return guarded([&] { halo_move(s, level, plan, which, const_cast<void *>(dev_buf), false); }); }
 
 // ---- monitoring ----
 int mgcfd_get_loop_iters(const mgcfd_solver *s, int level, int64_t out[MGCFD_NUM_LOOPS])

@@ -56,6 +56,10 @@ _SIGNATURES = [
     ("mgcfd_identify_differences", C.c_int, [_vp, _vp, _i64, C.c_int, C.POINTER(_i64)]),
     ("mgcfd_create", C.c_int, [C.POINTER(LevelDesc), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_create_from_mesh", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    ("mgcfd_create_partitioned", C.c_int, [C.POINTER(LevelDesc), C.c_int, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_vp)]),
+    ("mgcfd_halo_plan", C.c_int, [_vp, C.c_int, _i64, _vp, C.POINTER(C.c_int)]),
+    ("mgcfd_halo_pack", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+    ("mgcfd_halo_unpack", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     ("mgcfd_destroy", None, [_vp]),
     ("mgcfd_set_option", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mgcfd_get_option", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
@@ -198,7 +202,7 @@ class Solver:
         return cls(h, lib)
 
     @classmethod
-    def from_arrays(cls, levels: Sequence[dict], mesh_variant: int, device: int = 0) -> "Solver":
+    def from_arrays(cls, levels: Sequence[dict], mesh_variant: int, device: int = 0, n_owned=None) -> "Solver":
         """levels[l] = dict(nel, volumes, coords|None, edges[EDGE_DTYPE], n_internal, n_boundary, n_wall,
         mg_map|None) — the reference's read_grid()/read_mg_connectivity() outputs."""
         lib = load_library()
@@ -223,7 +227,11 @@ class Solver:
             d.mg_map = _ptr(mp) if mp is not None else None
             d.mgc = len(mp) if mp is not None else 0
         h = _vp()
-        _check(lib, lib.mgcfd_create(descs, len(levels), mesh_variant, device, C.byref(h)))
+        if n_owned is None:
+            _check(lib, lib.mgcfd_create(descs, len(levels), mesh_variant, device, C.byref(h)))
+        else:
+            owned = (_i64 * len(levels))(*[int(v) for v in n_owned])
+            _check(lib, lib.mgcfd_create_partitioned(descs, len(levels), mesh_variant, device, owned, C.byref(h)))
         return cls(h, lib)
 
     @classmethod
@@ -348,6 +356,19 @@ class Solver:
         t = C.c_double()
         self._c(self.lib.mgcfd_bench_flux(self.handle, l, launches, C.byref(t)))
         return t.value
+
+    # ---- halo exchange of a partitioned level ----
+    def halo_plan(self, l: int, node_ids) -> int:
+        ids = np.ascontiguousarray(node_ids, dtype=np.int64)
+        plan = C.c_int(-1)
+        self._c(self.lib.mgcfd_halo_plan(self.handle, l, len(ids), _ptr(ids) if len(ids) else None, C.byref(plan)))
+        return plan.value
+
+    def halo_pack(self, l: int, plan: int, name: str, dev_ptr: int):
+        self._c(self.lib.mgcfd_halo_pack(self.handle, l, plan, ARR[name], _vp(dev_ptr)))
+
+    def halo_unpack(self, l: int, plan: int, name: str, dev_ptr: int):
+        self._c(self.lib.mgcfd_halo_unpack(self.handle, l, plan, ARR[name], _vp(dev_ptr)))
 
     # ---- multi-GPU hooks ----
     def step_factor_local(self, l): self._c(self.lib.mgcfd_step_factor_local(self.handle, l))

@@ -1,0 +1,93 @@
+"""Partition one mesh level over ranks: owned nodes, ghost nodes, local edge lists, halo lists.
+
+Host-side preparation for the multi-GPU "within a level" mode (BASELINE config 5).
+Every rank owns a set of nodes and computes the fluxes of its own nodes only ("owner computes"):
+it therefore needs every edge with at least one owned end point and a read-only GHOST copy of the
+other end point when that belongs to another rank.  After each time_step the owners send the new
+variables of those nodes to the ranks that hold ghosts of them — one message per neighbouring pair
+per RK stage, 40 B per halo node.
+
+Local numbering: owned nodes first (ascending global id), then ghosts (ascending global id).
+Local edges keep the relative order they have in the global list inside each class, so every
+owned node's incident edges are summed in the reference's order and the partitioned run is
+bit-identical to the unpartitioned one.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import numpy as np
+
+from .meshgen import EDGE_DTYPE
+
+
+@dataclass
+class LevelPart:
+    rank: int
+    n_owned: int
+    global_ids: np.ndarray                 # [n_local] global id of every local node (owned first, then ghosts)
+    level: dict                            # read_grid()-shaped dict of the local part (for Solver.from_arrays)
+    send: Dict[int, np.ndarray] = field(default_factory=dict)   # peer -> LOCAL ids of owned nodes the peer holds as ghosts
+    recv: Dict[int, np.ndarray] = field(default_factory=dict)   # peer -> LOCAL ids of ghosts owned by the peer
+
+    @property
+    def n_local(self) -> int:
+        return len(self.global_ids)
+
+
+def slab_partition(coords: np.ndarray, n_parts: int, axis: int = 0) -> np.ndarray:
+    """Equal-count slabs along one coordinate axis (good enough for box-like meshes)."""
+    order = np.argsort(coords[:, axis], kind="stable")
+    part = np.empty(len(coords), dtype=np.int64)
+    part[order] = (np.arange(len(coords), dtype=np.int64) * n_parts) // len(coords)
+    return part
+
+
+def partition_level(level: dict, part: np.ndarray) -> List[LevelPart]:
+    """Split a read_grid()-shaped level dict (nel, volumes, coords, edges, n_internal, n_boundary,
+    n_wall) by the node->rank vector `part`."""
+    nel = int(level["nel"])
+    edges = level["edges"]
+    ni, nb, nw = int(level["n_internal"]), int(level["n_boundary"]), int(level["n_wall"])
+    ea, eb = edges["a"], edges["b"]
+    n_parts = int(part.max()) + 1
+    internal = np.arange(ni)
+    bnd = np.arange(ni, ni + nb)
+    wall = np.arange(ni + nb, ni + nb + nw)
+    owner_a = part[ea[internal]]
+    owner_b = part[eb[internal]]
+    parts: List[LevelPart] = []
+    for r in range(n_parts):
+        owned = np.flatnonzero(part == r)
+        keep_int = internal[(owner_a == r) | (owner_b == r)]            # global order preserved
+        keep_bnd = bnd[part[eb[bnd]] == r]
+        keep_wall = wall[part[eb[wall]] == r]
+        touched = np.union1d(ea[keep_int], eb[keep_int])
+        ghosts = np.setdiff1d(touched, owned)
+        gids = np.concatenate([owned, ghosts])
+        local_of_global = np.full(nel, -1, dtype=np.int64)
+        local_of_global[gids] = np.arange(len(gids))
+        keep = np.concatenate([keep_int, keep_bnd, keep_wall])
+        le = np.empty(len(keep), dtype=EDGE_DTYPE)
+        le[:] = edges[keep]
+        inner = np.arange(len(keep_int))
+        le["a"][inner] = local_of_global[ea[keep_int]]
+        le["b"] = local_of_global[eb[keep]]
+        coords = None if level.get("coords") is None else np.ascontiguousarray(level["coords"])[gids]
+        lvl = {"nel": len(gids), "volumes": np.ascontiguousarray(level["volumes"])[gids], "coords": coords,
+               "edges": le, "n_internal": len(keep_int), "n_boundary": len(keep_bnd), "n_wall": len(keep_wall),
+               "mg_map": None}
+        parts.append(LevelPart(rank=r, n_owned=len(owned), global_ids=gids, level=lvl))
+    # halo lists: ghosts of rank r owned by s, ascending global id on both sides
+    for r, P in enumerate(parts):
+        ghost_g = P.global_ids[P.n_owned:]
+        ghost_owner = part[ghost_g]
+        for s in np.unique(ghost_owner):
+            g = ghost_g[ghost_owner == s]
+            P.recv[int(s)] = (P.n_owned + np.flatnonzero(ghost_owner == s)).astype(np.int64)
+            Q = parts[int(s)]
+            local_in_s = np.searchsorted(Q.global_ids[:Q.n_owned], g)
+            assert np.array_equal(Q.global_ids[local_in_s], g)
+            Q.send[r] = local_in_s.astype(np.int64)
+    return parts

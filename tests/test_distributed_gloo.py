@@ -151,3 +151,132 @@ def test_two_ranks_equal_the_duplicated_mesh(tmp_path, oracle):
     # and the coupling is real: without the all-reduce the two copies would use different dt
     sf0, sf1 = np.load(tmp_path / "sf_0.npy"), np.load(tmp_path / "sf_1.npy")
     assert np.array_equal(sf0, sf1)
+
+
+# ------------------------------------------------------------------------------------------
+# Partitioned level + halo exchange over gloo point-to-point (BASELINE config 5 in miniature)
+# ------------------------------------------------------------------------------------------
+class OraclePartSolver:
+    """CPU stand-in (oracle-backed) for a partitioned mgcfd.api.Solver: one level, ghosts last."""
+
+    def __init__(self, oracle, level, q):
+        import ctypes as C
+        self.O, self.C = oracle, C
+        self.lib = oracle.load()
+        self.nel = level["nel"]
+        self.edges = np.ascontiguousarray(level["edges"]).copy()
+        self.coords = np.ascontiguousarray(level["coords"], dtype=np.float64)
+        self.lib.ora_adjust_ewt(oracle.ptr(self.coords), len(self.edges), oracle.ptr(self.edges))
+        self.lib.ora_dampen_ewt(len(self.edges), oracle.ptr(self.edges), 5e-8)
+        self.ni, self.nb, self.nw = level["n_internal"], level["n_boundary"], level["n_wall"]
+        self.vol = np.ascontiguousarray(level["volumes"], dtype=np.float64)
+        self.ff = oracle.farfield()
+        self.v = np.ascontiguousarray(q, dtype=np.float64).copy()
+        self.old, self.f, self.res = np.zeros_like(self.v), np.zeros_like(self.v), np.zeros_like(self.v)
+        self.sf = np.zeros(self.nel)
+        self._min = torch.zeros(1, dtype=torch.float64)
+        self.plans = []
+
+    def copy_old_variables(self, l):
+        self.old[:] = self.v
+
+    def step_factor_local(self, l):
+        q = self.v
+        vel = q[:, 1:4] / q[:, :1]
+        sp2 = (vel[:, 0] * vel[:, 0] + vel[:, 1] * vel[:, 1]) + vel[:, 2] * vel[:, 2]
+        p = (1.4 - 1.0) * (q[:, 4] - 0.5 * q[:, 0] * sp2)
+        self._min[0] = float((0.5 * (np.cbrt(self.vol) / (np.sqrt(sp2) + np.sqrt(1.4 * p / q[:, 0])))).min())
+
+    def min_tensor(self, l):
+        return self._min
+
+    def step_factor_apply(self, l):
+        self.sf[:] = float(self._min[0]) / self.vol
+
+    def compute_fluxes(self, l):
+        O, lib = self.O, self.lib
+        lib.ora_compute_flux_edge(0, self.ni, O.ptr(self.edges), O.ptr(self.v), O.ptr(self.f))
+        lib.ora_compute_boundary_flux_edge(self.ni, self.nb, O.ptr(self.edges), O.ptr(self.v), O.ptr(self.f))
+        lib.ora_compute_wall_flux_edge(self.ni + self.nb, self.nw, O.ptr(self.edges), O.ptr(self.v), O.ptr(self.f), self.C.byref(self.ff))
+
+    def time_step(self, l, j):
+        O = self.O
+        self.lib.ora_time_step(j, self.nel, O.ptr(self.sf), O.ptr(self.f), O.ptr(self.old), O.ptr(self.v))
+
+    def residual(self, l):
+        self.res[:] = self.v - self.old
+
+    def halo_plan(self, l, ids):
+        self.plans.append(np.asarray(ids, dtype=np.int64))
+        return len(self.plans) - 1
+
+    @staticmethod
+    def _view(ptr, n):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_double * n).from_address(ptr))
+
+    def halo_pack(self, l, plan, name, ptr):
+        ids = self.plans[plan]
+        if len(ids):
+            self._view(ptr, len(ids) * 5)[:] = self.v[ids].ravel()
+
+    def halo_unpack(self, l, plan, name, ptr):
+        ids = self.plans[plan]
+        if len(ids):
+            self.v[ids] = self._view(ptr, len(ids) * 5).reshape(-1, 5)
+
+
+def _part_worker(rank, world, port, sweeps, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    import mgcfd
+    from mgcfd import meshgen
+    from mgcfd.distributed import PartitionedSweep
+    from mgcfd.partition import partition_level, slab_partition
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mg = meshgen.make_multigrid((10,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    L = mgcfd.generated_to_levels(mg)[0]
+    P = partition_level(L, slab_partition(np.asarray(L["coords"]), world))[rank]
+    ff = oracle_py.farfield()
+    rng = np.random.default_rng(9)
+    q0 = np.tile(np.array(ff.var), (L["nel"], 1)) * (1 + 0.02 * rng.uniform(-1, 1, (L["nel"], 5)))
+    solver = OraclePartSolver(oracle_py, P.level, q0[P.global_ids])
+    sw = PartitionedSweep(solver, P, dist, make_buffer=lambda n: torch.zeros(n, dtype=torch.float64))
+    for _ in range(sweeps):
+        sw.sweep()
+    np.save(os.path.join(out_dir, f"part_vars_{rank}.npy"), solver.v[:P.n_owned])
+    np.save(os.path.join(out_dir, f"part_ids_{rank}.npy"), P.global_ids[:P.n_owned])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_partitioned_level_over_gloo_equals_whole_mesh(tmp_path, oracle):
+    import ctypes as C
+    import mgcfd
+    from mgcfd import meshgen
+    world, sweeps = 2, 2
+    mp.spawn(_part_worker, args=(world, _free_port(), sweeps, str(tmp_path)), nprocs=world, join=True)
+    mg = meshgen.make_multigrid((10,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    L = mgcfd.generated_to_levels(mg)[0]
+    ff = oracle.farfield()
+    rng = np.random.default_rng(9)
+    q0 = np.tile(np.array(ff.var), (L["nel"], 1)) * (1 + 0.02 * rng.uniform(-1, 1, (L["nel"], 5)))
+    whole = OraclePartSolver(oracle, L, q0)
+    for _ in range(sweeps):
+        whole.copy_old_variables(0)
+        whole.step_factor_local(0)
+        whole.step_factor_apply(0)
+        for j in range(3):
+            whole.compute_fluxes(0)
+            whole.time_step(0, j)
+        whole.residual(0)
+    seen = 0
+    for r in range(world):
+        ids = np.load(tmp_path / f"part_ids_{r}.npy")
+        got = np.load(tmp_path / f"part_vars_{r}.npy")
+        assert np.array_equal(got.view(np.int64), whole.v[ids].view(np.int64))     # same order of sums => same bits
+        seen += len(ids)
+    assert seen == L["nel"]

@@ -388,6 +388,86 @@ def test_ragged_tiles_overflow_the_lds_halo(oracle, exact):
     s.close()
 
 
+def test_partitioned_level_with_halo_exchange_equals_whole_mesh():
+    """BASELINE config 5 in miniature: one level split into 3 parts with ghost nodes, every RK stage
+    followed by a halo exchange (packed / unpacked on the GPU), global-min time step over all parts.
+    The three parts run as three solvers on this one GPU, threads standing in for ranks and an
+    in-process copy for the RCCL send/recv; owned nodes must equal the unpartitioned run bit for bit."""
+    import threading
+    import torch
+    import mgcfd
+    from mgcfd import meshgen
+    from mgcfd.distributed import HipSolverAdapter, PartitionedSweep
+    from mgcfd.partition import partition_level, slab_partition
+    dev = torch.device("cuda", 0)
+    mg = meshgen.make_multigrid((14,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    L = mgcfd.generated_to_levels(mg)[0]
+    n_parts, sweeps = 3, 3
+    parts = partition_level(L, slab_partition(np.asarray(L["coords"]), n_parts))
+    assert sum(p.n_owned for p in parts) == L["nel"] and all(p.send and p.recv for p in parts)
+
+    whole = mgcfd.Solver.from_arrays([L], mg.mesh_variant)
+    q0 = perturbed_state(L["nel"], whole.far_field()[:5], seed=9)
+    whole.set(0, "variables", q0)
+    whole.set_option("fuse_update", 0)
+    whole.smooth(0, sweeps)
+    want_v, want_res, want_rms = whole.get(0, "variables"), whole.get(0, "residuals"), whole.calc_rms(0)
+    whole.close()
+
+    stream = torch.cuda.current_stream().cuda_stream
+    solvers, sweepers = [], []
+    barrier = threading.Barrier(n_parts)
+
+    def exchange(sw):
+        barrier.wait()                                   # every part has enqueued its packs
+        for peer, buf in sw.buf_recv.items():
+            buf.copy_(sweepers[peer].buf_send[sw.part.rank])
+        barrier.wait()                                   # nobody repacks before all copies are enqueued
+
+    def allreduce_min(sw):
+        barrier.wait()
+        if sw.part.rank == 0:
+            m = torch.stack([x.s.min_tensor(0) for x in sweepers]).min()
+            for x in sweepers:
+                x.s.min_tensor(0).fill_(m)
+        barrier.wait()
+
+    for P in parts:
+        s = mgcfd.Solver.from_arrays([P.level], mg.mesh_variant, n_owned=[P.n_owned])
+        s.set_stream(stream)
+        s.set(0, "variables", q0[P.global_ids])          # ghosts start current
+        solvers.append(s)
+        sweepers.append(PartitionedSweep(HipSolverAdapter(s, dev), P, None, exchange=exchange, allreduce_min=allreduce_min,
+                                         make_buffer=lambda n: torch.empty(n, dtype=torch.float64, device=dev)))
+    errors = []
+
+    def run(sw):
+        try:
+            torch.cuda.set_device(0)
+            for _ in range(sweeps):
+                sw.sweep()
+        except Exception as e:                           # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(sw,)) for sw in sweepers]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    sumsq = 0.0
+    for P, s in zip(parts, solvers):
+        own = P.global_ids[:P.n_owned]
+        assert np.array_equal(s.get(0, "variables")[:P.n_owned].view(np.int64), want_v[own].view(np.int64))
+        assert np.array_equal(s.get(0, "residuals")[:P.n_owned].view(np.int64), want_res[own].view(np.int64))
+        # ghosts hold the owners' values after the last exchange
+        assert np.array_equal(s.get(0, "variables")[P.n_owned:].view(np.int64), want_v[P.global_ids[P.n_owned:]].view(np.int64))
+        sumsq += s.calc_rms(0) ** 2 * s.nel(0)          # library RMS counts owned nodes only, over nel_local
+        s.close()
+    assert abs(np.sqrt(sumsq / L["nel"]) - want_rms) <= 1e-12 * want_rms
+
+
 def test_min_scalar_aliases_device_memory(mesh3_dir):
     """The all-reduce acts on a torch tensor that must alias the library's device scalar."""
     import torch

@@ -98,6 +98,30 @@ def cpu_baseline(levels, sample_seconds: float):
             "sample": f"{passes} passes of compute_flux_edge over the same {n_int}-edge level ({dt:.1f} s), {how}"}
 
 
+def vcycle_wall(fast: bool, cycles: int = 25):
+    """Second half of BASELINE.json's metric: wall seconds per MG V-cycle on the 4-level M6-like hierarchy
+    (67^3/55^3/48^3/43^3 lattices = 300,763/166,375/110,592/79,507 nodes, nearest-node maps,
+    mesh_name = m6wing), 25 cycles as the reference's default (src/Base/config.cpp:63), best of 3."""
+    import mgcfd
+    from mgcfd import meshgen
+    mg = meshgen.make_multigrid((67, 55, 48, 43), "m6wing", seed=0, jitter=0.2, area_noise=0.02, volume_noise=0.02)
+    s = mgcfd.Solver.from_arrays(mgcfd.generated_to_levels(mg), mg.mesh_variant)
+    s.set_option("exact", 0 if fast else 1)
+    s.run_cycles(2)
+    best = float("inf")
+    for _ in range(3):
+        s.reset_monitoring()
+        t0 = time.perf_counter()
+        rms = s.run_cycles(cycles)
+        best = min(best, time.perf_counter() - t0)
+    edge_iters = sum(s.loop_iters(l)["flux"] for l in range(s.num_levels)) // cycles
+    out = {"workload": f"4-level M6-like synthetic hierarchy {[l.nel for l in mg.levels]} nodes, {cycles} cycles",
+           "wall_s_per_cycle": round(best / cycles, 9), "flux_edge_iterations_per_cycle": edge_iters,
+           "medges_per_s_whole_cycle": round(edge_iters * cycles / best / 1e6, 1), "rms_last": float(rms[-1])}
+    s.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +130,7 @@ def main():
     ap.add_argument("--lattice", type=int, default=LATTICE, help="nodes per side of the synthetic M6-L0-like level")
     ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
     ap.add_argument("--variant", type=int, default=0, help="MGCFD_OPT_FLUX_VARIANT (0 stream k, 1 recompute k)")
+    ap.add_argument("--no-vcycle", action="store_true", help="skip the 4-level V-cycle wall-time measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (0 disables)")
     args = ap.parse_args()
 
@@ -229,6 +254,8 @@ def main():
                                                "frac": round(achieved_flux_only / HBM_PEAK_GBS, 4),
                                                "medges_per_s": round(n_int / flux_only / 1e6, 1) if flux_only > 0 else None}},
         }
+        if world == 1 and not args.no_vcycle:
+            out["vcycle"] = vcycle_wall(args.fast)
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(levels, args.cpu_seconds)
         print(json.dumps(out))

@@ -256,6 +256,44 @@ def test_driver_reproduces_reference_binary(case, mode, tmp_path):
         assert float(t["flux0"]) > 0 and float(t["time_step0"]) > 0 and float(t["compute_step0"]) > 0
 
 
+def test_driver_validate_result_and_config_file(tmp_path):
+    """-v against a solution.* file (src/euler3d_cpu_double.cpp:704-744, tolerance rule of
+    validation.cpp:140-199) and the -c key=value config file (src/Base/config.cpp:159-217)."""
+    import shutil
+    d, cycles, dup = _case("m6_2lvl")
+    work = tmp_path / "in"
+    shutil.copytree(os.path.join(d, "input"), work)
+    sol = work / f"solution.variables.size={dup}x.cycles={cycles}.level=0"
+    shutil.copy(os.path.join(d, "variables.level0.txt"), sol)
+    exe = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
+    out = tmp_path / "out"
+    out.mkdir()
+    base = [exe, "-i", "input.dat", "-d", str(work), "-o", str(out) + "/", "-g", str(cycles), "-v"]
+    r = subprocess.run(base, capture_output=True, text=True)
+    assert r.returncode == 0 and "NaN check passed" in r.stdout and "PASS: variables[] validated successfully" in r.stdout
+    # FMA-contracted kernels still validate (differences ~1e-22 against a floor of 3e-19)
+    r = subprocess.run(base + ["--fast", "--no-timers"], capture_output=True, text=True)
+    assert r.returncode == 0 and "PASS: variables[] validated successfully" in r.stdout
+    # a wrong solution file must fail the run, as the reference's exit(EXIT_FAILURE) does
+    vals = np.loadtxt(sol)
+    vals[5, 2] += 1e-9
+    np.savetxt(sol, vals, fmt="%.17e")
+    r = subprocess.run(base, capture_output=True, text=True)
+    assert r.returncode != 0 and "ERROR: Unacceptable error detected at (i=5, v=2)" in r.stdout
+    # missing solution file: message, no PASS line, exit code 0 (euler3d_cpu_double.cpp:718-725)
+    os.remove(sol)
+    r = subprocess.run(base, capture_output=True, text=True)
+    assert r.returncode == 0 and "aborting validation" in r.stdout and "PASS" not in r.stdout
+    # -c: the same run described by a config file placed next to the inputs
+    (work / "run.conf").write_text(f"# config\ninput_file = input.dat\ninput_file_directory = ./\ncycles = {cycles}\n"
+                                   f"output_file_prefix = {out}/cfg\noutput_variables = Y\nmesh_duplicate_count = 1\n")
+    r = subprocess.run([exe, "-c", str(work / "run.conf")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    dump = out / f"cfg.variables.size=1x.cycles={cycles}.level=0"           # prefix without '/' => '<prefix>.<name>'
+    assert dump.read_bytes() == open(os.path.join(d, "variables.level0.txt"), "rb").read()
+    assert (out / "cfg.Times.csv").exists() and (out / "cfg.LoopNumIters.csv").exists()
+
+
 @pytest.mark.parametrize("case", GOLDEN_CASES)
 def test_kernels_reproduce_reference_vectors(case):
     import mgcfd

@@ -188,6 +188,44 @@ def test_fvcorr_single_level(oracle, fvcorr_dir, exact, fuse):
     _run_both(mgcfd, oracle, fvcorr_dir, 50, exact, fuse=fuse)
 
 
+def test_fvcorr_like_97k_nodes_developed_flow(oracle):
+    """BASELINE configs[0] in its synthetic form: mesh_name = fvcorr, single level,
+    46^3 box minus its centre node = 97,335 nodes, far-field outer faces + 6 solid-wall faces, permuted ids,
+    undamped edge weights, Rodinia's local time step.  300 iterations (the flow develops: the RMS falls by
+    an order of magnitude) against the oracle, bit for bit, then the reference's own -v tolerance rule."""
+    import mgcfd
+    from mgcfd import meshgen
+    mg = meshgen.make_multigrid((46,), "fvcorr", seed=0, cavity_radius=0.001)
+    assert mg.levels[0].nel == 46 ** 3 - 1
+    levels = mgcfd.generated_to_levels(mg)
+    assert levels[0]["n_boundary"] == 6
+    iters = 300
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    rms = s.run_cycles(iters)
+    got = s.get(0, "variables")
+    assert s.loop_iters(0)["flux"] == 3 * iters * levels[0]["n_internal"]
+    s.close()
+    # oracle on the same arrays
+    lib = oracle.load()
+    L = levels[0]
+    lv = (oracle.OraLevel * 1)()
+    keep = [np.ascontiguousarray(L["volumes"], dtype=np.float64), np.ascontiguousarray(L["coords"], dtype=np.float64),
+            np.ascontiguousarray(L["edges"]).copy()]
+    state = [np.zeros((L["nel"], 5)) for _ in range(4)] + [np.zeros(L["nel"])]
+    lv[0].nel, lv[0].n_edges = L["nel"], len(keep[2])
+    lv[0].n_internal, lv[0].n_boundary, lv[0].n_wall = L["n_internal"], L["n_boundary"], L["n_wall"]
+    lv[0].internal_start, lv[0].boundary_start, lv[0].wall_start = 0, L["n_internal"], L["n_internal"] + L["n_boundary"]
+    lv[0].volumes, lv[0].coords, lv[0].edges = oracle.ptr(keep[0]), oracle.ptr(keep[1]), oracle.ptr(keep[2])
+    lv[0].variables, lv[0].old_variables, lv[0].residuals, lv[0].fluxes = (oracle.ptr(a) for a in state[:4])
+    lv[0].step_factors = oracle.ptr(state[4])
+    want_rms = np.zeros(iters)
+    assert lib.ora_solve(lv, 1, 0, iters, 0, oracle.ptr(want_rms), None) == 0
+    _assert_close(got, state[0], True, "fvcorr-like 97K nodes, 300 iterations")
+    assert np.allclose(rms, want_rms, rtol=1e-12, atol=0)
+    assert rms[-1] < 0.2 * rms[0] and np.ptp(got[:, 0]) > 0.05          # a developed, converging flow
+    assert lib.ora_identify_differences(oracle.ptr(np.ascontiguousarray(got)), oracle.ptr(state[0]), L["nel"], 0) == -1
+
+
 def test_invalid_state_is_reported(setup, oracle):
     mgcfd, mesh, solver, case, lib = setup
     ff = oracle.farfield()

@@ -98,6 +98,10 @@ int mgcfd_abi_version(void);
  * src/Base/io_enhanced.cpp:407-579, src/Base/io.cpp:14-199, io_enhanced.cpp:629-650, :89-201.
  * `directory` may be NULL/"" (paths then relative to the cwd, as with no -d). */
 int mgcfd_mesh_load(const char *input_dat, const char *directory, int duplicate, mgcfd_mesh **out);
+/* The same with flags: MGCFD_MESH_LEGACY_ORDERING sorts every edge class by (a, b, x, y, z) as the
+ * reference's -DLEGACY_ORDERING build does (src/Base/io.cpp:183-193, src/Base/common.h:145-157). */
+#define MGCFD_MESH_LEGACY_ORDERING 1
+int mgcfd_mesh_load_ex(const char *input_dat, const char *directory, int duplicate, int flags, mgcfd_mesh **out);
 void mgcfd_mesh_free(mgcfd_mesh *m);
 int mgcfd_mesh_num_levels(const mgcfd_mesh *m);
 int mgcfd_mesh_variant(const mgcfd_mesh *m);

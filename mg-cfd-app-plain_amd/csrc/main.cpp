@@ -34,6 +34,7 @@ struct Config {                       // the reference's `config` (src/Base/conf
     bool timers = true;               // --no-timers: fused, graph-replayed fast path; Times.csv holds only Total
     bool fast_math = false;           // --fast: allow FMA contraction (MGCFD_OPT_EXACT = 0)
     bool indirect_rw = true;          // the reference runs the probe every RK stage; --no-indirect-rw skips it
+    bool legacy_ordering = false;     // --legacy-ordering: the reference's -DLEGACY_ORDERING edge sort (a compile-time flag there)
     int device = 0;
 };
 
@@ -112,7 +113,8 @@ void print_help()
         "  --device=INT                     GPU to run on (default 0)\n"
         "  --no-timers                      Fused, graph-replayed kernels; no per-loop times\n"
         "  --no-indirect-rw                 Skip the indirect_rw bandwidth probe each RK stage\n"
-        "  --fast                           Allow FMA contraction (results within 1e-12 relative)\n");
+        "  --fast                           Allow FMA contraction (results within 1e-12 relative)\n"
+        "  --legacy-ordering                Sort edges by (a,b,x,y,z) like the reference built with -DLEGACY_ORDERING\n");
 }
 
 bool parse_arguments(int argc, char **argv, Config &c)
@@ -137,6 +139,7 @@ bool parse_arguments(int argc, char **argv, Config &c)
         {"no-timers", no_argument, nullptr, 1005},
         {"no-indirect-rw", no_argument, nullptr, 1006},
         {"fast", no_argument, nullptr, 1007},
+        {"legacy-ordering", no_argument, nullptr, 1008},
         {nullptr, 0, nullptr, 0}};
     int optc;
     while ((optc = getopt_long(argc, argv, "hc:i:d:p:o:m:g:v", long_opts, nullptr)) != -1) {
@@ -157,6 +160,7 @@ bool parse_arguments(int argc, char **argv, Config &c)
             case 1005: c.timers = false; break;
             case 1006: c.indirect_rw = false; break;
             case 1007: c.fast_math = true; break;
+            case 1008: c.legacy_ordering = true; break;
             default: std::printf("Unknown command line parameter '%c'\n", optc);
         }
     }
@@ -265,7 +269,8 @@ int main(int argc, char **argv)
     }
 
     mgcfd_mesh *mesh = nullptr;
-    if (mgcfd_mesh_load(conf.input_file.c_str(), conf.input_file_directory.c_str(), conf.mesh_duplicate_count, &mesh) != MGCFD_OK)
+    if (mgcfd_mesh_load_ex(conf.input_file.c_str(), conf.input_file_directory.c_str(), conf.mesh_duplicate_count,
+                           conf.legacy_ordering ? MGCFD_MESH_LEGACY_ORDERING : 0, &mesh) != MGCFD_OK)
         return fail("reading input");
     const int levels = mgcfd_mesh_num_levels(mesh);
     const int mesh_variant = mgcfd_mesh_variant(mesh);

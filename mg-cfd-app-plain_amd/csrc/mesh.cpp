@@ -8,6 +8,7 @@
 //   * "%.17e" dumps                               src/Base/io.cpp:201-233
 #include "mesh.hpp"
 
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -268,7 +269,21 @@ void duplicate_level(HostLevel &L, int m, int64_t nel_above)
     L.boundary_start *= m; L.wall_start *= m;
 }
 
-HostMesh load_mesh(const std::string &input_dat, const std::string &directory, int duplicate)
+void sort_edges_legacy(HostLevel &L)
+{
+    auto before = [](const mgcfd_edge &p, const mgcfd_edge &q) {
+        if (p.a != q.a) return p.a < q.a;
+        if (p.b != q.b) return p.b < q.b;
+        if (p.x != q.x) return p.x < q.x;
+        if (p.y != q.y) return p.y < q.y;
+        return p.z < q.z;
+    };
+    std::sort(L.edges.begin() + L.internal_start, L.edges.begin() + L.internal_start + L.n_internal, before);
+    std::sort(L.edges.begin() + L.boundary_start, L.edges.begin() + L.boundary_start + L.n_boundary, before);
+    std::sort(L.edges.begin() + L.wall_start, L.edges.begin() + L.wall_start + L.n_wall, before);
+}
+
+HostMesh load_mesh(const std::string &input_dat, const std::string &directory, int duplicate, bool legacy_ordering)
 {
     auto join = [&](const std::string &p) { return directory.empty() ? p : directory + "/" + p; };
     const InputDat in = parse_input_dat(join(input_dat));
@@ -292,6 +307,7 @@ HostMesh load_mesh(const std::string &input_dat, const std::string &directory, i
             }
         }
         M.levels.push_back(read_mesh_level(join(in.level_files[static_cast<size_t>(l)]), in.mesh_variant, want));
+        if (legacy_ordering) sort_edges_legacy(M.levels.back());
         if (l < in.num_levels - 1) M.levels.back().mg_map = read_mg_map(join(in.map_files[static_cast<size_t>(l)]));
     }
     if (duplicate > 1) {

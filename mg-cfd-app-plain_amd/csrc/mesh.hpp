@@ -43,7 +43,10 @@ InputDat parse_input_dat(const std::string &path);
 HostLevel read_mesh_level(const std::string &path, int mesh_variant, bool read_coords);
 std::vector<int64_t> read_mg_map(const std::string &path);
 void duplicate_level(HostLevel &lvl, int copies, int64_t nel_above);
-HostMesh load_mesh(const std::string &input_dat, const std::string &directory, int duplicate);
+// legacy_ordering: sort every edge class by (a, b, x, y, z) as the reference's -DLEGACY_ORDERING build
+// does at the end of read_grid (src/Base/io.cpp:183-193, comparator src/Base/common.h:145-157).
+void sort_edges_legacy(HostLevel &lvl);
+HostMesh load_mesh(const std::string &input_dat, const std::string &directory, int duplicate, bool legacy_ordering = false);
 
 void write_array(const std::string &path, const double *data, int64_t nel, int ncols);
 std::vector<double> read_array(const std::string &path, int64_t nel, int ncols);

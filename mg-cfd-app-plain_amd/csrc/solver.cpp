@@ -530,6 +530,15 @@ int mgcfd_mesh_load(const char *input_dat, const char *directory, int duplicate,
         *out = m.release();
     });
 }
+int mgcfd_mesh_load_ex(const char *input_dat, const char *directory, int duplicate, int flags, mgcfd_mesh **out)
+{
+    REQUIRE(input_dat); REQUIRE(out);
+    return guarded([&] {
+        auto m = std::make_unique<mgcfd_mesh>();
+        m->mesh = load_mesh(input_dat, directory ? directory : "", duplicate, (flags & MGCFD_MESH_LEGACY_ORDERING) != 0);
+        *out = m.release();
+    });
+}
 void mgcfd_mesh_free(mgcfd_mesh *m) { delete m; }
 int mgcfd_mesh_num_levels(const mgcfd_mesh *m) { return m ? static_cast<int>(m->mesh.levels.size()) : 0; }
 int mgcfd_mesh_variant(const mgcfd_mesh *m) { return m ? m->mesh.mesh_variant : -1; }

@@ -47,6 +47,7 @@ _SIGNATURES = [
     ("mgcfd_last_error", C.c_char_p, []),
     ("mgcfd_abi_version", C.c_int, []),
     ("mgcfd_mesh_load", C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    ("mgcfd_mesh_load_ex", C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_mesh_free", None, [_vp]),
     ("mgcfd_mesh_num_levels", C.c_int, [_vp]),
     ("mgcfd_mesh_variant", C.c_int, [_vp]),
@@ -138,10 +139,11 @@ def _ptr(a: np.ndarray):
 class Mesh:
     """Multigrid input parsed by the library's own readers (the reference's file formats)."""
 
-    def __init__(self, input_dat: str, directory: str = "", duplicate: int = 1):
+    def __init__(self, input_dat: str, directory: str = "", duplicate: int = 1, legacy_ordering: bool = False):
         self.lib = load_library()
         h = _vp()
-        _check(self.lib, self.lib.mgcfd_mesh_load(input_dat.encode(), directory.encode(), duplicate, C.byref(h)))
+        _check(self.lib, self.lib.mgcfd_mesh_load_ex(input_dat.encode(), directory.encode(), duplicate,
+                                                      1 if legacy_ordering else 0, C.byref(h)))
         self.handle = h
 
     @property

@@ -25,6 +25,8 @@ LIBSRC="$SRC/Base/common.cpp $SRC/Base/config.cpp $SRC/Base/io.cpp $SRC/Base/io_
         $SRC/Monitoring/timer.cpp $SRC/Monitoring/papi_funcs.cpp $SRC/Monitoring/loop_stats.cpp"
 # 1) whole binary (timers on, as `make` would with -DTIME)
 g++ $FLAGS -DTIME $INC $SRC/euler3d_cpu_double.cpp $LIBSRC -o "$OUT/euler3d_cpu_double_ref.b"
+# 1b) the same built with -DLEGACY_ORDERING (edges sorted by (a,b,x,y,z), Makefile:20, src/Base/io.cpp:183-193)
+g++ $FLAGS -DTIME -DLEGACY_ORDERING $INC $SRC/euler3d_cpu_double.cpp $LIBSRC -o "$OUT/euler3d_cpu_double_ref_legacy_ordering.b"
 # 2) per-kernel harness: reference kernels behind a C ABI (our glue: ref_harness.cpp)
 g++ $FLAGS -fPIC -shared $INC "$HERE/ref_harness.cpp" $LIBSRC -o "$OUT/libmgcfd_ref.so"
 echo "built $OUT/euler3d_cpu_double_ref.b and $OUT/libmgcfd_ref.so"

@@ -473,6 +473,25 @@ int ora_read_grid(const char *path, int mesh_variant, int read_coords, ora_level
     return 0;
 }
 
+static int edge_before(const void *pp, const void *qq)
+{
+    /* compare_two_edges, src/Base/common.h:145-157, as a three-way comparison for qsort */
+    const ora_edge *p = (const ora_edge *)pp, *q = (const ora_edge *)qq;
+    if (p->a != q->a) return p->a < q->a ? -1 : 1;
+    if (p->b != q->b) return p->b < q->b ? -1 : 1;
+    if (p->x != q->x) return p->x < q->x ? -1 : 1;
+    if (p->y != q->y) return p->y < q->y ? -1 : 1;
+    if (p->z != q->z) return p->z < q->z ? -1 : 1;
+    return 0;
+}
+
+void ora_sort_edges_legacy(ora_level *L)
+{
+    qsort(L->edges + L->internal_start, (size_t)L->n_internal, sizeof(ora_edge), edge_before);
+    qsort(L->edges + L->boundary_start, (size_t)L->n_boundary, sizeof(ora_edge), edge_before);
+    qsort(L->edges + L->wall_start, (size_t)L->n_wall, sizeof(ora_edge), edge_before);
+}
+
 int ora_read_mg_connectivity(const char *path, int64_t **map, int64_t *mgc)
 {
     FILE *f = fopen(path, "r");

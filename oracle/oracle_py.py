@@ -89,6 +89,7 @@ def load(native: bool = False) -> C.CDLL:
     lib.ora_read_grid.restype = i32
     lib.ora_read_mg_connectivity.argtypes = [C.c_char_p, C.POINTER(_vp), _lp]
     lib.ora_read_mg_connectivity.restype = i32
+    lib.ora_sort_edges_legacy.argtypes = [C.POINTER(OraLevel)]
     lib.ora_duplicate_mesh.argtypes = [C.POINTER(OraLevel), i32, i64]
     lib.ora_alloc_state.argtypes = [C.POINTER(OraLevel)]
     lib.ora_free_level.argtypes = [C.POINTER(OraLevel)]
@@ -122,7 +123,7 @@ class OracleCase:
         self.nlevels = 0
 
     @classmethod
-    def from_files(cls, level_paths, map_paths, mesh_variant: int, duplicate: int = 1) -> "OracleCase":
+    def from_files(cls, level_paths, map_paths, mesh_variant: int, duplicate: int = 1, legacy_ordering: bool = False) -> "OracleCase":
         self = cls(mesh_variant)
         n = len(level_paths)
         self.nlevels = n
@@ -132,6 +133,8 @@ class OracleCase:
                                         C.byref(self.levels[l]))
             if rc:
                 raise RuntimeError(f"ora_read_grid({p}) failed rc={rc}")
+            if legacy_ordering:
+                self.lib.ora_sort_edges_legacy(C.byref(self.levels[l]))
             if l < n - 1:
                 m = _vp()
                 mgc = C.c_int64()
@@ -149,12 +152,12 @@ class OracleCase:
         return self
 
     @classmethod
-    def from_input_dat(cls, dat_path: str, duplicate: int = 1) -> "OracleCase":
+    def from_input_dat(cls, dat_path: str, duplicate: int = 1, legacy_ordering: bool = False) -> "OracleCase":
         info = parse_input_dat(dat_path)
         d = os.path.dirname(dat_path)
         return cls.from_files([os.path.join(d, p) for p in info["levels"]],
                               [os.path.join(d, p) for p in info["mg_mapping"]],
-                              info["mesh_variant"], duplicate)
+                              info["mesh_variant"], duplicate, legacy_ordering)
 
     # -- array views (owned by the C side) --
     def edges(self, l):
@@ -227,6 +230,7 @@ def parse_input_dat(path: str) -> dict:
 REF_DIR = os.path.join(HERE, "_ref")
 REF_LIB = os.path.join(REF_DIR, "libmgcfd_ref.so")
 REF_BIN = os.path.join(REF_DIR, "euler3d_cpu_double_ref.b")
+REF_BIN_LEGACY = os.path.join(REF_DIR, "euler3d_cpu_double_ref_legacy_ordering.b")
 
 
 def have_reference() -> bool:

@@ -37,6 +37,8 @@ CASES = {
     "m6_3lvl": ((9, 6, 4), "m6wing", dict(seed=11, cavity_radius=0.15, jitter=0.25, area_noise=0.08, volume_noise=0.1), 2, 1),
     "m6_2lvl_dup2": ((7, 4), "m6wing", dict(seed=5, cavity_radius=0.2, jitter=0.1, area_noise=0.03, volume_noise=0.02), 2, 2),
     "fvcorr_1lvl": ((8,), "fvcorr", dict(seed=7, cavity_radius=0.01, volume_noise=0.02), 20, 1),
+    # run with the reference built with -DLEGACY_ORDERING (only the binary's outputs; undamped, so the order matters)
+    "fvcorr_1lvl_legacy_ordering": ((8,), "fvcorr", dict(seed=8, cavity_radius=0.01, volume_noise=0.02), 30, 1),
 }
 
 
@@ -143,7 +145,8 @@ def main():
         meshgen.write_input(mg, os.path.join(d, "input"))
         out_dir = os.path.join(d, "_out")
         os.makedirs(out_dir)
-        cmd = [O.REF_BIN, "-i", "input.dat", "-d", os.path.join(d, "input"), "-o", out_dir + "/", "-g", str(cycles),
+        legacy = name.endswith("legacy_ordering")
+        cmd = [O.REF_BIN_LEGACY if legacy else O.REF_BIN, "-i", "input.dat", "-d", os.path.join(d, "input"), "-o", out_dir + "/", "-g", str(cycles),
                "-m", str(dup), "--output-variables"]
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, check=True)
         shutil.copy(os.path.join(out_dir, f"variables.size={dup}x.cycles={cycles}.level=0"), os.path.join(d, "variables.level0.txt"))
@@ -152,10 +155,13 @@ def main():
             f.write("\n".join(l for l in r.stdout.splitlines() if "cycle" in l.lower()) + "\n")
         with open(os.path.join(d, "case.txt"), "w") as f:
             f.write(f"cycles = {cycles}\nduplicate = {dup}\nmesh_name = {mesh_name}\n")
+            if name.endswith("legacy_ordering"):
+                f.write("legacy_ordering = 1\n")
         shutil.rmtree(out_dir)
-        info = O.parse_input_dat(os.path.join(d, "input", "input.dat"))
-        vec = kernel_vectors(ref, d, info, info["mesh_variant"])
-        np.savez_compressed(os.path.join(d, "kernels.npz"), **vec)
+        if not legacy:
+            info = O.parse_input_dat(os.path.join(d, "input", "input.dat"))
+            vec = kernel_vectors(ref, d, info, info["mesh_variant"])
+            np.savez_compressed(os.path.join(d, "kernels.npz"), **vec)
         print(f"{name}: {[l.nel for l in mg.levels]} nodes, {cycles} cycles, x{dup}")
 
 

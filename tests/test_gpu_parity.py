@@ -294,6 +294,27 @@ def test_driver_reproduces_reference_binary(case, mode, tmp_path):
         assert float(t["flux0"]) > 0 and float(t["time_step0"]) > 0 and float(t["compute_step0"]) > 0
 
 
+def test_driver_legacy_ordering_reproduces_reference_built_with_that_flag(tmp_path):
+    """--legacy-ordering == the reference compiled with -DLEGACY_ORDERING (src/Base/io.cpp:183-193): byte-identical
+    dump; and the Python binding's Mesh(legacy_ordering=True) hands back the sorted edges."""
+    d, cycles, dup = _case("fvcorr_1lvl_legacy_ordering")
+    exe = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
+    for extra in ([], ["--no-timers"]):
+        out = tmp_path / ("a" if not extra else "b")
+        out.mkdir()
+        r = subprocess.run([exe, "-i", "input.dat", "-d", os.path.join(d, "input"), "-o", str(out) + "/", "-g", str(cycles),
+                            "--output-variables", "--legacy-ordering"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        dump = out / f"variables.size={dup}x.cycles={cycles}.level=0"
+        assert dump.read_bytes() == open(os.path.join(d, "variables.level0.txt"), "rb").read()
+    import mgcfd
+    m = mgcfd.Mesh("input.dat", os.path.join(d, "input"), legacy_ordering=True)
+    lv = m.level(0)
+    ni = lv["n_internal"]
+    a, b = lv["edges"]["a"][:ni], lv["edges"]["b"][:ni]
+    assert np.all((np.diff(a) > 0) | ((np.diff(a) == 0) & (np.diff(b) >= 0)))
+
+
 def test_driver_validate_result_and_config_file(tmp_path):
     """-v against a solution.* file (src/euler3d_cpu_double.cpp:704-744, tolerance rule of
     validation.cpp:140-199) and the -c key=value config file (src/Base/config.cpp:159-217)."""

@@ -154,7 +154,10 @@ def main():
     import mgcfd
     mg, levels = build_workload(args.lattice)
     solver = mgcfd.Solver.from_arrays(levels, mg.mesh_variant, device=local_rank)
-    stream = torch.cuda.current_stream()
+    # one explicit stream for the solver's kernels AND torch's collectives (the legacy default stream
+    # cannot be shared with the library: its own stream does not synchronise with it)
+    stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(stream)
     solver.set_stream(stream.cuda_stream)
     solver.set_option("exact", 0 if args.fast else 1)
     solver.set_option("flux_variant", args.variant)

@@ -61,7 +61,11 @@ enum {
     MGCFD_OPT_TIMING = 1,      /* 1: bracket every loop with hipEvents (Times.csv columns); 2: only the flux launches of every 8th sweep */
     MGCFD_OPT_INDIRECT_RW = 2, /* 1: also run the indirect_rw probe each RK stage, as the reference's main() does */
     MGCFD_OPT_CHECK_INVALID = 3, /* 1 (default): NaN / negativity check every RK stage (validation.cpp:107-138) */
-    MGCFD_OPT_FLUX_VARIANT = 4, /* 0 (default): edge-length factor streamed; 1: recomputed from the weights */
+    MGCFD_OPT_FLUX_VARIANT = 4, /* bit 0: 0 (default) edge-length factor streamed, 1 recomputed from the weights;
+                                   bit 1: 0 (default) node gather (every edge evaluated from both ends),
+                                   2 edge-once tiles (every edge evaluated once per tile; levels whose tiles
+                                   hold too many edges fall back to the node gather, see
+                                   mgcfd_level_has_edge_once).  All four give bit-identical results. */
     MGCFD_OPT_FUSE_UPDATE = 5, /* 1 (default): mgcfd_smooth / mgcfd_run_cycles run each Runge-Kutta stage as ONE
                                   launch (fluxes + time_step, same operations); 0: one launch per loop */
     MGCFD_OPT_GRAPH = 6        /* 1 (default): replay each smoothing sweep from a captured hipGraph */
@@ -135,9 +139,14 @@ int mgcfd_create_partitioned(const mgcfd_level_desc *levels, int nlevels, int me
                              const int64_t *n_owned, mgcfd_solver **out);
 void mgcfd_destroy(mgcfd_solver *s);
 int mgcfd_set_option(mgcfd_solver *s, int option, int value);
+/* *yes = 1 when level `level` can run the edge-once flux variant (MGCFD_OPT_FLUX_VARIANT bit 1). */
+int mgcfd_level_has_edge_once(const mgcfd_solver *s, int level, int *yes);
 int mgcfd_get_option(const mgcfd_solver *s, int option, int *value);
-/* Run all subsequent work of this solver on an existing HIP stream (hipStream_t as void*),
- * e.g. torch.cuda.current_stream().cuda_stream; NULL restores the solver's own stream. */
+/* Run all subsequent work of this solver on an existing HIP stream (hipStream_t as void*), e.g.
+ * the cuda_stream of a torch.cuda.Stream() made current with torch.cuda.set_stream(): collectives
+ * and copies torch enqueues on that stream are then ordered with the solver's kernels.  NULL restores
+ * the solver's own stream, which is created non-blocking: it does NOT synchronise with the legacy
+ * default stream, whose handle is also NULL — the default stream cannot be shared this way. */
 int mgcfd_set_stream(mgcfd_solver *s, void *hip_stream);
 int mgcfd_synchronize(mgcfd_solver *s);
 int mgcfd_num_levels(const mgcfd_solver *s);

@@ -44,8 +44,16 @@ struct DevicePlan {
     int32_t *slice_row0 = nullptr, *rows_int = nullptr, *rows_bnd = nullptr, *nbr = nullptr;
     double *w = nullptr;                // [row][4 components][64 lanes]: signed, halved edge weights fx,fy,fz and k = -|e|*0.2f*0.5
     int32_t n_tiles = 0;
+    int32_t pad_row = 0;                // index of a row of padding after the last row (nbr16, w, gat16)
+    int32_t pad_chunk = 0;              // index of a chunk of padding after the last edge chunk (te_slots, te_w)
     uint16_t *nbr16 = nullptr;          // [row][64 lanes] tile-local codes
-    int32_t *tile_halo_ptr = nullptr, *tile_halo = nullptr, *tile_ovf_ptr = nullptr, *tile_ovf = nullptr;
+    int32_t *tile_halo = nullptr;        // [n_tiles][kHaloStride] ids of the staged halo nodes, -1 padded
+    int32_t *tile_ovf_ptr = nullptr, *tile_ovf = nullptr;
+    // edge-once tiles (preprocess.hpp: LevelPlan::te_*); edge_once == 0: not available on this level
+    int edge_once = 0;
+    int32_t *te_chunk_ptr = nullptr, *te_count = nullptr;
+    uint16_t *te_slots = nullptr, *gat16 = nullptr;
+    double *te_w = nullptr;
     int32_t *old_of_new = nullptr;
     // transfer to/from the next-coarser level
     int32_t *child_ptr = nullptr, *child = nullptr;

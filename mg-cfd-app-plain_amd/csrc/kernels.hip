@@ -21,6 +21,7 @@
 //     per STAGED node while the tile is filled (3 div + 2 sqrt); values are identical because
 //     the reference recomputes the very same per-node expressions for every incident edge.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include "device_plan.hpp"
@@ -85,22 +86,31 @@ __device__ __forceinline__ void store_conserved(double *__restrict__ q, int64_t 
 // LDS tile records: 12 doubles (96 B) per staged node, read back with 16-byte LDS loads.
 constexpr int kLdsRecD2 = 6;               // double2 per record
 
-__device__ __forceinline__ void lds_store_record(double2 *rec, const NodeQ &n)
+// Within a record the three pairs of 16-byte quads are swapped when bit 3 of the slot is set: with a
+// 24-dword record stride a fixed quad of slots s and s+8 would otherwise sit on the same 4 banks and
+// a 16-lane ds_read_b128 group could reach only 8 of the 16 quad positions of the 256-B bank row
+// (MI355X_MICROARCH.md, LDS); the swap makes all 16 reachable.
+__device__ __forceinline__ void lds_store_record(double2 *tile, uint32_t slot, const NodeQ &n)
 {
-    rec[0] = make_double2(n.rho, n.mx);
-    rec[1] = make_double2(n.my, n.mz);
-    rec[2] = make_double2(n.en, n.vx);
-    rec[3] = make_double2(n.vy, n.vz);
-    rec[4] = make_double2(n.p, n.speed);
-    rec[5] = make_double2(n.c, 0.0);
+    double2 *rec = tile + slot * kLdsRecD2;
+    const uint32_t b = (slot >> 3) & 1u;
+    rec[0 ^ b] = make_double2(n.rho, n.mx);
+    rec[1 ^ b] = make_double2(n.my, n.mz);
+    rec[2 ^ b] = make_double2(n.en, n.vx);
+    rec[3 ^ b] = make_double2(n.vy, n.vz);
+    rec[4 ^ b] = make_double2(n.p, n.speed);
+    rec[5 ^ b] = make_double2(n.c, 0.0);
 }
 
-__device__ __forceinline__ NodeQ lds_load_record(const double2 *rec)
+__device__ __forceinline__ NodeQ lds_load_record(const double2 *tile, uint32_t slot)
 {
-    const double2 a = rec[0], b = rec[1], c = rec[2], d = rec[3], e = rec[4];
-    const double f = reinterpret_cast<const double *>(rec)[10];
+    const uint32_t b = (slot >> 3) & 1u;
+    const double2 *even = tile + slot * kLdsRecD2 + b;      // logical quads 0, 2, 4 (+0, +2, +4)
+    const double2 *odd = tile + slot * kLdsRecD2 - b;       // logical quads 1, 3, 5 (+1, +3, +5)
+    const double2 a = even[0], bq = odd[1], c = even[2], d = odd[3], e = even[4];
+    const double f = odd[5].x;
     NodeQ r;
-    r.rho = a.x; r.mx = a.y; r.my = b.x; r.mz = b.y; r.en = c.x; r.vx = c.y;
+    r.rho = a.x; r.mx = a.y; r.my = bq.x; r.mz = bq.y; r.en = c.x; r.vx = c.y;
     r.vy = d.x; r.vz = d.y; r.p = e.x; r.speed = e.y; r.c = f;
     return r;
 }
@@ -324,14 +334,83 @@ __device__ __forceinline__ Flux5 edge_flux(const NodeQ &me, const FluxC &fm, con
     return f;
 }
 
+// What a node does with its complete flux: store it, or (FUSE) apply time_step to it
+// (cfd_loops.cpp:241-268) — same operations as k_time_step — and write the new state to fs.q_out.
+template <bool FUSE>
+__device__ __forceinline__ void finish_node(int64_t i, int64_t nel, int64_t stride, double a0, double a1, double a2,
+                                            double a3, double a4, double *__restrict__ fluxes, const FusedStep &fs,
+                                            double min_dt)
+{
+    if (i >= nel) return;
+    if (!FUSE) {
+        fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
+        fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
+        return;
+    }
+    // (operands fetched here, not under the row loop: the loop already sits at the register budget
+    //  of 3 waves per SIMD and hoisting these twelve registers makes it spill)
+    const double r0 = fs.old_variables[i], r1 = fs.old_variables[stride + i], r2 = fs.old_variables[2 * stride + i],
+                 r3 = fs.old_variables[3 * stride + i], r4 = fs.old_variables[4 * stride + i];
+    double sf;
+    if (fs.partial_min) {                       // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
+        sf = min_dt / fs.volumes[i];
+        fs.step_factors[i] = sf;
+    } else {
+        sf = fs.step_factors[i];
+    }
+    const double factor = sf / fs.rk_div;
+    const double rho = r0 + factor * a0, mx = r1 + factor * a1, my = r2 + factor * a2, mz = r3 + factor * a3,
+                 en = r4 + factor * a4;
+    store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
+    if (fs.residuals) {
+        fs.residuals[i] = rho - r0; fs.residuals[stride + i] = mx - r1; fs.residuals[2 * stride + i] = my - r2;
+        fs.residuals[3 * stride + i] = mz - r3; fs.residuals[4 * stride + i] = en - r4;
+    }
+    if (fs.check) {
+        const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
+        int code = 0;
+        if (!finite) code = 1;
+        else if (rho < 0.0) code = 2;
+        else if (en < 0.0) code = 3;
+        if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
+    }
+}
+
+// The boundary rows of a node (after its internal rows): solid-wall faces, then far-field faces.
+__device__ __forceinline__ void boundary_rows(const NodeQ &me, const FluxC &fm, const FarField &ff,
+                                              const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
+                                              int64_t first_row, int32_t n_bnd, int lane, int classes, double &a0,
+                                              double &a1, double &a2, double &a3, double &a4)
+{
+    for (int32_t r = 0; r < n_bnd; r++) {
+        const EdgeRow e = load_row<false>(nbr16, w, first_row + r, lane);
+        const double fx = e.fx, fy = e.fy, fz = e.fz;
+        if (e.code == kT16Wall && (classes & 2)) {
+            // flux_boundary_kernel.elemfunc.c:37-64: pressure force only
+            a0 += 0.0;
+            a1 += fx * me.p;
+            a2 += fy * me.p;
+            a3 += fz * me.p;
+            a4 += 0.0;
+        } else if (e.code == kT16Far && (classes & 4)) {
+            // flux_wall_kernel.elemfunc.c:51-88: average with the far-field state
+            a0 += fx * (ff.var[1] + me.mx) + fy * (ff.var[2] + me.my) + fz * (ff.var[3] + me.mz);
+            a4 += fx * (ff.fc_de[0] + fm.ex) + fy * (ff.fc_de[1] + fm.ey) + fz * (ff.fc_de[2] + fm.ez);
+            a1 += fx * (ff.fc_mx[0] + fm.xx) + fy * (ff.fc_mx[1] + fm.xy) + fz * (ff.fc_mx[2] + fm.xz);
+            a2 += fx * (ff.fc_my[0] + fm.xy) + fy * (ff.fc_my[1] + fm.yy) + fz * (ff.fc_my[2] + fm.yz);
+            a3 += fx * (ff.fc_mz[0] + fm.xz) + fy * (ff.fc_mz[1] + fm.yz) + fz * (ff.fc_mz[2] + fm.zz);
+        }
+    }
+}
+
 template <int MINW, bool LOADK, bool FUSE, bool ACC>
 __global__ void __launch_bounds__(kBlock, MINW)
 k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
             const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
             const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
-            const int32_t *__restrict__ tile_halo_ptr, const int32_t *__restrict__ tile_halo,
+            const int32_t *__restrict__ tile_halo,
             const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
-            double *__restrict__ fluxes, int classes, FusedStep fs)
+            double *__restrict__ fluxes, int classes, FusedStep fs, int32_t pad_row)
 {
     __shared__ double2 tile[kTileCap * kLdsRecD2];
 
@@ -341,36 +420,39 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
     double min_dt = 0.0;
     if (FUSE && fs.partial_min) min_dt = block_min_of_partials(fs.partial_min, fs.n_partial);
 
-    const unsigned t = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const unsigned t = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int64_t base = int64_t(t) * kTile;
     const int64_t i = base + tid;
     const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
 
-    // first rows' ids and weights go in flight before anything else
+    // Issue order of the prologue's loads (they return in order, and a wait after a conditional load
+    // is conservative, so none of them sits under a branch): the halo ids first — they head the only
+    // dependent chain (ids -> halo state; fixed-stride table, the address needs only the tile number)
+    // — then the own node's state, the first two rows' ids and weights, and the halo state by id.
+    const int32_t *hrow = tile_halo + int64_t(t) * kHaloStride;
+    const int32_t hid = hrow[tid];                                     // -1: no halo node for this thread
+    const int32_t hid2 = tid < kHaloStride - kBlock ? hrow[kBlock + tid] : -1;   // halo larger than the workgroup (rare)
+    const double o0 = q[i], o1 = q[stride + i], o2 = q[2 * stride + i], o3 = q[3 * stride + i], o4 = q[4 * stride + i];
     const int32_t row0 = slice_row0[slice];
     const int32_t n_int = (classes & 1) ? rows_int[slice] : 0;
     const int32_t n_bnd = rows_bnd[slice];
-    EdgeRow e0 = pad_row(), e1 = pad_row();
-    if (n_int > 0) e0 = load_row<LOADK>(nbr16, w, row0, lane);
-    if (n_int > 1) e1 = load_row<LOADK>(nbr16, w, int64_t(row0) + 1, lane);
-
-    // ---- phase 1: stage + derive.  All loads are issued before any arithmetic: halo ids first
-    //      (the halo gather depends on them), then the own node's state (coalesced), then the
-    //      halo state by id. ----
-    const int32_t h0 = tile_halo_ptr[t];
-    const int32_t n_halo = tile_halo_ptr[t + 1] - h0;
-    const bool has_halo = tid < n_halo;
-    const int64_t hnode = has_halo ? int64_t(tile_halo[h0 + tid]) : i;
-    const double o0 = q[i], o1 = q[stride + i], o2 = q[2 * stride + i], o3 = q[3 * stride + i], o4 = q[4 * stride + i];
+    // (a row the slice does not have is read from pad_row, a row of padding after the last one: the
+    //  load itself is never conditional, so the compiler can count the loads in flight exactly)
+    EdgeRow e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
+    EdgeRow e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
+    const bool has_halo = hid >= 0;
+    const int64_t hnode = has_halo ? int64_t(hid) : i;
     const double g0 = q[hnode], g1 = q[stride + hnode], g2 = q[2 * stride + hnode], g3 = q[3 * stride + hnode],
                  g4 = q[4 * stride + hnode];
     const NodeQ me = make_nodeq(o0, o1, o2, o3, o4);
-    lds_store_record(&tile[tid * kLdsRecD2], me);
-    if (has_halo) lds_store_record(&tile[(kTile + tid) * kLdsRecD2], make_nodeq(g0, g1, g2, g3, g4));
-    for (int32_t h = tid + kBlock; h < n_halo; h += kBlock)            // halo larger than the workgroup (rare)
-        lds_store_record(&tile[(kTile + h) * kLdsRecD2], load_and_derive(q, stride, tile_halo[h0 + h]));
+    lds_store_record(tile, uint32_t(tid), me);
+    // Unconditional: a thread without a halo node re-reads its own node and parks the copy in its
+    // (unused) halo slot.  A branch here lets the compiler sink the gather loads below the own
+    // record's derivation and serialise the two.
+    lds_store_record(tile, uint32_t(kTile + tid), make_nodeq(g0, g1, g2, g3, g4));
+    if (hid2 >= 0) lds_store_record(tile, uint32_t(kTile + kBlock + tid), load_and_derive(q, stride, hid2));
 
     const FluxC fm_pre = flux_contribution(me);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
@@ -384,9 +466,8 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
     // ---- phase 2: incidence rows two at a time (independent arithmetic, ordered accumulation),
     //      ids/weights fetched two rows ahead ----
     for (int32_t r = 0; r < n_int; r += 2) {
-        EdgeRow e2 = pad_row(), e3 = pad_row();
-        if (r + 2 < n_int) e2 = load_row<LOADK>(nbr16, w, int64_t(row0) + r + 2, lane);
-        if (r + 3 < n_int) e3 = load_row<LOADK>(nbr16, w, int64_t(row0) + r + 3, lane);
+        const EdgeRow e2 = load_row<LOADK>(nbr16, w, r + 2 < n_int ? row0 + r + 2 : pad_row, lane);
+        const EdgeRow e3 = load_row<LOADK>(nbr16, w, r + 3 < n_int ? row0 + r + 3 : pad_row, lane);
 
         const uint32_t s0 = e0.code & kT16SlotMask, s1 = e1.code & kT16SlotMask;
         const bool v0 = s0 != kT16Pad, v1 = s1 != kT16Pad;               // ELL padding contributes nothing
@@ -395,12 +476,12 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
         if (__builtin_expect(__any(o0 || o1), 0)) {
             // ragged cluster: some neighbour did not fit the LDS tile, read it from HBM
             n0 = o0 ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s0) - kTileCap])
-                    : lds_load_record(&tile[(v0 ? s0 : uint32_t(tid)) * kLdsRecD2]);
+                    : lds_load_record(tile, v0 ? s0 : uint32_t(tid));
             n1 = o1 ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s1) - kTileCap])
-                    : lds_load_record(&tile[(v1 ? s1 : uint32_t(tid)) * kLdsRecD2]);
+                    : lds_load_record(tile, v1 ? s1 : uint32_t(tid));
         } else {
-            n0 = lds_load_record(&tile[(v0 ? s0 : uint32_t(tid)) * kLdsRecD2]);
-            n1 = lds_load_record(&tile[(v1 ? s1 : uint32_t(tid)) * kLdsRecD2]);
+            n0 = lds_load_record(tile, v0 ? s0 : uint32_t(tid));
+            n1 = lds_load_record(tile, v1 ? s1 : uint32_t(tid));
         }
         Flux5 f0, f1;
         if (FUSE) {
@@ -501,6 +582,174 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
         else if (en < 0.0) code = 3;
         if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// flux_edge_once: the same three loops with every internal edge evaluated ONCE per tile.
+//
+// k_flux_tile reads an edge's weights and evaluates its flux twice, once from each end.  Here a
+// tile lists the internal edges that touch it once (preprocess.cpp, te_*), in ORIGINAL edge
+// order; with the node records staged as before, thread p % 256 evaluates edge p of the list
+// (a-side form, flux_kernel.elemfunc.c:130-161) and keeps the five results in registers.  When
+// all edges are done the records are dead: the fluxes replace them in LDS (40 B each, position
+// p), and every node then sums its incident edges from LDS in its own row order = the reference's
+// accumulation order; the b end adds -F, which is what the reference's b-side expressions
+// (:170-189) evaluate to bit for bit (every term negates exactly).  An edge cut by a tile
+// boundary is evaluated by both tiles from identical operands.  Per tile this moves ~36 B per
+// listed edge + 2 B per row entry instead of 34 B per row entry (two per edge), and does ~0.6 of
+// the flux arithmetic.
+// ------------------------------------------------------------------------------------------
+struct TileEdge { uint32_t sa, sb; double fx, fy, fz, k; };
+constexpr int kGatherPre = 8;             // gather-list rows held in registers from the start of the kernel
+
+template <bool LOADK>
+__device__ __forceinline__ TileEdge load_tile_edge(const uint16_t *__restrict__ te_slots, const double *__restrict__ te_w,
+                                                   int64_t chunk, int tid)
+{
+    TileEdge e;
+    e.sa = te_slots[(chunk * 2) * kEdgeChunk + tid];
+    e.sb = te_slots[(chunk * 2 + 1) * kEdgeChunk + tid];
+    const double *wr = te_w + chunk * (4 * kEdgeChunk) + tid;
+    e.fx = wr[0]; e.fy = wr[kEdgeChunk]; e.fz = wr[2 * kEdgeChunk];
+    e.k = LOADK ? wr[3 * kEdgeChunk] : 0.0;
+    return e;
+}
+
+__device__ __forceinline__ TileEdge no_tile_edge()
+{
+    TileEdge e;
+    e.sa = kT16Pad; e.sb = kT16Pad; e.fx = 0.0; e.fy = 0.0; e.fz = 0.0; e.k = 0.0;
+    return e;
+}
+
+template <bool LOADK, bool FUSE, bool ACC>
+__global__ void __launch_bounds__(kBlock, 3)
+k_flux_edge_once(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
+                 const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
+                 const uint16_t *__restrict__ nbr16, const double *__restrict__ w, const uint16_t *__restrict__ gat16,
+                 const int32_t *__restrict__ te_chunk_ptr, const int32_t *__restrict__ te_count,
+                 const uint16_t *__restrict__ te_slots, const double *__restrict__ te_w,
+                 const int32_t *__restrict__ tile_halo,
+                 const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
+                 double *__restrict__ fluxes, int classes, FusedStep fs, int32_t pad_chunk, int32_t pad_row)
+{
+    __shared__ double2 tile[kTileCap * kLdsRecD2];
+
+    double min_dt = 0.0;
+    if (FUSE && fs.partial_min) min_dt = block_min_of_partials(fs.partial_min, fs.n_partial);
+
+    const unsigned t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave_base = tid & ~63;                 // first list position of this wave within a chunk
+    const int64_t base = int64_t(t) * kTile;
+    const int64_t i = base + tid;
+    const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
+
+    // load issue order as in k_flux_tile: halo ids, own state, then the bulk prefetches (first two
+    // chunks of the edge list, the node's gather list), then the halo state by id; nothing under a branch
+    const int32_t *hrow = tile_halo + int64_t(t) * kHaloStride;
+    const int32_t hid = hrow[tid];                                     // -1: no halo node for this thread
+    const int32_t hid2 = tid < kHaloStride - kBlock ? hrow[kBlock + tid] : -1;   // halo larger than the workgroup (rare)
+    const double o0 = q[i], o1 = q[stride + i], o2 = q[2 * stride + i], o3 = q[3 * stride + i], o4 = q[4 * stride + i];
+    const int32_t n_te = te_count[t];
+    const int64_t chunk0 = te_chunk_ptr[t];
+    // (a chunk this wave has no edges in is read from pad_chunk, a chunk of padding after the last
+    //  one: the loads are never conditional, so the compiler can count the loads in flight exactly)
+    TileEdge e_cur = load_tile_edge<LOADK>(te_slots, te_w, wave_base < n_te ? chunk0 : pad_chunk, tid);
+    TileEdge e_nxt = load_tile_edge<LOADK>(te_slots, te_w, kEdgeChunk + wave_base < n_te ? chunk0 + 1 : pad_chunk, tid);
+
+    // the node's gather list (positions of its incident edges in the tile's list): the first rows
+    // are fetched now, long before phase 4 needs them
+    const int32_t row0 = slice_row0[slice];
+    const int32_t n_int = rows_int[slice];
+    const int32_t n_bnd = rows_bnd[slice];
+    const uint16_t *grow = gat16 + (int64_t(row0) << 6) + lane;
+    uint32_t gc[kGatherPre];
+#pragma unroll
+    for (int k = 0; k < kGatherPre; k++) gc[k] = gat16[(int64_t(k < n_int ? row0 + k : pad_row) << 6) + lane];
+
+    // ---- phase 1: stage + derive, as k_flux_tile ----
+    const bool has_halo = hid >= 0;
+    const int64_t hnode = has_halo ? int64_t(hid) : i;
+    {
+        const double g0 = q[hnode], g1 = q[stride + hnode], g2 = q[2 * stride + hnode], g3 = q[3 * stride + hnode],
+                     g4 = q[4 * stride + hnode];
+        lds_store_record(tile, uint32_t(tid), make_nodeq(o0, o1, o2, o3, o4));
+        lds_store_record(tile, uint32_t(kTile + tid), make_nodeq(g0, g1, g2, g3, g4));   // unconditional, see k_flux_tile
+    }
+    if (hid2 >= 0) lds_store_record(tile, uint32_t(kTile + kBlock + tid), load_and_derive(q, stride, hid2));
+    const int32_t ovf0 = tile_ovf_ptr[t];
+    __syncthreads();
+
+    // ---- phase 2: one edge per thread and chunk ----
+    Flux5 F[kMaxEdgeChunks];
+#pragma unroll
+    for (int c = 0; c < kMaxEdgeChunks; c++) {
+        TileEdge e_n2 = no_tile_edge();
+        if (c + 2 < kMaxEdgeChunks)                                    // compile-time
+            e_n2 = load_tile_edge<LOADK>(te_slots, te_w, (c + 2) * kEdgeChunk + wave_base < n_te ? chunk0 + c + 2 : pad_chunk, tid);
+        F[c].d = 0.0; F[c].mx = 0.0; F[c].my = 0.0; F[c].mz = 0.0; F[c].en = 0.0;
+        if (c * kEdgeChunk + wave_base < n_te) {                     // wave-uniform
+            const bool v = e_cur.sa != kT16Pad;                      // the list's last chunk is padded
+            const uint32_t sa = v ? e_cur.sa : uint32_t(tid), sb = v ? e_cur.sb : uint32_t(tid);
+            const bool oa = sa >= uint32_t(kTileCap), ob = sb >= uint32_t(kTileCap);
+            NodeQ A, B;
+            if (__builtin_expect(__any(oa || ob), 0)) {
+                // ragged cluster: an end point did not fit the LDS tile, read it from HBM
+                A = oa ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(sa) - kTileCap]) : lds_load_record(tile, sa);
+                B = ob ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(sb) - kTileCap]) : lds_load_record(tile, sb);
+            } else {
+                A = lds_load_record(tile, sa);
+                B = lds_load_record(tile, sb);
+            }
+            EdgeRow er;
+            er.code = 0;                                             // role a
+            er.fx = e_cur.fx; er.fy = e_cur.fy; er.fz = e_cur.fz; er.k = e_cur.k;
+            F[c] = edge_flux<LOADK>(A, flux_contribution(A), B, er);
+        }
+        e_cur = e_nxt; e_nxt = e_n2;
+    }
+
+    // ---- phase 3: the records are dead; the edge fluxes take their place ----
+    double *fb = reinterpret_cast<double *>(tile);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kMaxEdgeChunks; c++) {
+        if (c * kEdgeChunk + wave_base < n_te) {
+            double *slot = fb + (c * kEdgeChunk + tid) * 5;
+            slot[0] = F[c].d; slot[1] = F[c].mx; slot[2] = F[c].my; slot[3] = F[c].mz; slot[4] = F[c].en;
+        }
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+    if (ACC) {
+        a0 = fluxes[i]; a1 = fluxes[stride + i]; a2 = fluxes[2 * stride + i];
+        a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
+    }
+    __syncthreads();
+
+    // ---- phase 4: every node sums its incident edges in row order ----
+    auto add_entry = [&](uint32_t code) {
+        const uint32_t p = code & kT16SlotMask;
+        if (p == kT16Pad) return;
+        const double *sl = fb + p * 5;
+        const double f0 = sl[0], f1 = sl[1], f2 = sl[2], f3 = sl[3], f4 = sl[4];
+        const bool neg = (code & kT16RoleB) != 0;                   // this node is the edge's b end
+        a0 = neg ? a0 - f0 : a0 + f0;  a1 = neg ? a1 - f1 : a1 + f1;  a2 = neg ? a2 - f2 : a2 + f2;
+        a3 = neg ? a3 - f3 : a3 + f3;  a4 = neg ? a4 - f4 : a4 + f4;
+    };
+#pragma unroll
+    for (int k = 0; k < kGatherPre; k++)
+        if (k < n_int) add_entry(gc[k]);
+    for (int32_t r = kGatherPre; r < n_int; r++) add_entry(grow[r << 6]);
+
+    if ((classes & 6) && n_bnd > 0) {
+        // boundary faces need the node's own derived state again (its LDS record is gone)
+        const NodeQ me = load_and_derive(q, stride, i);
+        boundary_rows(me, flux_contribution(me), ff, nbr16, w, int64_t(row0) + n_int, n_bnd, lane, classes, a0, a1, a2, a3, a4);
+    }
+
+    finish_node<FUSE>(i, nel, stride, a0, a1, a2, a3, a4, fluxes, fs, min_dt);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -806,15 +1055,34 @@ void launch_step_factor_legacy(hipStream_t st, int64_t nel, int64_t stride, cons
 void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const FarField &ff, double *fluxes,
                  int classes, int accumulate, int variant, const FusedStep *fused)
 {
-    const dim3 grid(p.n_tiles), block(kBlock);
+    const dim3 block(kBlock);
+    const dim3 grid(p.n_tiles);
     FusedStep fs{};
     if (fused) fs = *fused;
     // 3 tiles of 52.5 KiB LDS fit a CU => at least 3 waves per SIMD wanted
 #define MGCFD_TILE_LAUNCH(LOADK, FUSE, ACC)                                                                    \
-    hipLaunchKernelGGL((k_flux_tile<3, LOADK, FUSE, ACC>), grid, block, 0, st, p.nel, p.stride, q,             \
-                       p.slice_row0, p.rows_int, p.rows_bnd, p.nbr16, p.w, p.tile_halo_ptr, p.tile_halo,       \
-                       p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs)
-    const bool loadk = variant != 1;            // variant 1: recompute k = -|e|*s*0.5 from the weights
+    hipLaunchKernelGGL((k_flux_tile<3, LOADK, FUSE, ACC>), grid, block,  0, st, p.nel, p.stride, q,            \
+                       p.slice_row0, p.rows_int, p.rows_bnd, p.nbr16, p.w, p.tile_halo,                        \
+                       p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs, p.pad_row)
+    const bool loadk = (variant & 1) == 0;      // odd variants recompute k = -|e|*s*0.5 from the weights
+    // variants 2, 3: every edge evaluated once per tile (needs the internal class and a level whose
+    // tiles fit the edge-once limits; otherwise the node gather below)
+    if ((variant & 2) && p.edge_once && (classes & 1)) {
+#define MGCFD_EO_LAUNCH(LOADK, FUSE, ACC)                                                                      \
+    hipLaunchKernelGGL((k_flux_edge_once<LOADK, FUSE, ACC>), grid, block, 0, st, p.nel, p.stride, q,           \
+                       p.slice_row0, p.rows_int, p.rows_bnd, p.nbr16, p.w, p.gat16, p.te_chunk_ptr,            \
+                       p.te_count, p.te_slots, p.te_w, p.tile_halo, p.tile_ovf_ptr,           \
+                       p.tile_ovf, ff, fluxes, classes, fs, p.pad_chunk, p.pad_row)
+        if (fused) {
+            if (loadk) MGCFD_EO_LAUNCH(true, true, false); else MGCFD_EO_LAUNCH(false, true, false);
+        } else if (accumulate) {
+            if (loadk) MGCFD_EO_LAUNCH(true, false, true); else MGCFD_EO_LAUNCH(false, false, true);
+        } else {
+            if (loadk) MGCFD_EO_LAUNCH(true, false, false); else MGCFD_EO_LAUNCH(false, false, false);
+        }
+#undef MGCFD_EO_LAUNCH
+        return;
+    }
     if (fused) {
         if (loadk) MGCFD_TILE_LAUNCH(true, true, false); else MGCFD_TILE_LAUNCH(false, true, false);
     } else if (accumulate) {

@@ -276,6 +276,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
 
     // ---- fill, in original edge order = the reference's accumulation order ----
     std::vector<int32_t> fill_int(static_cast<size_t>(nel), 0), fill_bnd(static_cast<size_t>(nel), 0);
+    std::vector<int32_t> entry_edge(static_cast<size_t>(rows) * kSlice, -1);   // internal entries: edge index - internal_start
     auto entry_index = [&](int32_t node_new, int32_t row_in_slice) {
         const int32_t s = node_new / kSlice, lane = node_new % kSlice;
         return (static_cast<int64_t>(P.slice_row0[static_cast<size_t>(s)]) + row_in_slice) * kSlice + lane;
@@ -290,12 +291,14 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         if (owned(E.a)) {
             int64_t ia = entry_index(a, fill_int[static_cast<size_t>(a)]++);
             P.nbr[static_cast<size_t>(ia)] = b;                                // this node is 'a'
+            entry_edge[static_cast<size_t>(ia)] = static_cast<int32_t>(e - L.internal_start);
             P.w[static_cast<size_t>(ia)] = EdgeW{fx, fy, fz, k};
             useful++;
         }
         if (owned(E.b)) {
             int64_t ib = entry_index(b, fill_int[static_cast<size_t>(b)]++);
             P.nbr[static_cast<size_t>(ib)] = a | kRoleB;                       // this node is 'b'
+            entry_edge[static_cast<size_t>(ib)] = static_cast<int32_t>(e - L.internal_start);
             P.w[static_cast<size_t>(ib)] = EdgeW{-fx, -fy, -fz, k};            // x - f*y == x + (-f)*y exactly
             useful++;
         }
@@ -317,8 +320,15 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     P.tile_ovf_ptr.assign(static_cast<size_t>(P.n_tiles) + 1, 0);
     P.tile_halo.clear();
     P.tile_ovf.clear();
+    P.gat16.assign(P.nbr.size(), static_cast<uint16_t>(kT16Pad));
+    P.te_chunk_ptr.assign(static_cast<size_t>(P.n_tiles) + 1, 0);
+    P.te_count.assign(static_cast<size_t>(P.n_tiles), 0);
+    P.te_slots.clear();
+    P.te_w.clear();
+    P.edge_once = true;
     {
-        std::vector<int32_t> halo;
+        std::vector<int32_t> halo, tile_edges;
+        int64_t te_total = 0;
         const int32_t halo_cap = kTileCap - kTile;
         const int32_t ovf_cap = int32_t(kT16Far) - kTileCap;          // overflow slots a 15-bit code can name
         int64_t halo_total = 0;
@@ -361,12 +371,59 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                 }
                 P.nbr16[static_cast<size_t>(e)] = static_cast<uint16_t>(c16);
             }
+            // edge-once list: the tile's internal edges, once each, ascending original index.  A node's
+            // incident edges keep their relative order in it, so summing a node's entries by position
+            // is the reference's accumulation order.
+            tile_edges.clear();
+            for (int64_t e = e0; e < e1; e++)
+                if (entry_edge[static_cast<size_t>(e)] >= 0) tile_edges.push_back(entry_edge[static_cast<size_t>(e)]);
+            std::sort(tile_edges.begin(), tile_edges.end());
+            tile_edges.erase(std::unique(tile_edges.begin(), tile_edges.end()), tile_edges.end());
+            const int32_t n_te = static_cast<int32_t>(tile_edges.size());
+            P.te_count[static_cast<size_t>(t)] = n_te;
+            P.te_max = std::max(P.te_max, n_te);
+            te_total += n_te;
+            if (n_te > kMaxEdgeChunks * kEdgeChunk) P.edge_once = false;
+            if (P.edge_once) {
+                auto slot_of = [&](int32_t id) -> uint16_t {
+                    if (id >= base && id < base + kTile) return static_cast<uint16_t>(id - base);
+                    const int32_t pos = static_cast<int32_t>(std::lower_bound(halo.begin(), halo.end(), id) - halo.begin());
+                    return static_cast<uint16_t>(kTile + pos);            // >= kTileCap: overflow table, as in nbr16
+                };
+                const size_t chunk0 = static_cast<size_t>(P.te_chunk_ptr[static_cast<size_t>(t)]);
+                const size_t n_chunks = (static_cast<size_t>(n_te) + kEdgeChunk - 1) / kEdgeChunk;
+                P.te_slots.resize((chunk0 + n_chunks) * 2 * kEdgeChunk, static_cast<uint16_t>(kT16Pad));
+                P.te_w.resize((chunk0 + n_chunks) * 4 * kEdgeChunk, 0.0);
+                for (int32_t p = 0; p < n_te; p++) {
+                    const mgcfd_edge &E = edges[static_cast<size_t>(L.internal_start + tile_edges[static_cast<size_t>(p)])];
+                    const size_t c = chunk0 + static_cast<size_t>(p / kEdgeChunk), ln = static_cast<size_t>(p % kEdgeChunk);
+                    P.te_slots[(c * 2 + 0) * kEdgeChunk + ln] = slot_of(P.new_of_old[static_cast<size_t>(E.a)]);
+                    P.te_slots[(c * 2 + 1) * kEdgeChunk + ln] = slot_of(P.new_of_old[static_cast<size_t>(E.b)]);
+                    const double ewt = std::sqrt(E.x * E.x + E.y * E.y + E.z * E.z);
+                    P.te_w[(c * 4 + 0) * kEdgeChunk + ln] = -0.5 * E.x;
+                    P.te_w[(c * 4 + 1) * kEdgeChunk + ln] = -0.5 * E.y;
+                    P.te_w[(c * 4 + 2) * kEdgeChunk + ln] = -0.5 * E.z;
+                    P.te_w[(c * 4 + 3) * kEdgeChunk + ln] = -ewt * kSmoothing * 0.5;
+                }
+                for (int64_t e = e0; e < e1; e++) {
+                    const int32_t ge = entry_edge[static_cast<size_t>(e)];
+                    if (ge < 0) continue;
+                    const uint32_t p = static_cast<uint32_t>(std::lower_bound(tile_edges.begin(), tile_edges.end(), ge) - tile_edges.begin());
+                    P.gat16[static_cast<size_t>(e)] = static_cast<uint16_t>(p | ((P.nbr[static_cast<size_t>(e)] & kRoleB) ? kT16RoleB : 0u));
+                }
+                P.te_chunk_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(chunk0 + n_chunks);
+            }
             P.tile_halo.insert(P.tile_halo.end(), halo.begin(), halo.begin() + staged);
             P.tile_halo_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(P.tile_halo.size());
             P.tile_ovf.insert(P.tile_ovf.end(), halo.begin() + staged, halo.end());
             P.tile_ovf_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(P.tile_ovf.size());
         }
         P.halo_mean = P.n_tiles ? double(halo_total) / double(P.n_tiles) : 0.0;
+        P.te_mean = P.n_tiles ? double(te_total) / double(P.n_tiles) : 0.0;
+        if (!P.edge_once) {
+            P.te_slots.clear(); P.te_w.clear(); P.gat16.clear();
+            P.te_chunk_ptr.assign(static_cast<size_t>(P.n_tiles) + 1, 0);
+        }
     }
 
     P.n_internal_entries = useful;

@@ -21,6 +21,15 @@ namespace mgcfd {
 constexpr int kSlice = 64;   // wavefront width
 constexpr int kTile = 256;   // nodes per tile = one 256-thread workgroup = 4 slices
 constexpr int kTileCap = 560;   // node records a tile can stage in LDS (560 * 96 B = 52.5 KiB => 3 tiles per CU)
+// edge-once tiles: a tile's internal edges are evaluated in chunks of one edge per thread; the
+// fluxes of up to kMaxEdgeChunks chunks wait in registers, then replace the node records in LDS
+// (kMaxEdgeChunks * 256 * 40 B must fit kTileCap * 96 B)
+constexpr int kHaloStride = kTileCap - kTile;   // halo ids a tile can stage (device table: fixed stride, -1 padded)
+static_assert(kTileCap >= 2 * kTile, "every thread has a halo slot (the kernels stage one unconditionally)");
+static_assert(kHaloStride <= 2 * kTile, "the staging code reads at most two halo ids per thread");
+constexpr int kEdgeChunk = 256;
+constexpr int kMaxEdgeChunks = 5;
+static_assert(kMaxEdgeChunks * kEdgeChunk * 40 <= kTileCap * 96, "edge fluxes must fit the LDS tile");
 
 // neighbour codes in Sell::nbr
 constexpr int32_t kRoleB = 1 << 30;     // set when THIS node is the edge's 'b' end (else it is 'a')
@@ -63,6 +72,16 @@ struct LevelPlan {
     //   internal, this node = b:  (x,y,z) = +0.5*e   k = same
     //   wall (-1):                (x,y,z) = e                                  (flux_boundary_kernel.elemfunc.c:37-45)
     //   far field (-2):           (x,y,z) = 0.5*e                              (flux_wall_kernel.elemfunc.c:51-53)
+    // ---- edge-once tiles: every internal edge that touches a tile, listed once per tile in
+    //      ORIGINAL edge order; entry p of tile t is evaluated by thread p % 256 in chunk p / 256 ----
+    bool edge_once = false;               // false: some tile holds more than kMaxEdgeChunks*256 edges (node gather only)
+    int32_t te_max = 0; double te_mean = 0.0;
+    std::vector<int32_t> te_chunk_ptr;    // [n_tiles+1] first chunk of each tile
+    std::vector<int32_t> te_count;        // [n_tiles] edges of each tile
+    std::vector<uint16_t> te_slots;       // [chunk][2][256] LDS slot (as nbr16, no role bit) of end points a and b; kT16Pad = no edge
+    std::vector<double> te_w;             // [chunk][4][256] a-side weights: -0.5*e (x,y,z) and k = -|e|*smoothing*0.5
+    std::vector<uint16_t> gat16;          // [rows*64] internal rows: position p of the entry's edge in its tile's list
+                                          //   | kT16RoleB when this node is the edge's b end (it gets -F); kT16Pad
     int64_t n_internal_entries = 0;    // = 2 * internal edges
     double pad_fraction = 0.0;         // padding / useful entries in the internal rows
 

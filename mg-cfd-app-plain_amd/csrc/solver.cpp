@@ -339,10 +339,11 @@ mgcfd_solver::~mgcfd_solver()
     for (auto &p : pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto e : free_events) (void)hipEventDestroy(e);
     for (auto &lv : L) {
-        void *ptrs[] = {lv.q_alt, lv.dp.nbr16, lv.dp.tile_halo_ptr, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
+        void *ptrs[] = {lv.q_alt, lv.dp.nbr16, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
                         lv.cbrt_vol, lv.min_dt, lv.partial_min, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.pro,
-                        lv.dp.pro_parent, lv.dp.pro_wsum};
+                        lv.dp.pro_parent, lv.dp.pro_wsum, lv.dp.te_chunk_ptr, lv.dp.te_count, lv.dp.te_slots, lv.dp.te_w,
+                        lv.dp.gat16};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         for (auto &hp : lv.halo_plans) if (hp.first) (void)hipFree(hp.first);
     }
@@ -402,9 +403,10 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         }
         build_level_plan(d, lv.edges, popt, lv.plan);
         if (std::getenv("MGCFD_VERBOSE"))
-            std::fprintf(stderr, "[mgcfd] level %d: %ld nodes, %d tiles, halo mean %.0f max %d (cap %d), overflow refs %ld, ELL padding %.1f%%\n",
+            std::fprintf(stderr, "[mgcfd] level %d: %ld nodes, %d tiles, halo mean %.0f max %d (cap %d), overflow refs %ld, ELL padding %.1f%%, tile edges mean %.0f max %d (edge-once %s)\n",
                          l, (long)d.nel, lv.plan.n_tiles, lv.plan.halo_mean, lv.plan.halo_max, kTileCap - kTile,
-                         (long)lv.plan.halo_overflow_refs, 100.0 * lv.plan.pad_fraction);
+                         (long)lv.plan.halo_overflow_refs, 100.0 * lv.plan.pad_fraction, lv.plan.te_mean, lv.plan.te_max,
+                         lv.plan.edge_once ? "yes" : "no");
     }
     for (int l = 0; l + 1 < nlevels; l++) {
         const mgcfd_level_desc &d = levels[l];
@@ -451,7 +453,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         {
             // edge weights as [row][component][lane] so each component load of a wave is one
             // contiguous 512-byte run
-            std::vector<double> ws(P.w.size() * 4);
+            std::vector<double> ws(P.w.size() * 4 + 2 * 4 * kSlice, 0.0);   // + two rows of padding (k_flux_tile's prologue)
             for (size_t e = 0; e < P.w.size(); e++) {
                 const size_t row = e / kSlice, lane = e % kSlice;
                 ws[(row * 4 + 0) * kSlice + lane] = P.w[e].x;
@@ -463,11 +465,34 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         }
         lv.dp.old_of_new = dev_upload(P.old_of_new);
         lv.dp.n_tiles = P.n_tiles;
+        lv.plan.nbr16.resize(P.nbr16.size() + 2 * kSlice, static_cast<uint16_t>(kT16Pad));   // two rows of padding
         lv.dp.nbr16 = dev_upload(P.nbr16);
-        lv.dp.tile_halo_ptr = dev_upload(P.tile_halo_ptr);
-        lv.dp.tile_halo = dev_upload(P.tile_halo);
+        {
+            std::vector<int32_t> fixed(static_cast<size_t>(P.n_tiles) * kHaloStride, -1);
+            for (int32_t t = 0; t < P.n_tiles; t++)
+                std::copy(P.tile_halo.begin() + P.tile_halo_ptr[static_cast<size_t>(t)],
+                          P.tile_halo.begin() + P.tile_halo_ptr[static_cast<size_t>(t) + 1],
+                          fixed.begin() + static_cast<size_t>(t) * kHaloStride);
+            lv.dp.tile_halo = dev_upload(fixed);
+        }
         lv.dp.tile_ovf_ptr = dev_upload(P.tile_ovf_ptr);
         lv.dp.tile_ovf = dev_upload(P.tile_ovf);
+        lv.dp.pad_row = P.slice_row0.back();
+        lv.dp.pad_chunk = P.te_chunk_ptr.empty() ? 0 : P.te_chunk_ptr.back();
+        lv.dp.edge_once = (P.edge_once && !std::getenv("MGCFD_NO_EDGE_ONCE")) ? 1 : 0;
+        if (lv.dp.edge_once) {
+            lv.dp.te_chunk_ptr = dev_upload(P.te_chunk_ptr);
+            lv.dp.te_count = dev_upload(P.te_count);
+            lv.plan.te_slots.resize(P.te_slots.size() + 2 * kEdgeChunk, static_cast<uint16_t>(kT16Pad));   // one chunk of padding
+            lv.plan.te_w.resize(P.te_w.size() + 4 * kEdgeChunk, 0.0);
+            lv.dp.te_slots = dev_upload(P.te_slots);
+            lv.dp.te_w = dev_upload(P.te_w);
+            lv.plan.gat16.resize(P.gat16.size() + 2 * kSlice, static_cast<uint16_t>(kT16Pad));   // two rows of padding
+            lv.dp.gat16 = dev_upload(P.gat16);
+        }
+        lv.plan.te_slots.clear(); lv.plan.te_slots.shrink_to_fit();
+        lv.plan.te_w.clear(); lv.plan.te_w.shrink_to_fit();
+        lv.plan.gat16.clear(); lv.plan.gat16.shrink_to_fit();
         lv.plan.nbr16.clear(); lv.plan.nbr16.shrink_to_fit();
         if (lv.has_transfer) {
             lv.dp.child_ptr = dev_upload(P.child_ptr);
@@ -602,6 +627,13 @@ int mgcfd_set_option(mgcfd_solver *s, int option, int value)
             default: throw std::invalid_argument("unknown option");
         }
     });
+}
+int mgcfd_level_has_edge_once(const mgcfd_solver *s, int level, int *yes)
+{
+    REQUIRE(s); REQUIRE(yes);
+    if (level < 0 || level >= static_cast<int>(s->L.size())) { g_last_error = "level out of range"; return MGCFD_ERR_ARG; }
+    *yes = s->L[static_cast<size_t>(level)].dp.edge_once;
+    return MGCFD_OK;
 }
 int mgcfd_get_option(const mgcfd_solver *s, int option, int *value)
 {

@@ -16,7 +16,8 @@ from .meshgen import EDGE_DTYPE, LevelMesh, MultigridMesh, to_edge_arrays
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(PKG_DIR, "..", "csrc"))
-LIB_PATH = os.path.join(CSRC_DIR, "libmgcfd_hip.so")
+# MGCFD_LIB overrides the library path (profiling builds; tools/exp_variants.py)
+LIB_PATH = os.environ.get("MGCFD_LIB") or os.path.join(CSRC_DIR, "libmgcfd_hip.so")
 
 NVAR = 5
 RK = 3
@@ -63,6 +64,7 @@ _SIGNATURES = [
     ("mgcfd_halo_unpack", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     ("mgcfd_destroy", None, [_vp]),
     ("mgcfd_set_option", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("mgcfd_level_has_edge_once", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_get_option", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_set_stream", C.c_int, [_vp, _vp]),
     ("mgcfd_synchronize", C.c_int, [_vp]),
@@ -258,13 +260,25 @@ class Solver:
     def set_option(self, name: str, value: int):
         self._c(self.lib.mgcfd_set_option(self.handle, OPT[name], int(value)))
 
+    def has_edge_once(self, l: int) -> bool:
+        v = C.c_int()
+        self._c(self.lib.mgcfd_level_has_edge_once(self.handle, l, C.byref(v)))
+        return bool(v.value)
+
     def get_option(self, name: str) -> int:
         v = C.c_int()
         self._c(self.lib.mgcfd_get_option(self.handle, OPT[name], C.byref(v)))
         return v.value
 
     def set_stream(self, stream_handle: Optional[int]):
-        self._c(self.lib.mgcfd_set_stream(self.handle, _vp(stream_handle) if stream_handle else None))
+        """Run this solver's work on an existing HIP stream (e.g. torch.cuda.Stream().cuda_stream);
+        None restores the solver's own non-blocking stream.  Handle 0 is the legacy default stream,
+        which the library cannot share (its own stream does not synchronise with it): refused, so that
+        work torch enqueues (collectives, copies) is never silently unordered with the kernels."""
+        if stream_handle is not None and int(stream_handle) == 0:
+            raise ValueError("stream handle 0 is the legacy default stream; make a torch.cuda.Stream() current "
+                             "(torch.cuda.set_stream) and pass its .cuda_stream, or pass None for the solver's own stream")
+        self._c(self.lib.mgcfd_set_stream(self.handle, _vp(stream_handle) if stream_handle is not None else None))
 
     def synchronize(self):
         self._c(self.lib.mgcfd_synchronize(self.handle))

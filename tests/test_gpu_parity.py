@@ -146,10 +146,11 @@ def test_restrict_and_prolong(setup, oracle, exact):
     solver.set_option("exact", 1)
 
 
-def _run_both(mgcfd, oracle, directory, cycles, exact, indirect_rw=False, duplicate=1, fuse=True):
+def _run_both(mgcfd, oracle, directory, cycles, exact, indirect_rw=False, duplicate=1, fuse=True, variant=0):
     mesh = mgcfd.Mesh("input.dat", directory, duplicate)
     solver = mgcfd.Solver.from_mesh(mesh)
     solver.set_option("exact", int(exact))
+    solver.set_option("flux_variant", variant)
     solver.set_option("fuse_update", int(fuse))
     solver.set_option("indirect_rw", int(indirect_rw))
     rms = solver.run_cycles(cycles)
@@ -174,6 +175,68 @@ def _run_both(mgcfd, oracle, directory, cycles, exact, indirect_rw=False, duplic
 def test_vcycles_three_levels(oracle, mesh3_dir, exact, fuse):
     import mgcfd
     _run_both(mgcfd, oracle, mesh3_dir, 4, exact, fuse=fuse)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_vcycles_flux_variants(oracle, mesh3_dir, variant, fuse):
+    """Every flux variant (length factor streamed / recomputed, node gather / edge-once tiles) runs the
+    same V-cycles bit-identically to the oracle."""
+    import mgcfd
+    _run_both(mgcfd, oracle, mesh3_dir, 4, True, fuse=fuse, variant=variant)
+    _run_both(mgcfd, oracle, mesh3_dir, 2, False, fuse=fuse, variant=variant)
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+def test_edge_once_on_ragged_tiles_and_fallback(oracle, variant):
+    """Edge-once tiles on a random graph of degree 4: every tile's halo overflows the LDS tile, so
+    end points come from the overflow table; each class on its own onto a non-zero flux array and all
+    at once.  A degree-10 graph holds more edges per tile than the variant supports: the level must
+    report that and the launch must fall back to the node gather — same bits either way."""
+    import ctypes as C
+    import mgcfd
+    from mgcfd import meshgen
+    lib = oracle.load()
+    ff = oracle.farfield()
+    for degree, expect in ((4, True), (10, False)):
+        lvl = meshgen.make_random_graph_level(2500, degree=degree, seed=11 + degree)
+        mg = meshgen.MultigridMesh(mesh_name="m6wing", levels=[lvl])
+        L = mgcfd.generated_to_levels(mg)[0]
+        s = mgcfd.Solver.from_arrays([L], mg.mesh_variant)
+        assert s.has_edge_once(0) == expect
+        s.set_option("flux_variant", variant)
+        edges = np.ascontiguousarray(L["edges"]).copy()
+        coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+        lib.ora_adjust_ewt(oracle.ptr(coords), len(edges), oracle.ptr(edges))
+        lib.ora_dampen_ewt(len(edges), oracle.ptr(edges), 5e-8)
+        assert np.array_equal(s.get_edges(0, len(edges)), edges)
+        ni, nb, nw = L["n_internal"], L["n_boundary"], L["n_wall"]
+        q = perturbed_state(L["nel"], ff.var, seed=60 + degree)
+        f0 = np.random.default_rng(degree).normal(size=(L["nel"], 5))
+        s.set(0, "variables", q)
+        s.set(0, "fluxes", f0)
+        want = f0.copy()
+        lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(want))
+        s.compute_flux_edge(0)
+        _assert_close(s.get(0, "fluxes"), want, True, f"degree {degree}: internal class onto a non-zero array")
+        s.zero_fluxes(0)
+        s.compute_fluxes(0)
+        want = np.zeros_like(q)
+        lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(want))
+        lib.ora_compute_boundary_flux_edge(ni, nb, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(want))
+        lib.ora_compute_wall_flux_edge(ni + nb, nw, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(want), C.byref(ff))
+        _assert_close(s.get(0, "fluxes"), want, True, f"degree {degree}: all classes")
+        # fused sweeps equal the node gather's (both from a zero flux array)
+        s.zero_fluxes(0)
+        s.set(0, "variables", q)
+        s.smooth(0, 2)
+        got = s.get(0, "variables")
+        s.set_option("flux_variant", 0)
+        s.zero_fluxes(0)
+        s.set(0, "variables", q)
+        s.smooth(0, 2)
+        assert np.array_equal(got.view(np.int64), s.get(0, "variables").view(np.int64))
+        s.close()
 
 
 def test_vcycles_with_indirect_rw_and_duplication(oracle, mesh_dir):
@@ -413,12 +476,15 @@ def test_sharded_sweep_hooks_equal_smooth(mesh3_dir):
             s.smooth(0, 3)
             rms = s.calc_rms(0)
         else:
-            s.set_stream(torch.cuda.current_stream().cuda_stream)
+            st = torch.cuda.Stream()
+            torch.cuda.set_stream(st)
+            s.set_stream(st.cuda_stream)
             sw = ShardedSweep(HipSolverAdapter(s, torch.device("cuda", 0)), None, fused=mode.startswith("sharded-fused"))
             sw.overlap_even_alone = mode.endswith("overlap")      # the path a multi-rank run takes
             for _ in range(3):
                 sw.sweep(0)
             rms = sw.rms(0, s.nel(0))
+        torch.cuda.set_stream(torch.cuda.default_stream())
         results.append((s.get(0, "variables"), s.get(0, "residuals"), s.get(0, "step_factors"), rms))
         s.close()
     for other in results[1:]:
@@ -485,7 +551,8 @@ def test_ragged_tiles_overflow_the_lds_halo(oracle, exact):
     s.close()
 
 
-def test_partitioned_level_with_halo_exchange_equals_whole_mesh():
+@pytest.mark.parametrize("variant", [0, 2])
+def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant):
     """BASELINE config 5 in miniature: one level split into 3 parts with ghost nodes, every RK stage
     followed by a halo exchange (packed / unpacked on the GPU), global-min time step over all parts.
     The three parts run as three solvers on this one GPU, threads standing in for ranks and an
@@ -511,7 +578,10 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh():
     want_v, want_res, want_rms = whole.get(0, "variables"), whole.get(0, "residuals"), whole.calc_rms(0)
     whole.close()
 
-    stream = torch.cuda.current_stream().cuda_stream
+    # one explicit stream for all three parts and the in-process copies (each thread makes it current):
+    # the library's own streams are non-blocking and would not be ordered with torch's copies
+    tstream = torch.cuda.Stream()
+    stream = tstream.cuda_stream
     solvers, sweepers = [], []
     barrier = threading.Barrier(n_parts)
 
@@ -531,6 +601,7 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh():
 
     for P in parts:
         s = mgcfd.Solver.from_arrays([P.level], mg.mesh_variant, n_owned=[P.n_owned])
+        s.set_option("flux_variant", variant)
         s.set_stream(stream)
         s.set(0, "variables", q0[P.global_ids])          # ghosts start current
         solvers.append(s)
@@ -541,6 +612,7 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh():
     def run(sw):
         try:
             torch.cuda.set_device(0)
+            torch.cuda.set_stream(tstream)                # the current stream is per thread
             for _ in range(sweeps):
                 sw.sweep()
         except Exception as e:                           # pragma: no cover
@@ -571,7 +643,11 @@ def test_min_scalar_aliases_device_memory(mesh3_dir):
     import mgcfd
     from mgcfd.distributed import HipSolverAdapter
     s = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", mesh3_dir))
-    s.set_stream(torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(ValueError):
+        s.set_stream(0)                                   # the legacy default stream cannot be shared
+    st = torch.cuda.Stream()
+    torch.cuda.set_stream(st)
+    s.set_stream(st.cuda_stream)
     s.set(0, "variables", perturbed_state(s.nel(0), s.far_field()[:5], seed=3))
     ad = HipSolverAdapter(s, torch.device("cuda", 0))
     s.step_factor_local(0)
@@ -584,6 +660,7 @@ def test_min_scalar_aliases_device_memory(mesh3_dir):
     t.fill_(0.25 * m)                      # what an all-reduce(MIN) with a smaller remote value does
     s.step_factor_apply(0)
     assert np.array_equal(s.get(0, "step_factors"), (0.25 * m) / vol)
+    torch.cuda.set_stream(torch.cuda.default_stream())
     s.close()
 
 

@@ -34,6 +34,13 @@ struct FusedStep {
     const int32_t *old_of_new = nullptr;
     unsigned long long *err = nullptr;
     int check = 0;
+    // last stage extras
+    double *old_out = nullptr;                // != nullptr: the sweep's start state (this launch's old_variables values) is written here
+                                              // (a sweep that aliases old_variables to the state it started from materialises the array here)
+    // look-ahead for the NEXT sweep on this level, from the state this launch produces:
+    double *next_partial_min = nullptr;       // first half of compute_step_factor: per-tile minima of 0.5*cbrt(vol)/(|v|+c)
+    const double *cbrt_vol = nullptr;
+    int next_legacy = 0;                      // mesh_name = fvcorr: step_factors[i] = 0.5/(sqrt(vol)*(|v|+c)) (cfd_loops.cpp:37-61)
 };
 
 // Device pointers of one level's gather plan.

@@ -339,40 +339,68 @@ __device__ __forceinline__ Flux5 edge_flux(const NodeQ &me, const FluxC &fm, con
 template <bool FUSE>
 __device__ __forceinline__ void finish_node(int64_t i, int64_t nel, int64_t stride, double a0, double a1, double a2,
                                             double a3, double a4, double *__restrict__ fluxes, const FusedStep &fs,
-                                            double min_dt)
+                                            double min_dt, unsigned t)
 {
-    if (i >= nel) return;
     if (!FUSE) {
-        fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
-        fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
+        if (i < nel) {
+            fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
+            fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
+        }
         return;
     }
+    // ---- fused time_step: same operations as k_time_step on the flux just summed ----
     // (operands fetched here, not under the row loop: the loop already sits at the register budget
     //  of 3 waves per SIMD and hoisting these twelve registers makes it spill)
-    const double r0 = fs.old_variables[i], r1 = fs.old_variables[stride + i], r2 = fs.old_variables[2 * stride + i],
-                 r3 = fs.old_variables[3 * stride + i], r4 = fs.old_variables[4 * stride + i];
-    double sf;
-    if (fs.partial_min) {                       // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
-        sf = min_dt / fs.volumes[i];
-        fs.step_factors[i] = sf;
-    } else {
-        sf = fs.step_factors[i];
+    double sf_next = __longlong_as_double(0x7FF0000000000000LL);          // +inf: lanes past nel
+    if (i < nel) {
+        const double r0 = fs.old_variables[i], r1 = fs.old_variables[stride + i], r2 = fs.old_variables[2 * stride + i],
+                     r3 = fs.old_variables[3 * stride + i], r4 = fs.old_variables[4 * stride + i];
+        double sf;
+        if (fs.partial_min) {                       // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
+            sf = min_dt / fs.volumes[i];
+            fs.step_factors[i] = sf;
+        } else {
+            sf = fs.step_factors[i];
+        }
+        const double factor = sf / fs.rk_div;
+        const double rho = r0 + factor * a0, mx = r1 + factor * a1, my = r2 + factor * a2, mz = r3 + factor * a3,
+                     en = r4 + factor * a4;
+        // q_out may be the array old_variables points at (last stage, in place): this thread has read
+        // its node's old values above and nobody else reads them
+        store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
+        if (fs.old_out) store_conserved(fs.old_out, stride, i, r0, r1, r2, r3, r4);
+        if (fs.residuals) {
+            fs.residuals[i] = rho - r0; fs.residuals[stride + i] = mx - r1; fs.residuals[2 * stride + i] = my - r2;
+            fs.residuals[3 * stride + i] = mz - r3; fs.residuals[4 * stride + i] = en - r4;
+        }
+        if (fs.check) {
+            const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
+            int code = 0;
+            if (!finite) code = 1;
+            else if (rho < 0.0) code = 2;
+            else if (en < 0.0) code = 3;
+            if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
+        }
+        // look-ahead: the next sweep's compute_step_factor starts from the state just produced
+        if (fs.next_partial_min) {
+            const Derived d = derive(rho, mx, my, mz, en);
+            const double dt = fs.cbrt_vol[i] / (d.speed + d.c);          // k_step_factor_local
+            sf_next = 0.5 * dt;
+        } else if (fs.next_legacy) {
+            const Derived d = derive(rho, mx, my, mz, en);
+            fs.step_factors[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
+        }
     }
-    const double factor = sf / fs.rk_div;
-    const double rho = r0 + factor * a0, mx = r1 + factor * a1, my = r2 + factor * a2, mz = r3 + factor * a3,
-                 en = r4 + factor * a4;
-    store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
-    if (fs.residuals) {
-        fs.residuals[i] = rho - r0; fs.residuals[stride + i] = mx - r1; fs.residuals[2 * stride + i] = my - r2;
-        fs.residuals[3 * stride + i] = mz - r3; fs.residuals[4 * stride + i] = en - r4;
-    }
-    if (fs.check) {
-        const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
-        int code = 0;
-        if (!finite) code = 1;
-        else if (rho < 0.0) code = 2;
-        else if (en < 0.0) code = 3;
-        if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
+    if (fs.next_partial_min) {                      // uniform: every thread of the workgroup takes part
+        __shared__ double s_next[kBlock / 64];
+        sf_next = wave_min(sf_next);
+        if ((threadIdx.x & 63) == 0) s_next[threadIdx.x >> 6] = sf_next;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double m = s_next[0];
+            for (int wv = 1; wv < kBlock / 64; wv++) m = fmin(m, s_next[wv]);
+            fs.next_partial_min[t] = m;
+        }
     }
 }
 
@@ -405,12 +433,14 @@ __device__ __forceinline__ void boundary_rows(const NodeQ &me, const FluxC &fm, 
 
 template <int MINW, bool LOADK, bool FUSE, bool ACC>
 __global__ void __launch_bounds__(kBlock, MINW)
-k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
+k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at wave launch (Makefile:
+            // -amdgpu-kernarg-preload-count): what the first loads of the prologue need comes first
+            const double *__restrict__ q, const int32_t *__restrict__ tile_halo, uint32_t n_tiles, int32_t pad_row,
+            int64_t stride, int64_t nel, const int32_t *__restrict__ slice_row0,
             const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
             const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
-            const int32_t *__restrict__ tile_halo,
             const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
-            double *__restrict__ fluxes, int classes, FusedStep fs, int32_t pad_row)
+            double *__restrict__ fluxes, int classes, FusedStep fs)
 {
     __shared__ double2 tile[kTileCap * kLdsRecD2];
 
@@ -422,7 +452,7 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const unsigned t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const unsigned t = xcd_contiguous_block(blockIdx.x, n_tiles);      // n_tiles == gridDim.x, without the hidden-argument load
     const int64_t base = int64_t(t) * kTile;
     const int64_t i = base + tid;
     const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
@@ -548,39 +578,66 @@ k_flux_tile(int64_t nel, int64_t stride, const double *__restrict__ q, const int
         }
     }
 
-    if (i >= nel) return;
     if (!FUSE) {
-        fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
-        fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
+        if (i < nel) {
+            fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
+            fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
+        }
         return;
     }
     // ---- fused time_step: same operations as k_time_step on the flux just summed ----
     // (operands fetched here, not under the row loop: the loop already sits at the register budget
     //  of 3 waves per SIMD and hoisting these twelve registers makes it spill)
-    const double r0 = fs.old_variables[i], r1 = fs.old_variables[stride + i], r2 = fs.old_variables[2 * stride + i],
-                 r3 = fs.old_variables[3 * stride + i], r4 = fs.old_variables[4 * stride + i];
-    double sf;
-    if (fs.partial_min) {                       // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
-        sf = min_dt / fs.volumes[i];
-        fs.step_factors[i] = sf;
-    } else {
-        sf = fs.step_factors[i];
+    double sf_next = __longlong_as_double(0x7FF0000000000000LL);          // +inf: lanes past nel
+    if (i < nel) {
+        const double r0 = fs.old_variables[i], r1 = fs.old_variables[stride + i], r2 = fs.old_variables[2 * stride + i],
+                     r3 = fs.old_variables[3 * stride + i], r4 = fs.old_variables[4 * stride + i];
+        double sf;
+        if (fs.partial_min) {                       // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
+            sf = min_dt / fs.volumes[i];
+            fs.step_factors[i] = sf;
+        } else {
+            sf = fs.step_factors[i];
+        }
+        const double factor = sf / fs.rk_div;
+        const double rho = r0 + factor * a0, mx = r1 + factor * a1, my = r2 + factor * a2, mz = r3 + factor * a3,
+                     en = r4 + factor * a4;
+        // q_out may be the array old_variables points at (last stage, in place): this thread has read
+        // its node's old values above and nobody else reads them
+        store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
+        if (fs.old_out) store_conserved(fs.old_out, stride, i, r0, r1, r2, r3, r4);
+        if (fs.residuals) {
+            fs.residuals[i] = rho - r0; fs.residuals[stride + i] = mx - r1; fs.residuals[2 * stride + i] = my - r2;
+            fs.residuals[3 * stride + i] = mz - r3; fs.residuals[4 * stride + i] = en - r4;
+        }
+        if (fs.check) {
+            const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
+            int code = 0;
+            if (!finite) code = 1;
+            else if (rho < 0.0) code = 2;
+            else if (en < 0.0) code = 3;
+            if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
+        }
+        // look-ahead: the next sweep's compute_step_factor starts from the state just produced
+        if (fs.next_partial_min) {
+            const Derived d = derive(rho, mx, my, mz, en);
+            const double dt = fs.cbrt_vol[i] / (d.speed + d.c);          // k_step_factor_local
+            sf_next = 0.5 * dt;
+        } else if (fs.next_legacy) {
+            const Derived d = derive(rho, mx, my, mz, en);
+            fs.step_factors[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
+        }
     }
-    const double factor = sf / fs.rk_div;
-    const double rho = r0 + factor * a0, mx = r1 + factor * a1, my = r2 + factor * a2, mz = r3 + factor * a3,
-                 en = r4 + factor * a4;
-    store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
-    if (fs.residuals) {
-        fs.residuals[i] = rho - r0; fs.residuals[stride + i] = mx - r1; fs.residuals[2 * stride + i] = my - r2;
-        fs.residuals[3 * stride + i] = mz - r3; fs.residuals[4 * stride + i] = en - r4;
-    }
-    if (fs.check) {
-        const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
-        int code = 0;
-        if (!finite) code = 1;
-        else if (rho < 0.0) code = 2;
-        else if (en < 0.0) code = 3;
-        if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
+    if (fs.next_partial_min) {                      // uniform: every thread of the workgroup takes part
+        __shared__ double s_next[kBlock / 64];
+        sf_next = wave_min(sf_next);
+        if ((threadIdx.x & 63) == 0) s_next[threadIdx.x >> 6] = sf_next;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double m = s_next[0];
+            for (int wv = 1; wv < kBlock / 64; wv++) m = fmin(m, s_next[wv]);
+            fs.next_partial_min[t] = m;
+        }
     }
 }
 
@@ -624,21 +681,22 @@ __device__ __forceinline__ TileEdge no_tile_edge()
 
 template <bool LOADK, bool FUSE, bool ACC>
 __global__ void __launch_bounds__(kBlock, 3)
-k_flux_edge_once(int64_t nel, int64_t stride, const double *__restrict__ q, const int32_t *__restrict__ slice_row0,
+k_flux_edge_once(const double *__restrict__ q, const int32_t *__restrict__ tile_halo, uint32_t n_tiles, int32_t pad_row,
+                 int64_t stride, int64_t nel, const int32_t *__restrict__ te_chunk_ptr,
+                 const int32_t *__restrict__ te_count, int32_t pad_chunk, int classes,
+                 const int32_t *__restrict__ slice_row0,
                  const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
                  const uint16_t *__restrict__ nbr16, const double *__restrict__ w, const uint16_t *__restrict__ gat16,
-                 const int32_t *__restrict__ te_chunk_ptr, const int32_t *__restrict__ te_count,
                  const uint16_t *__restrict__ te_slots, const double *__restrict__ te_w,
-                 const int32_t *__restrict__ tile_halo,
                  const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
-                 double *__restrict__ fluxes, int classes, FusedStep fs, int32_t pad_chunk, int32_t pad_row)
+                 double *__restrict__ fluxes, FusedStep fs)
 {
     __shared__ double2 tile[kTileCap * kLdsRecD2];
 
     double min_dt = 0.0;
     if (FUSE && fs.partial_min) min_dt = block_min_of_partials(fs.partial_min, fs.n_partial);
 
-    const unsigned t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const unsigned t = xcd_contiguous_block(blockIdx.x, n_tiles);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_base = tid & ~63;                 // first list position of this wave within a chunk
@@ -749,7 +807,7 @@ k_flux_edge_once(int64_t nel, int64_t stride, const double *__restrict__ q, cons
         boundary_rows(me, flux_contribution(me), ff, nbr16, w, int64_t(row0) + n_int, n_bnd, lane, classes, a0, a1, a2, a3, a4);
     }
 
-    finish_node<FUSE>(i, nel, stride, a0, a1, a2, a3, a4, fluxes, fs, min_dt);
+    finish_node<FUSE>(i, nel, stride, a0, a1, a2, a3, a4, fluxes, fs, min_dt, t);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1061,18 +1119,18 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     if (fused) fs = *fused;
     // 3 tiles of 52.5 KiB LDS fit a CU => at least 3 waves per SIMD wanted
 #define MGCFD_TILE_LAUNCH(LOADK, FUSE, ACC)                                                                    \
-    hipLaunchKernelGGL((k_flux_tile<3, LOADK, FUSE, ACC>), grid, block,  0, st, p.nel, p.stride, q,            \
-                       p.slice_row0, p.rows_int, p.rows_bnd, p.nbr16, p.w, p.tile_halo,                        \
-                       p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs, p.pad_row)
+    hipLaunchKernelGGL((k_flux_tile<3, LOADK, FUSE, ACC>), grid, block, 0, st, q, p.tile_halo,                 \
+                       uint32_t(p.n_tiles), p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.rows_bnd,  \
+                       p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs)
     const bool loadk = (variant & 1) == 0;      // odd variants recompute k = -|e|*s*0.5 from the weights
     // variants 2, 3: every edge evaluated once per tile (needs the internal class and a level whose
     // tiles fit the edge-once limits; otherwise the node gather below)
     if ((variant & 2) && p.edge_once && (classes & 1)) {
 #define MGCFD_EO_LAUNCH(LOADK, FUSE, ACC)                                                                      \
-    hipLaunchKernelGGL((k_flux_edge_once<LOADK, FUSE, ACC>), grid, block, 0, st, p.nel, p.stride, q,           \
-                       p.slice_row0, p.rows_int, p.rows_bnd, p.nbr16, p.w, p.gat16, p.te_chunk_ptr,            \
-                       p.te_count, p.te_slots, p.te_w, p.tile_halo, p.tile_ovf_ptr,           \
-                       p.tile_ovf, ff, fluxes, classes, fs, p.pad_chunk, p.pad_row)
+    hipLaunchKernelGGL((k_flux_edge_once<LOADK, FUSE, ACC>), grid, block, 0, st, q, p.tile_halo,               \
+                       uint32_t(p.n_tiles), p.pad_row, p.stride, p.nel, p.te_chunk_ptr, p.te_count,            \
+                       p.pad_chunk, classes, p.slice_row0, p.rows_int, p.rows_bnd, p.nbr16, p.w, p.gat16,      \
+                       p.te_slots, p.te_w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, fs)
         if (fused) {
             if (loadk) MGCFD_EO_LAUNCH(true, true, false); else MGCFD_EO_LAUNCH(false, true, false);
         } else if (accumulate) {

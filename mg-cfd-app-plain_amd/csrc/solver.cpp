@@ -61,6 +61,13 @@ struct DeviceLevel {
     // SoA state, stride = dp.stride: q = the reference's `variables`
     double *q = nullptr, *old_variables = nullptr, *fluxes = nullptr, *residuals = nullptr;   // [5][stride]
     double *q_alt = nullptr;             // [5][stride] second state buffer for the fused RK stages
+    // The three state buffers change roles after every fused sweep (no copy<double>(old, variables)):
+    // variables = state[rot], q_alt = state[rot+1], old_variables = state[rot+2] (mod 3).
+    double *state[3] = {nullptr, nullptr, nullptr};
+    int rot = 0;
+    void apply_rot() { q = state[rot % 3]; q_alt = state[(rot + 1) % 3]; old_variables = state[(rot + 2) % 3]; }
+    bool min_ahead = false;              // partial_min already holds the first half of compute_step_factor for the
+                                         // CURRENT variables (written by the stage that produced them)
     double *step_factors = nullptr, *volumes = nullptr, *cbrt_vol = nullptr;                  // [stride]
     double *min_dt = nullptr;            // global-min time step scalar (after the reduction)
     double *partial_min = nullptr;       // one partial minimum per step-factor workgroup
@@ -96,9 +103,9 @@ struct mgcfd_solver {
     int timing_stride = 8;                  // OPT_TIMING == 2: bracket the flux launches of every Nth sweep
     int64_t sweep_counter = 0;
     bool in_timed_group = false;
-    struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; };
+    struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; bool ahead_after = false; int rot_after = 0; };
     std::map<uint64_t, SweepGraph> sweep_graphs;   // captured smoothing sweeps, keyed by (level, options)
-    struct CycleGraph { hipGraphExec_t exec = nullptr; std::vector<std::vector<int64_t>> iters; };
+    struct CycleGraph { hipGraphExec_t exec = nullptr; std::vector<std::vector<int64_t>> iters; std::vector<bool> ahead_after; std::vector<int> rot_after; };
     std::map<uint64_t, CycleGraph> cycle_graphs;   // captured whole multigrid cycles, keyed by options
     static constexpr int kRmsRing = 4096;
     double *rms_ring = nullptr;                    // level-0 sum of squares of the cycles run since the last read-back
@@ -171,6 +178,7 @@ struct mgcfd_solver {
     void op_step_factor_local(int l, bool fuse_copy_old, bool reduce_to_scalar)
     {
         DeviceLevel &lv = level(l);
+        lv.min_ahead = false;                       // partial_min is rewritten (same values if it was ahead)
         double *old = fuse_copy_old ? lv.old_variables : nullptr;
         if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.partial_min, old);
         else fast::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.partial_min, old);
@@ -191,17 +199,17 @@ struct mgcfd_solver {
     }
     // fused = true: also copy old_variables <- variables, and leave the "/ volume" half of the
     // global time step to the first time_step of the sweep (returns true in that case)
-    bool op_step_factor(int l, bool fused = false)
+    bool op_step_factor(int l, bool fused = false, bool copy_old = true)
     {
         DeviceLevel &lv = level(l);
         Timed t(this, l, MGCFD_LOOP_COMPUTE_STEP);
         bool apply_pending = false;
         if (mesh_variant == MGCFD_MESH_FVCORR) {
-            double *old = fused ? lv.old_variables : nullptr;
+            double *old = (fused && copy_old) ? lv.old_variables : nullptr;
             if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors, old);
             else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors, old);
         } else {
-            op_step_factor_local(l, fused, !fused);
+            op_step_factor_local(l, fused && copy_old, !fused);
             if (fused) apply_pending = true;
             else op_step_factor_apply(l);
         }
@@ -224,14 +232,22 @@ struct mgcfd_solver {
     // One whole Runge-Kutta stage in one launch: fluxes of all edge classes from `in`, then
     // time_step into `out` (in != out).  fluxes[] stays logically zero, as after time_step.
     // apply_min: 0 no, 1 from the workgroups' partial minima, 2 from the (all-reduced) scalar
-    void op_fused_stage(int l, int j, const double *in, double *out, int apply_min, bool with_residual)
+    // old: where the sweep's start state is read from (default: old_variables); old_out: where the
+    // stage also writes that state (a sweep that aliased old to variables materialises old_variables
+    // in its last stage); look_ahead: the stage leaves the next sweep's partial minima in partial_min
+    void op_fused_stage(int l, int j, const double *in, double *out, int apply_min, bool with_residual,
+                        const double *old = nullptr, double *old_out = nullptr, bool look_ahead = false)
     {
         DeviceLevel &lv = level(l);
         FusedStep fs;
         fs.rk_div = double(MGCFD_RK + 1 - j);
         fs.step_factors = lv.step_factors;
-        fs.old_variables = lv.old_variables;
+        fs.old_variables = old ? old : lv.old_variables;
         fs.q_out = out;
+        fs.old_out = old_out;
+        fs.next_partial_min = look_ahead ? lv.partial_min : nullptr;
+        fs.cbrt_vol = lv.cbrt_vol;
+        if (out == lv.q) lv.min_ahead = false;      // (a caller that looks ahead sets it after its last stage)
         fs.partial_min = apply_min == 1 ? lv.partial_min : (apply_min == 2 ? lv.min_dt : nullptr);
         fs.n_partial = apply_min == 2 ? 1 : static_cast<int>((lv.info.nel + 255) / 256);
         fs.volumes = lv.volumes;
@@ -268,6 +284,7 @@ struct mgcfd_solver {
         if (j < 0 || j >= MGCFD_RK) throw std::invalid_argument("RK stage out of range");
         DeviceLevel &lv = level(l);
         settle_fluxes(lv);
+        lv.min_ahead = false;
         Timed t(this, l, MGCFD_LOOP_TIME_STEP);
         const double *pm = apply_min == 1 ? lv.partial_min : (apply_min == 2 ? lv.min_dt : nullptr);
         const int n_pm = apply_min == 2 ? 1 : static_cast<int>((lv.info.nel + 255) / 256);
@@ -297,6 +314,7 @@ struct mgcfd_solver {
         if (!F.has_transfer) throw std::invalid_argument("level has no multigrid map");
         // Timer / iteration attribution quirk: the reference bumps `level` before the call,
         // so restriction is booked to the COARSE level.
+        C.min_ahead = false;
         Timed t(this, fine + 1, MGCFD_LOOP_RESTRICT);
         if (opt_exact) exact::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q);
         else fast::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q);
@@ -307,6 +325,7 @@ struct mgcfd_solver {
         DeviceLevel &F = level(fine);
         DeviceLevel &C = level(fine + 1);
         if (!F.has_transfer) throw std::invalid_argument("level has no multigrid map");
+        F.min_ahead = false;
         Timed t(this, fine, MGCFD_LOOP_PROLONG);
         if (opt_exact) exact::launch_prolong(stream, F.dp, C.dp.stride, C.residuals, F.residuals, F.q);
         else fast::launch_prolong(stream, F.dp, C.dp.stride, C.residuals, F.residuals, F.q);
@@ -435,6 +454,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.q = dev_alloc<double>(static_cast<size_t>(stride) * kNumStateFields);
         lv.q_alt = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.old_variables = dev_alloc<double>(static_cast<size_t>(stride) * 5);
+        lv.state[0] = lv.q; lv.state[1] = lv.q_alt; lv.state[2] = lv.old_variables;
         lv.fluxes = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.residuals = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.step_factors = dev_alloc<double>(static_cast<size_t>(stride));
@@ -740,18 +760,34 @@ int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_c
 // the three edge classes share one flux launch.
 static void smooth_once(mgcfd_solver *s, int level)
 {
-    const bool apply_pending = s->op_step_factor(level, true);     // :383 + :388-395
     DeviceLevel &lv = s->level(level);
     if (s->opt_fuse && !s->opt_indirect_rw && s->opt_timing != 1 && lv.fluxes_zero) {
-        // Fused stages: flux + time_step in one launch each.  Stage 0 reads the sweep's start
-        // state from old_variables (just copied) so it can write variables in place; the state
-        // then ping-pongs variables -> q_alt -> variables.
+        // Fused stages: flux + time_step in one launch each.  No copy<double>(old_variables, variables)
+        // (:383): the sweep's start state stays where it is and BECOMES old_variables; the stages run
+        // variables -> q_alt -> (the former old_variables buffer) -> q_alt, and the three buffers
+        // change roles at the end (DeviceLevel::rot).
+        const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
+        bool apply_pending = global_dt;
+        if (global_dt && lv.min_ahead) {
+            // the launch that produced `variables` already left the first half of compute_step_factor
+            // (:388-395) in partial_min
+            lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;
+        } else {
+            apply_pending = s->op_step_factor(level, true, false);
+        }
+        // single level: the next sweep starts from this sweep's result, let the last stage look ahead
+        const bool look_ahead = global_dt && s->L.size() == 1;
+        double *const start = lv.q, *const b1 = lv.q_alt, *const b2 = lv.old_variables;
         mgcfd_solver::Timed group(s, level, MGCFD_LOOP_FLUX, true, s->opt_timing == 2 ? MGCFD_RK : 1);
-        s->op_fused_stage(level, 0, lv.old_variables, lv.q, apply_pending ? 1 : 0, false);
-        s->op_fused_stage(level, 1, lv.q, lv.q_alt, 0, false);
-        s->op_fused_stage(level, 2, lv.q_alt, lv.q, 0, true);      // + :508
+        s->op_fused_stage(level, 0, start, b1, apply_pending ? 1 : 0, false, start);
+        s->op_fused_stage(level, 1, b1, b2, 0, false, start);
+        s->op_fused_stage(level, 2, b2, b1, 0, true, start, nullptr, look_ahead);   // + :508
+        lv.rot = (lv.rot + 1) % 3;                 // variables = b1, q_alt = b2, old_variables = start
+        lv.apply_rot();
+        lv.min_ahead = look_ahead;
         return;
     }
+    const bool apply_pending = s->op_step_factor(level, true);     // :383 + :388-395
     for (int j = 0; j < MGCFD_RK; j++) {                           // :397-506
         s->op_flux(level, 7);
         // the indirect_rw probe reads fluxes[] right after, so zero for real when it is on
@@ -776,7 +812,7 @@ static void run_sweep(mgcfd_solver *s, int level)
         s->opt_timing = keep;
         return;
     }
-    const uint64_t key = (uint64_t(level) << 32) | (uint64_t(s->opt_exact) << 16) | (uint64_t(s->opt_check) << 8) | uint64_t(s->opt_variant & 0xFF);
+    const uint64_t key = (uint64_t(level) << 32) | (uint64_t(lv.rot) << 25) | (uint64_t(lv.min_ahead) << 24) | (uint64_t(s->opt_exact) << 16) | (uint64_t(s->opt_check) << 8) | uint64_t(s->opt_variant & 0xFF);
     auto it = s->sweep_graphs.find(key);
     if (it == s->sweep_graphs.end()) {
         mgcfd_solver::SweepGraph g;
@@ -799,9 +835,14 @@ static void run_sweep(mgcfd_solver *s, int level)
         HIP_CHECK(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
         HIP_CHECK(hipGraphDestroy(graph));
         for (int k = 0; k < MGCFD_NUM_LOOPS; k++) { g.iters[k] = lv.iters[k] - before[k]; lv.iters[k] = before[k]; }
+        g.ahead_after = lv.min_ahead;
+        g.rot_after = lv.rot;
         it = s->sweep_graphs.emplace(key, g).first;
     }
     HIP_CHECK(hipGraphLaunch(it->second.exec, s->stream));
+    lv.min_ahead = it->second.ahead_after;
+    lv.rot = it->second.rot_after;
+    lv.apply_rot();
     for (int k = 0; k < MGCFD_NUM_LOOPS; k++) lv.iters[k] += it->second.iters[k];
 }
 
@@ -890,37 +931,59 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
             HIP_CHECK(hipMemsetAsync(s->rms_count, 0, sizeof(int), s->stream));
             bool graphable = s->opt_graph && s->opt_fuse && !s->opt_indirect_rw && s->opt_timing == 0;
             for (auto &lv : s->L) graphable = graphable && lv.fluxes_zero && !lv.fluxes_stale;
+            graphable = graphable && nl <= 8;               // the graph key holds 8 levels' buffer rotations
             if (graphable) {
-                // the whole cycle — every sweep and transfer of every level — as ONE graph replay
-                const uint64_t key = (uint64_t(s->opt_exact) << 16) | (uint64_t(s->opt_check) << 8) | uint64_t(s->opt_variant & 0xFF);
-                auto it = s->cycle_graphs.find(key);
-                if (it == s->cycle_graphs.end()) {
-                    mgcfd_solver::CycleGraph g;
-                    std::vector<std::vector<int64_t>> before(nl);
-                    for (size_t l = 0; l < nl; l++) before[l].assign(s->L[l].iters, s->L[l].iters + MGCFD_NUM_LOOPS);
-                    hipGraph_t graph = nullptr;
-                    HIP_CHECK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
-                    try {
-                        cycle_once(s, true);
-                    } catch (...) {
-                        (void)hipStreamEndCapture(s->stream, &graph);
-                        if (graph) (void)hipGraphDestroy(graph);
-                        throw;
-                    }
-                    HIP_CHECK(hipStreamEndCapture(s->stream, &graph));
-                    HIP_CHECK(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
-                    HIP_CHECK(hipGraphDestroy(graph));
-                    g.iters.resize(nl);
-                    for (size_t l = 0; l < nl; l++)
-                        for (int k = 0; k < MGCFD_NUM_LOOPS; k++) {
-                            g.iters[l].push_back(s->L[l].iters[k] - before[l][static_cast<size_t>(k)]);
-                            s->L[l].iters[k] = before[l][static_cast<size_t>(k)];
+                // the whole cycle — every sweep and transfer of every level — as ONE graph replay.
+                // The launch sequence depends on which levels enter with their step-factor minima
+                // already computed (min_ahead), so that is part of the key and looked up per cycle.
+                for (int c = 0; c < chunk; c++) {
+                    uint64_t key = (uint64_t(s->opt_exact) << 16) | (uint64_t(s->opt_check) << 8) | uint64_t(s->opt_variant & 0xFF);
+                    for (size_t l = 0; l < nl && l < 8; l++) key |= (uint64_t(s->L[l].min_ahead) << (24 + l)) | (uint64_t(s->L[l].rot) << (32 + 2 * l));
+                    auto it = s->cycle_graphs.find(key);
+                    if (it == s->cycle_graphs.end()) {
+                        mgcfd_solver::CycleGraph g;
+                        std::vector<std::vector<int64_t>> before(nl);
+                        std::vector<bool> ahead_before;
+                        std::vector<int> rot_before;
+                        for (size_t l = 0; l < nl; l++) {
+                            before[l].assign(s->L[l].iters, s->L[l].iters + MGCFD_NUM_LOOPS);
+                            ahead_before.push_back(s->L[l].min_ahead);
+                            rot_before.push_back(s->L[l].rot);
                         }
-                    it = s->cycle_graphs.emplace(key, std::move(g)).first;
+                        hipGraph_t graph = nullptr;
+                        HIP_CHECK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+                        try {
+                            cycle_once(s, true);
+                        } catch (...) {
+                            (void)hipStreamEndCapture(s->stream, &graph);
+                            if (graph) (void)hipGraphDestroy(graph);
+                            throw;
+                        }
+                        HIP_CHECK(hipStreamEndCapture(s->stream, &graph));
+                        HIP_CHECK(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+                        HIP_CHECK(hipGraphDestroy(graph));
+                        g.iters.resize(nl);
+                        for (size_t l = 0; l < nl; l++) {
+                            for (int k = 0; k < MGCFD_NUM_LOOPS; k++) {
+                                g.iters[l].push_back(s->L[l].iters[k] - before[l][static_cast<size_t>(k)]);
+                                s->L[l].iters[k] = before[l][static_cast<size_t>(k)];
+                            }
+                            g.ahead_after.push_back(s->L[l].min_ahead);
+                            g.rot_after.push_back(s->L[l].rot);
+                            s->L[l].min_ahead = ahead_before[l];          // nothing ran yet: capture only recorded
+                            s->L[l].rot = rot_before[l];
+                            s->L[l].apply_rot();
+                        }
+                        it = s->cycle_graphs.emplace(key, std::move(g)).first;
+                    }
+                    HIP_CHECK(hipGraphLaunch(it->second.exec, s->stream));
+                    for (size_t l = 0; l < nl; l++) {
+                        for (int k = 0; k < MGCFD_NUM_LOOPS; k++) s->L[l].iters[k] += it->second.iters[l][static_cast<size_t>(k)];
+                        s->L[l].min_ahead = it->second.ahead_after[l];
+                        s->L[l].rot = it->second.rot_after[l];
+                        s->L[l].apply_rot();
+                    }
                 }
-                for (int c = 0; c < chunk; c++) HIP_CHECK(hipGraphLaunch(it->second.exec, s->stream));
-                for (size_t l = 0; l < nl; l++)
-                    for (int k = 0; k < MGCFD_NUM_LOOPS; k++) s->L[l].iters[k] += it->second.iters[l][static_cast<size_t>(k)] * chunk;
             } else {
                 for (int c = 0; c < chunk; c++) cycle_once(s, false);
             }
@@ -994,6 +1057,7 @@ int mgcfd_set_array(mgcfd_solver *s, int level, int which, const double *in)
         HIP_CHECK(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
         HIP_CHECK(hipStreamSynchronize(s->stream));
         if (which == MGCFD_ARR_FLUXES) { lv.fluxes_zero = false; lv.fluxes_stale = false; }
+        if (which == MGCFD_ARR_VARIABLES) lv.min_ahead = false;
     });
 }
 int mgcfd_get_edges(mgcfd_solver *s, int level, mgcfd_edge *out)
@@ -1031,6 +1095,7 @@ static void halo_move(mgcfd_solver *s, int level, int plan, int which, void *dev
     double *field = array_ptr(lv, which, &nc);
     if (nc != 5) throw std::invalid_argument("halo messages carry 5-component node arrays");
     if (which == MGCFD_ARR_FLUXES) { if (pack) s->settle_fluxes(lv); else { lv.fluxes_zero = false; lv.fluxes_stale = false; } }
+    if (which == MGCFD_ARR_VARIABLES && !pack) lv.min_ahead = false;
     const auto &hp = lv.halo_plans[static_cast<size_t>(plan)];
     if (hp.second > 0 && !dev_buf) throw std::invalid_argument("null message buffer");
     if (pack) exact::launch_halo_pack(s->stream, hp.second, lv.dp.stride, hp.first, field, static_cast<double *>(dev_buf));

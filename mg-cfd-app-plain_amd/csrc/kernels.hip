@@ -221,6 +221,28 @@ __device__ __forceinline__ double block_min_of_partials(const double *__restrict
     return r;
 }
 
+// One workgroup's minimum of v -> out[blockIdx.x]; every thread of the workgroup must call it.
+__device__ __forceinline__ void block_min_to(double v, double *__restrict__ out)
+{
+    __shared__ double s_m[kBlock / 64];
+    v = wave_min(v);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = s_m[0];
+        for (int w = 1; w < kBlock / 64; w++) m = fmin(m, s_m[w]);
+        out[blockIdx.x] = m;
+    }
+}
+
+// first half of compute_step_factor for one node, as k_step_factor_local computes it
+__device__ __forceinline__ double local_step_factor(double rho, double mx, double my, double mz, double en, double cbrt_vol)
+{
+    const Derived d = derive(rho, mx, my, mz, en);
+    const double dt = cbrt_vol / (d.speed + d.c);
+    return 0.5 * dt;
+}
+
 // partial minima -> one scalar (only needed where the scalar itself is the interface: the
 // kernel-granular API and the multi-GPU all-reduce hook)
 __global__ void __launch_bounds__(kBlock)
@@ -1014,20 +1036,36 @@ __global__ void k_append_scalar(const double *__restrict__ src, double *__restri
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_restrict(int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine, const int32_t *__restrict__ child_ptr,
-           const int32_t *__restrict__ child, const double *__restrict__ fine_q, double *__restrict__ coarse_q)
+           const int32_t *__restrict__ child, const double *__restrict__ fine_q, double *__restrict__ coarse_q,
+           const double *__restrict__ cbrt_vol, double *__restrict__ partial_min /* nullptr, or: look ahead, see below */)
 {
     const int64_t c = blockIdx.x * int64_t(kBlock) + threadIdx.x;
-    if (c >= nel_coarse) return;
-    const int32_t b = child_ptr[c], e = child_ptr[c + 1];
-    if (b == e) return;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
-    for (int32_t k = b; k < e; k++) {
-        const int64_t j = child[k];
-        s0 += fine_q[j]; s1 += fine_q[stride_fine + j]; s2 += fine_q[2 * stride_fine + j];
-        s3 += fine_q[3 * stride_fine + j]; s4 += fine_q[4 * stride_fine + j];
+    double sf = __longlong_as_double(0x7FF0000000000000LL);          // +inf
+    if (c < nel_coarse) {
+        const int32_t b = child_ptr[c], e = child_ptr[c + 1];
+        double n0, n1, n2, n3, n4;
+        if (b == e) {
+            // no children: the coarse node keeps its value (mg_loops.cpp:63-78,174-189)
+            if (partial_min) {
+                n0 = coarse_q[c]; n1 = coarse_q[stride_coarse + c]; n2 = coarse_q[2 * stride_coarse + c];
+                n3 = coarse_q[3 * stride_coarse + c]; n4 = coarse_q[4 * stride_coarse + c];
+            }
+        } else {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
+            for (int32_t k = b; k < e; k++) {
+                const int64_t j = child[k];
+                s0 += fine_q[j]; s1 += fine_q[stride_fine + j]; s2 += fine_q[2 * stride_fine + j];
+                s3 += fine_q[3 * stride_fine + j]; s4 += fine_q[4 * stride_fine + j];
+            }
+            const double average = 1.0 / double(e - b);
+            n0 = s0 * average; n1 = s1 * average; n2 = s2 * average; n3 = s3 * average; n4 = s4 * average;
+            store_conserved(coarse_q, stride_coarse, c, n0, n1, n2, n3, n4);
+        }
+        // The sweep that follows on the coarse level starts with compute_step_factor on exactly these
+        // values: leave its first half (the per-workgroup minima) behind.
+        if (partial_min) sf = local_step_factor(n0, n1, n2, n3, n4, cbrt_vol[c]);
     }
-    const double average = 1.0 / double(e - b);
-    store_conserved(coarse_q, stride_coarse, c, s0 * average, s1 * average, s2 * average, s3 * average, s4 * average);
+    if (partial_min) block_min_to(sf, partial_min);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1041,12 +1079,16 @@ k_prolong(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t *__r
           const int32_t *__restrict__ rows_int, const ProlongW *__restrict__ pro,
           const int32_t *__restrict__ pro_parent, const double *__restrict__ pro_wsum,
           const double *__restrict__ coarse_residuals, const double *__restrict__ fine_residuals,
-          double *__restrict__ fine_q)
+          double *__restrict__ fine_q, const double *__restrict__ cbrt_vol,
+          double *__restrict__ partial_min /* nullptr, or: look ahead as in k_restrict */)
 {
     const int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
-    if ((int64_t(slice) << 6) >= nel) return;
+    if ((int64_t(slice) << 6) >= nel) {                              // a wave past the last node
+        if (partial_min) block_min_to(__longlong_as_double(0x7FF0000000000000LL), partial_min);
+        return;
+    }
     const bool active = i < nel;
     const int64_t ii = active ? i : nel - 1;
     const int32_t row0 = slice_row0[slice];
@@ -1077,13 +1119,18 @@ k_prolong(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t *__r
             r0 += pw.w_other * x0; r1 += pw.w_other * x1; r2 += pw.w_other * x2; r3 += pw.w_other * x3; r4 += pw.w_other * x4;
         }
     }
-    if (!active) return;
-    const double ws = pro_wsum[i];
-    fine_q[i] += fine_residuals[i] - r0 / ws;
-    fine_q[stride + i] += fine_residuals[stride + i] - r1 / ws;
-    fine_q[2 * stride + i] += fine_residuals[2 * stride + i] - r2 / ws;
-    fine_q[3 * stride + i] += fine_residuals[3 * stride + i] - r3 / ws;
-    fine_q[4 * stride + i] += fine_residuals[4 * stride + i] - r4 / ws;
+    double sf = __longlong_as_double(0x7FF0000000000000LL);          // +inf
+    if (active) {
+        const double ws = pro_wsum[i];
+        const double n0 = fine_q[i] + (fine_residuals[i] - r0 / ws);
+        const double n1 = fine_q[stride + i] + (fine_residuals[stride + i] - r1 / ws);
+        const double n2 = fine_q[2 * stride + i] + (fine_residuals[2 * stride + i] - r2 / ws);
+        const double n3 = fine_q[3 * stride + i] + (fine_residuals[3 * stride + i] - r3 / ws);
+        const double n4 = fine_q[4 * stride + i] + (fine_residuals[4 * stride + i] - r4 / ws);
+        store_conserved(fine_q, stride, i, n0, n1, n2, n3, n4);
+        if (partial_min) sf = local_step_factor(n0, n1, n2, n3, n4, cbrt_vol[i]);
+    }
+    if (partial_min) block_min_to(sf, partial_min);
 }
 
 // ==========================================================================================
@@ -1192,17 +1239,20 @@ void launch_append_scalar(hipStream_t st, const double *src, double *ring, int *
 { hipLaunchKernelGGL(k_append_scalar, dim3(1), dim3(64), 0, st, src, ring, count, cap); }
 
 void launch_restrict(hipStream_t st, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,
-                     const int32_t *child_ptr, const int32_t *child, const double *fine_q, double *coarse_q)
+                     const int32_t *child_ptr, const int32_t *child, const double *fine_q, double *coarse_q,
+                     const double *cbrt_vol, double *partial_min)
 {
     hipLaunchKernelGGL(k_restrict, dim3(grid_for(nel_coarse)), dim3(kBlock), 0, st, nel_coarse, stride_coarse,
-                       stride_fine, child_ptr, child, fine_q, coarse_q);
+                       stride_fine, child_ptr, child, fine_q, coarse_q, cbrt_vol, partial_min);
 }
 
 void launch_prolong(hipStream_t st, const DevicePlan &p, int64_t stride_coarse, const double *coarse_residuals,
-                    const double *fine_residuals, double *fine_q)
+                    const double *fine_residuals, double *fine_q, const double *cbrt_vol, double *partial_min)
 {
-    hipLaunchKernelGGL(k_prolong, dim3(grid_for(p.stride)), dim3(kBlock), 0, st, p.nel, p.stride, stride_coarse,
-                       p.slice_row0, p.rows_int, p.pro, p.pro_parent, p.pro_wsum, coarse_residuals, fine_residuals, fine_q);
+    // grid_for(nel) workgroups: the same partition k_step_factor_local's partial minima use
+    hipLaunchKernelGGL(k_prolong, dim3(grid_for(p.nel)), dim3(kBlock), 0, st, p.nel, p.stride, stride_coarse,
+                       p.slice_row0, p.rows_int, p.pro, p.pro_parent, p.pro_wsum, coarse_residuals, fine_residuals, fine_q,
+                       cbrt_vol, partial_min);
 }
 
 } // namespace MGCFD_KERNEL_NS

@@ -314,10 +314,14 @@ struct mgcfd_solver {
         if (!F.has_transfer) throw std::invalid_argument("level has no multigrid map");
         // Timer / iteration attribution quirk: the reference bumps `level` before the call,
         // so restriction is booked to the COARSE level.
-        C.min_ahead = false;
+        // the coarse sweep that follows starts with compute_step_factor on the restricted state: the
+        // kernel leaves its first half (per-workgroup minima) in partial_min (global time step only)
+        const bool ahead = mesh_variant != MGCFD_MESH_FVCORR;
+        double *pm = ahead ? C.partial_min : nullptr;
         Timed t(this, fine + 1, MGCFD_LOOP_RESTRICT);
-        if (opt_exact) exact::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q);
-        else fast::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q);
+        if (opt_exact) exact::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q, C.cbrt_vol, pm);
+        else fast::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q, C.cbrt_vol, pm);
+        C.min_ahead = ahead;
         C.iters[MGCFD_LOOP_RESTRICT] += 2 * F.info.mgc + C.info.nel;   // mg_loops.cpp:61,117,172
     }
     void op_prolong(int fine)
@@ -325,10 +329,12 @@ struct mgcfd_solver {
         DeviceLevel &F = level(fine);
         DeviceLevel &C = level(fine + 1);
         if (!F.has_transfer) throw std::invalid_argument("level has no multigrid map");
-        F.min_ahead = false;
+        const bool ahead = mesh_variant != MGCFD_MESH_FVCORR;      // as in op_restrict, for the fine sweep that follows
+        double *pm = ahead ? F.partial_min : nullptr;
         Timed t(this, fine, MGCFD_LOOP_PROLONG);
-        if (opt_exact) exact::launch_prolong(stream, F.dp, C.dp.stride, C.residuals, F.residuals, F.q);
-        else fast::launch_prolong(stream, F.dp, C.dp.stride, C.residuals, F.residuals, F.q);
+        if (opt_exact) exact::launch_prolong(stream, F.dp, C.dp.stride, C.residuals, F.residuals, F.q, F.cbrt_vol, pm);
+        else fast::launch_prolong(stream, F.dp, C.dp.stride, C.residuals, F.residuals, F.q, F.cbrt_vol, pm);
+        F.min_ahead = ahead;
         F.iters[MGCFD_LOOP_PROLONG] += F.info.n_internal + F.info.nel;  // mg_loops.cpp:728,842
     }
     int read_error(int64_t *bad_cell)

@@ -140,6 +140,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 code path on a one-GPU box (not a measurement): every rank on device 0,
+    # collectives through gloo.  MGCFD_BENCH_REHEARSAL=1 python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
+    rehearsal = os.environ.get("MGCFD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MG-CFD HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -147,7 +152,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -240,7 +248,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"M6-L0-like synthetic level ({args.lattice}^3 jittered lattice, permuted ids): "
                                    f"{nel} nodes / {n_int} internal edges per GPU, flux + update sweep, no MG",
-                       "step": "copy, compute_step_factor, 3 x (fluxes, time_step), residual",
+                       "step": "copy, compute_step_factor, 3 x (fluxes, time_step), residual (the reference's per-sweep loops; run as 3 fused launches)",
                        "numerics": "fast (FMA contraction)" if args.fast else "exact (bit-identical to the reference)",
                        "parallelism": f"{world} mesh copies, all-reduce(min dt) per sweep" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

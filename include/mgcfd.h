@@ -236,8 +236,9 @@ int mgcfd_step_factor_min_devptr(mgcfd_solver *s, int level, void **devptr);
 /* Second half: step_factors[i] = min_dt / volumes[i]. */
 int mgcfd_step_factor_apply(mgcfd_solver *s, int level);
 /* One smoothing sweep (as mgcfd_smooth) split around that all-reduce, with the fused stage
- * kernels: sweep_begin = copy + first half of compute_step_factor + reduction to the scalar
- * behind mgcfd_step_factor_min_devptr; [all-reduce MIN that scalar across ranks];
+ * kernels: sweep_begin = first half of compute_step_factor (skipped when the launch that produced
+ * the variables already left its minima behind) + reduction to the scalar behind
+ * mgcfd_step_factor_min_devptr; [all-reduce MIN that scalar across ranks];
  * sweep_end = the RK stages (fluxes + time_step fused, "/ volume" applied in the first) + residual.
  * Optional, to HIDE the all-reduce: sweep_flux0 computes the first stage's fluxes, which do not
  * depend on the time step, and may run while the collective is in flight; sweep_end then starts

@@ -279,18 +279,23 @@ struct mgcfd_solver {
         lv.fluxes_stale = false;
     }
     // apply_min: 0 no, 1 from the workgroups' partial minima, 2 from the (all-reduced) scalar
-    void op_time_step(int l, int j, int apply_min = 0, bool with_residual = false, bool lazy_zero = false)
+    // old / out: default old_variables / variables (in place, as the reference); a sweep that keeps its
+    // start state in `variables` passes both
+    void op_time_step(int l, int j, int apply_min = 0, bool with_residual = false, bool lazy_zero = false,
+                      const double *old = nullptr, double *out = nullptr)
     {
         if (j < 0 || j >= MGCFD_RK) throw std::invalid_argument("RK stage out of range");
         DeviceLevel &lv = level(l);
         settle_fluxes(lv);
-        lv.min_ahead = false;
+        if (!old) old = lv.old_variables;
+        if (!out) out = lv.q;
+        if (out == lv.q) lv.min_ahead = false;
         Timed t(this, l, MGCFD_LOOP_TIME_STEP);
         const double *pm = apply_min == 1 ? lv.partial_min : (apply_min == 2 ? lv.min_dt : nullptr);
         const int n_pm = apply_min == 2 ? 1 : static_cast<int>((lv.info.nel + 255) / 256);
         double *res = with_residual ? lv.residuals : nullptr;
-        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, pm, n_pm, lv.volumes, res, lazy_zero ? 0 : 1);
-        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, lv.old_variables, lv.q, lv.dp.old_of_new, err, opt_check, pm, n_pm, lv.volumes, res, lazy_zero ? 0 : 1);
+        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, old, out, lv.dp.old_of_new, err, opt_check, pm, n_pm, lv.volumes, res, lazy_zero ? 0 : 1);
+        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, old, out, lv.dp.old_of_new, err, opt_check, pm, n_pm, lv.volumes, res, lazy_zero ? 0 : 1);
         lv.fluxes_stale = lazy_zero;
         lv.fluxes_zero = true;
         lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
@@ -859,8 +864,13 @@ int mgcfd_sweep_begin(mgcfd_solver *s, int level)
         DeviceLevel &lv = s->level(level);
         if (!lv.fluxes_zero) throw std::invalid_argument("sweep_begin needs zero fluxes (as after time_step)");
         lv.sweep_flux0_done = false;
-        const bool pending = s->op_step_factor(level, true);       // copy + first half, partial minima
-        if (pending) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
+        // As in smooth_once: no copy (the start state stays in `variables` and becomes old_variables
+        // when sweep_end rotates the buffers), and no step-factor kernel when the launch that produced
+        // `variables` already left the minima behind.
+        const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
+        if (global_dt && lv.min_ahead) lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;
+        else s->op_step_factor(level, true, false);
+        if (global_dt) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
     });
 }
 int mgcfd_sweep_flux0(mgcfd_solver *s, int level)
@@ -876,16 +886,24 @@ int mgcfd_sweep_end(mgcfd_solver *s, int level)
 {
     OP({
         DeviceLevel &lv = s->level(level);
-        const int apply = s->mesh_variant == MGCFD_MESH_FVCORR ? 0 : 2;
+        const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
+        const int apply = global_dt ? 2 : 0;
+        const bool look_ahead = global_dt && s->L.size() == 1;
+        double *const start = lv.q;
+        double *const b1 = lv.q_alt;
+        double *const b2 = lv.old_variables;
         if (lv.sweep_flux0_done) {
-            s->op_time_step(level, 0, apply, false, true);         // time_step on the fluxes of sweep_flux0
+            s->op_time_step(level, 0, apply, false, true, start, b1);   // time_step on the fluxes of sweep_flux0
             lv.sweep_flux0_done = false;
         } else {
             s->settle_fluxes(lv);
-            s->op_fused_stage(level, 0, lv.old_variables, lv.q, apply, false);
+            s->op_fused_stage(level, 0, start, b1, apply, false, start);
         }
-        s->op_fused_stage(level, 1, lv.q, lv.q_alt, 0, false);
-        s->op_fused_stage(level, 2, lv.q_alt, lv.q, 0, true);
+        s->op_fused_stage(level, 1, b1, b2, 0, false, start);
+        s->op_fused_stage(level, 2, b2, b1, 0, true, start, nullptr, look_ahead);
+        lv.rot = (lv.rot + 1) % 3;                 // variables = b1, q_alt = b2, old_variables = start
+        lv.apply_rot();
+        lv.min_ahead = look_ahead;
     });
 }
 

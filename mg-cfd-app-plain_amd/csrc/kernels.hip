@@ -490,14 +490,14 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     const int32_t row0 = slice_row0[slice];
     const int32_t n_int = (classes & 1) ? rows_int[slice] : 0;
     const int32_t n_bnd = rows_bnd[slice];
-    // (a row the slice does not have is read from pad_row, a row of padding after the last one: the
-    //  load itself is never conditional, so the compiler can count the loads in flight exactly)
-    EdgeRow e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
-    EdgeRow e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
     const bool has_halo = hid >= 0;
     const int64_t hnode = has_halo ? int64_t(hid) : i;
     const double g0 = q[hnode], g1 = q[stride + hnode], g2 = q[2 * stride + hnode], g3 = q[3 * stride + hnode],
                  g4 = q[4 * stride + hnode];
+    // (a row the slice does not have is read from pad_row, a row of padding after the last one: the
+    //  load itself is never conditional, so the compiler can count the loads in flight exactly)
+    EdgeRow e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
+    EdgeRow e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
     const NodeQ me = make_nodeq(o0, o1, o2, o3, o4);
     lds_store_record(tile, uint32_t(tid), me);
     // Unconditional: a thread without a halo node re-reads its own node and parks the copy in its

@@ -64,7 +64,11 @@ struct DevicePlan {
     int32_t *old_of_new = nullptr;
     // transfer to/from the next-coarser level
     int32_t *child_ptr = nullptr, *child = nullptr;
-    ProlongW *pro = nullptr;
+    double *pro_w = nullptr;            // [row][w_own | w_other][64 lanes]
+    int32_t *pro_p = nullptr;           // [row][64 lanes] coarse NEW id of the other end's parent
+    int pro_tiled = 0;                  // k_prolong_tile can run (coarse residuals staged in LDS)
+    int32_t *pro_tile_n = nullptr, *pro_tile_ids = nullptr;
+    uint16_t *pro_s16 = nullptr, *pro_own16 = nullptr;
     int32_t *pro_parent = nullptr;
     double *pro_wsum = nullptr;
 };

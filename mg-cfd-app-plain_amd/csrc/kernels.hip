@@ -1076,7 +1076,7 @@ k_restrict(int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine, const
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_prolong(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t *__restrict__ slice_row0,
-          const int32_t *__restrict__ rows_int, const ProlongW *__restrict__ pro,
+          const int32_t *__restrict__ rows_int, const double *__restrict__ pro_w, const int32_t *__restrict__ pro_p,
           const int32_t *__restrict__ pro_parent, const double *__restrict__ pro_wsum,
           const double *__restrict__ coarse_residuals, const double *__restrict__ fine_residuals,
           double *__restrict__ fine_q, const double *__restrict__ cbrt_vol,
@@ -1095,6 +1095,12 @@ k_prolong(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t *__r
     const int32_t n_int = rows_int[slice];
     const int32_t parent = pro_parent[ii];
     const int64_t sc = stride_coarse;
+    // this node's own state and residual: needed at the end, requested now
+    const double q0 = fine_q[ii], q1 = fine_q[stride + ii], q2 = fine_q[2 * stride + ii], q3 = fine_q[3 * stride + ii],
+                 q4 = fine_q[4 * stride + ii];
+    const double f0 = fine_residuals[ii], f1 = fine_residuals[stride + ii], f2 = fine_residuals[2 * stride + ii],
+                 f3 = fine_residuals[3 * stride + ii], f4 = fine_residuals[4 * stride + ii];
+    const double ws = pro_wsum[ii];
     // The node's own parent appears in every entry (and, through the reference's b1-for-a1 quirk,
     // as BOTH terms of every entry in which this node is the edge's 'b' end): fetch it once.
     const int64_t own = parent < 0 ? int64_t(~parent) : int64_t(parent);
@@ -1105,28 +1111,121 @@ k_prolong(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t *__r
         r0 = o0; r1 = o1; r2 = o2; r3 = o3; r4 = o4;
     } else {
         r0 = r1 = r2 = r3 = r4 = 0.0;
-        int64_t e = (int64_t(row0) << 6) + lane;
-        for (int32_t r = 0; r < n_int; r++, e += 64) {
-            const ProlongW pw = pro[e];
-            if (pw.w_own == 0.0 && pw.w_other == 0.0) continue;      // ELL padding
-            r0 += pw.w_own * o0; r1 += pw.w_own * o1; r2 += pw.w_own * o2; r3 += pw.w_own * o3; r4 += pw.w_own * o4;
+        // entries stored [row][w_own | w_other][64 lanes] and [row][64 lanes] (the other end's parent)
+        const double *wr = pro_w + (int64_t(row0) << 7) + lane;
+        const int32_t *pr = pro_p + (int64_t(row0) << 6) + lane;
+        for (int32_t r = 0; r < n_int; r++, wr += 128, pr += 64) {
+            const double w_own = wr[0], w_other = wr[64];
+            const int32_t p_other = pr[0];
+            if (w_own == 0.0 && w_other == 0.0) continue;            // ELL padding
+            r0 += w_own * o0; r1 += w_own * o1; r2 += w_own * o2; r3 += w_own * o3; r4 += w_own * o4;
             double x0 = o0, x1 = o1, x2 = o2, x3 = o3, x4 = o4;
-            if (pw.p_other != parent) {                                // the other end's parent: gather
-                const int64_t px = pw.p_other;
+            if (p_other != parent) {                                   // the other end's parent: gather
+                const int64_t px = p_other;
                 x0 = coarse_residuals[px]; x1 = coarse_residuals[sc + px]; x2 = coarse_residuals[2 * sc + px];
                 x3 = coarse_residuals[3 * sc + px]; x4 = coarse_residuals[4 * sc + px];
             }
-            r0 += pw.w_other * x0; r1 += pw.w_other * x1; r2 += pw.w_other * x2; r3 += pw.w_other * x3; r4 += pw.w_other * x4;
+            r0 += w_other * x0; r1 += w_other * x1; r2 += w_other * x2; r3 += w_other * x3; r4 += w_other * x4;
         }
     }
     double sf = __longlong_as_double(0x7FF0000000000000LL);          // +inf
     if (active) {
-        const double ws = pro_wsum[i];
-        const double n0 = fine_q[i] + (fine_residuals[i] - r0 / ws);
-        const double n1 = fine_q[stride + i] + (fine_residuals[stride + i] - r1 / ws);
-        const double n2 = fine_q[2 * stride + i] + (fine_residuals[2 * stride + i] - r2 / ws);
-        const double n3 = fine_q[3 * stride + i] + (fine_residuals[3 * stride + i] - r3 / ws);
-        const double n4 = fine_q[4 * stride + i] + (fine_residuals[4 * stride + i] - r4 / ws);
+        const double n0 = q0 + (f0 - r0 / ws);
+        const double n1 = q1 + (f1 - r1 / ws);
+        const double n2 = q2 + (f2 - r2 / ws);
+        const double n3 = q3 + (f3 - r3 / ws);
+        const double n4 = q4 + (f4 - r4 / ws);
+        store_conserved(fine_q, stride, i, n0, n1, n2, n3, n4);
+        if (partial_min) sf = local_step_factor(n0, n1, n2, n3, n4, cbrt_vol[i]);
+    }
+    if (partial_min) block_min_to(sf, partial_min);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same prolongation with the coarse residuals served from LDS: one workgroup = one fine tile;
+// the distinct coarse nodes the tile refers to (own parents and the other ends' parents, a few
+// hundred) are read from HBM once, 40 bytes each, and every entry then finds them in LDS instead
+// of gathering five scattered doubles through L1.  Same entries, same order, same arithmetic.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_prolong_tile(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t *__restrict__ slice_row0,
+               const int32_t *__restrict__ rows_int, const double *__restrict__ pro_w,
+               const uint16_t *__restrict__ pro_s16, const uint16_t *__restrict__ pro_own16,
+               const int32_t *__restrict__ pro_tile_n, const int32_t *__restrict__ pro_tile_ids,
+               const int32_t *__restrict__ pro_parent, const double *__restrict__ pro_wsum,
+               const double *__restrict__ coarse_residuals, const double *__restrict__ fine_residuals,
+               double *__restrict__ fine_q, const double *__restrict__ cbrt_vol, double *__restrict__ partial_min)
+{
+    __shared__ double cr[kProCap * 5];
+    const unsigned t = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t i = int64_t(t) * kTile + tid;
+    const bool active = i < nel;
+    const int64_t ii = active ? i : nel - 1;
+    const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
+    const int64_t sc = stride_coarse;
+
+    // stage the tile's coarse residuals (ids first: they head the dependent chain)
+    const int32_t n_ids = pro_tile_n[t];
+    const int32_t *ids = pro_tile_ids + int64_t(t) * kProCap;
+    for (int32_t k = tid; k < n_ids; k += kBlock) {
+        const int64_t c = ids[k];
+        double *d = cr + k * 5;
+        d[0] = coarse_residuals[c]; d[1] = coarse_residuals[sc + c]; d[2] = coarse_residuals[2 * sc + c];
+        d[3] = coarse_residuals[3 * sc + c]; d[4] = coarse_residuals[4 * sc + c];
+    }
+    const bool wave_live = (int64_t(slice) << 6) < nel;
+    const int32_t row0 = wave_live ? slice_row0[slice] : 0;
+    const int32_t n_int = wave_live ? rows_int[slice] : 0;
+    const int32_t parent = pro_parent[ii];
+    const uint32_t own_slot = pro_own16[ii];
+    const double q0 = fine_q[ii], q1 = fine_q[stride + ii], q2 = fine_q[2 * stride + ii], q3 = fine_q[3 * stride + ii],
+                 q4 = fine_q[4 * stride + ii];
+    const double f0 = fine_residuals[ii], f1 = fine_residuals[stride + ii], f2 = fine_residuals[2 * stride + ii],
+                 f3 = fine_residuals[3 * stride + ii], f4 = fine_residuals[4 * stride + ii];
+    const double ws = pro_wsum[ii];
+    __syncthreads();
+
+    const double *od = cr + own_slot * 5;
+    const double o0 = od[0], o1 = od[1], o2 = od[2], o3 = od[3], o4 = od[4];
+    double r0, r1, r2, r3, r4;
+    if (parent < 0) {
+        r0 = o0; r1 = o1; r2 = o2; r3 = o3; r4 = o4;
+    } else {
+        r0 = r1 = r2 = r3 = r4 = 0.0;
+        // entries two rows ahead of their use (the arrays end in padding rows, so the reads past a
+        // slice's last row are in bounds and nothing is conditional)
+        const double *wr = pro_w + (int64_t(row0) << 7) + lane;
+        const uint16_t *sr = pro_s16 + (int64_t(row0) << 6) + lane;
+        double wa0 = wr[0], wb0 = wr[64], wa1 = wr[128], wb1 = wr[192];
+        uint32_t sl0 = sr[0], sl1 = sr[64];
+        for (int32_t r = 0; r < n_int; r += 2, wr += 256, sr += 128) {
+            const double wa2 = wr[256], wb2 = wr[320], wa3 = wr[384], wb3 = wr[448];
+            const uint32_t sl2 = sr[128], sl3 = sr[192];
+            const bool v0 = wa0 != 0.0 || wb0 != 0.0;                  // ELL padding carries zero weights
+            const bool v1 = (r + 1 < n_int) && (wa1 != 0.0 || wb1 != 0.0);
+            const double *xd0 = cr + (v0 ? sl0 : own_slot) * 5, *xd1 = cr + (v1 ? sl1 : own_slot) * 5;
+            const double x00 = xd0[0], x01 = xd0[1], x02 = xd0[2], x03 = xd0[3], x04 = xd0[4];
+            const double x10 = xd1[0], x11 = xd1[1], x12 = xd1[2], x13 = xd1[3], x14 = xd1[4];
+            if (v0) {
+                r0 += wa0 * o0; r1 += wa0 * o1; r2 += wa0 * o2; r3 += wa0 * o3; r4 += wa0 * o4;
+                r0 += wb0 * x00; r1 += wb0 * x01; r2 += wb0 * x02; r3 += wb0 * x03; r4 += wb0 * x04;
+            }
+            if (v1) {
+                r0 += wa1 * o0; r1 += wa1 * o1; r2 += wa1 * o2; r3 += wa1 * o3; r4 += wa1 * o4;
+                r0 += wb1 * x10; r1 += wb1 * x11; r2 += wb1 * x12; r3 += wb1 * x13; r4 += wb1 * x14;
+            }
+            wa0 = wa2; wb0 = wb2; wa1 = wa3; wb1 = wb3; sl0 = sl2; sl1 = sl3;
+        }
+    }
+    double sf = __longlong_as_double(0x7FF0000000000000LL);          // +inf
+    if (active) {
+        const double n0 = q0 + (f0 - r0 / ws);
+        const double n1 = q1 + (f1 - r1 / ws);
+        const double n2 = q2 + (f2 - r2 / ws);
+        const double n3 = q3 + (f3 - r3 / ws);
+        const double n4 = q4 + (f4 - r4 / ws);
         store_conserved(fine_q, stride, i, n0, n1, n2, n3, n4);
         if (partial_min) sf = local_step_factor(n0, n1, n2, n3, n4, cbrt_vol[i]);
     }
@@ -1250,8 +1349,14 @@ void launch_prolong(hipStream_t st, const DevicePlan &p, int64_t stride_coarse, 
                     const double *fine_residuals, double *fine_q, const double *cbrt_vol, double *partial_min)
 {
     // grid_for(nel) workgroups: the same partition k_step_factor_local's partial minima use
+    if (p.pro_tiled) {
+        hipLaunchKernelGGL(k_prolong_tile, dim3(grid_for(p.nel)), dim3(kBlock), 0, st, p.nel, p.stride, stride_coarse,
+                           p.slice_row0, p.rows_int, p.pro_w, p.pro_s16, p.pro_own16, p.pro_tile_n, p.pro_tile_ids,
+                           p.pro_parent, p.pro_wsum, coarse_residuals, fine_residuals, fine_q, cbrt_vol, partial_min);
+        return;
+    }
     hipLaunchKernelGGL(k_prolong, dim3(grid_for(p.nel)), dim3(kBlock), 0, st, p.nel, p.stride, stride_coarse,
-                       p.slice_row0, p.rows_int, p.pro, p.pro_parent, p.pro_wsum, coarse_residuals, fine_residuals, fine_q,
+                       p.slice_row0, p.rows_int, p.pro_w, p.pro_p, p.pro_parent, p.pro_wsum, coarse_residuals, fine_residuals, fine_q,
                        cbrt_vol, partial_min);
 }
 

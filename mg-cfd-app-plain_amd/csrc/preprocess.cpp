@@ -513,6 +513,45 @@ void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge
             P.pro_parent[static_cast<size_t>(n)] = ~P.pro_parent[static_cast<size_t>(n)];
             P.pro_wsum[static_cast<size_t>(n)] = 0.0;
         }
+
+    // ---- tiled form: per fine tile, the distinct coarse nodes its nodes and entries refer to ----
+    P.pro_tiled = true;
+    P.pro_tile_n.assign(static_cast<size_t>(P.n_tiles), 0);
+    P.pro_tile_ids.assign(static_cast<size_t>(P.n_tiles) * kProCap, -1);
+    P.pro_s16.assign(P.pro.size(), 0);
+    P.pro_own16.assign(static_cast<size_t>(nel), 0);
+    std::vector<int32_t> ids;
+    auto parent_of = [&](int64_t n) { const int32_t p = P.pro_parent[static_cast<size_t>(n)]; return p < 0 ? ~p : p; };
+    for (int32_t t = 0; t < P.n_tiles && P.pro_tiled; t++) {
+        const int64_t n0 = int64_t(t) * kTile, n1 = std::min<int64_t>(nel, n0 + kTile);
+        const int32_t s0 = t * (kTile / kSlice), s1 = s0 + kTile / kSlice;
+        ids.clear();
+        for (int64_t n = n0; n < n1; n++) ids.push_back(parent_of(n));
+        for (int32_t sl = s0; sl < s1; sl++) {
+            const int64_t e0 = int64_t(P.slice_row0[static_cast<size_t>(sl)]) * kSlice;
+            const int64_t e1 = e0 + int64_t(P.rows_int[static_cast<size_t>(sl)]) * kSlice;
+            for (int64_t e = e0; e < e1; e++) {
+                const ProlongW &w = P.pro[static_cast<size_t>(e)];
+                if (w.w_own != 0.0 || w.w_other != 0.0) ids.push_back(w.p_other);
+            }
+        }
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        if (ids.size() > static_cast<size_t>(kProCap)) { P.pro_tiled = false; break; }
+        P.pro_tile_n[static_cast<size_t>(t)] = static_cast<int32_t>(ids.size());
+        std::copy(ids.begin(), ids.end(), P.pro_tile_ids.begin() + static_cast<size_t>(t) * kProCap);
+        auto pos = [&](int32_t id) { return static_cast<uint16_t>(std::lower_bound(ids.begin(), ids.end(), id) - ids.begin()); };
+        for (int64_t n = n0; n < n1; n++) P.pro_own16[static_cast<size_t>(n)] = pos(parent_of(n));
+        for (int32_t sl = s0; sl < s1; sl++) {
+            const int64_t e0 = int64_t(P.slice_row0[static_cast<size_t>(sl)]) * kSlice;
+            const int64_t e1 = e0 + int64_t(P.rows_int[static_cast<size_t>(sl)]) * kSlice;
+            for (int64_t e = e0; e < e1; e++) {
+                const ProlongW &w = P.pro[static_cast<size_t>(e)];
+                if (w.w_own != 0.0 || w.w_other != 0.0) P.pro_s16[static_cast<size_t>(e)] = pos(w.p_other);
+            }
+        }
+    }
+    if (!P.pro_tiled) { P.pro_tile_n.clear(); P.pro_tile_ids.clear(); P.pro_s16.clear(); P.pro_own16.clear(); }
 }
 
 } // namespace mgcfd

@@ -27,6 +27,8 @@ constexpr int kTileCap = 560;   // node records a tile can stage in LDS (560 * 9
 constexpr int kHaloStride = kTileCap - kTile;   // halo ids a tile can stage (device table: fixed stride, -1 padded)
 static_assert(kTileCap >= 2 * kTile, "every thread has a halo slot (the kernels stage one unconditionally)");
 static_assert(kHaloStride <= 2 * kTile, "the staging code reads at most two halo ids per thread");
+// prolongation tiles: distinct coarse nodes (own parents + neighbours' parents) a fine tile may stage in LDS (40 B each)
+constexpr int kProCap = 768;
 constexpr int kEdgeChunk = 256;
 constexpr int kMaxEdgeChunks = 5;
 static_assert(kMaxEdgeChunks * kEdgeChunk * 40 <= kTileCap * 96, "edge fluxes must fit the LDS tile");
@@ -93,6 +95,12 @@ struct LevelPlan {
     std::vector<ProlongW> pro;         // [rows*64] only the internal rows are meaningful
     std::vector<int32_t> pro_parent;   // [nel] coarse NEW id of the node's parent; ~id when the node coincides with it
     std::vector<double> pro_wsum;      // [nel] sum of weights in reference order (1.0 when coincident)
+    // tiled form: the coarse nodes a fine tile refers to, staged in LDS by k_prolong_tile
+    bool pro_tiled = false;            // false: some tile refers to more than kProCap coarse nodes (k_prolong gathers from HBM)
+    std::vector<int32_t> pro_tile_n;   // [n_tiles] distinct coarse nodes of the tile
+    std::vector<int32_t> pro_tile_ids; // [n_tiles][kProCap] their coarse NEW ids, ascending, -1 padded
+    std::vector<uint16_t> pro_s16;     // [rows*64] position of the entry's other-end parent in that list
+    std::vector<uint16_t> pro_own16;   // [nel] position of the node's own parent
 };
 
 // n_owned < nel marks the nodes with ORIGINAL id >= n_owned as ghosts of a partitioned level:

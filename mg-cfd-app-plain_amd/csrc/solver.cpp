@@ -371,7 +371,7 @@ mgcfd_solver::~mgcfd_solver()
     for (auto &lv : L) {
         void *ptrs[] = {lv.q_alt, lv.dp.nbr16, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
                         lv.cbrt_vol, lv.min_dt, lv.partial_min, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
-                        lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.pro,
+                        lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.pro_w, lv.dp.pro_p, lv.dp.pro_tile_n, lv.dp.pro_tile_ids, lv.dp.pro_s16, lv.dp.pro_own16,
                         lv.dp.pro_parent, lv.dp.pro_wsum, lv.dp.te_chunk_ptr, lv.dp.te_count, lv.dp.te_slots, lv.dp.te_w,
                         lv.dp.gat16};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -528,7 +528,28 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         if (lv.has_transfer) {
             lv.dp.child_ptr = dev_upload(P.child_ptr);
             lv.dp.child = dev_upload(P.child);
-            lv.dp.pro = dev_upload(P.pro);
+            {
+                // prolongation entries as [row][component][lane]: every load of a wave is one contiguous run
+                const size_t rows_n = P.pro.size() / kSlice;
+                std::vector<double> pw((rows_n + 4) * 2 * kSlice, 0.0);      // + four rows of padding (k_prolong_tile reads ahead)
+                std::vector<int32_t> pp(rows_n * kSlice);
+                for (size_t e = 0; e < P.pro.size(); e++) {
+                    const size_t row = e / kSlice, lane = e % kSlice;
+                    pw[(row * 2 + 0) * kSlice + lane] = P.pro[e].w_own;
+                    pw[(row * 2 + 1) * kSlice + lane] = P.pro[e].w_other;
+                    pp[row * kSlice + lane] = P.pro[e].p_other;
+                }
+                lv.dp.pro_w = dev_upload(pw);
+                lv.dp.pro_p = dev_upload(pp);
+            }
+            lv.dp.pro_tiled = P.pro_tiled ? 1 : 0;
+            if (P.pro_tiled) {
+                lv.dp.pro_tile_n = dev_upload(P.pro_tile_n);
+                lv.dp.pro_tile_ids = dev_upload(P.pro_tile_ids);
+                lv.plan.pro_s16.resize(P.pro_s16.size() + 4 * kSlice, 0);          // four rows of padding
+                lv.dp.pro_s16 = dev_upload(P.pro_s16);
+                lv.dp.pro_own16 = dev_upload(P.pro_own16);
+            }
             lv.dp.pro_parent = dev_upload(P.pro_parent);
             lv.dp.pro_wsum = dev_upload(P.pro_wsum);
             // the per-entry host copies are not needed again

@@ -64,6 +64,7 @@ struct DevicePlan {
     int32_t *old_of_new = nullptr;
     // transfer to/from the next-coarser level
     int32_t *child_ptr = nullptr, *child = nullptr;
+    int32_t *child4 = nullptr;          // [nel_coarse][4] the first four children of every coarse node, -1 padded
     double *pro_w = nullptr;            // [row][w_own | w_other][64 lanes]
     int32_t *pro_p = nullptr;           // [row][64 lanes] coarse NEW id of the other end's parent
     int pro_tiled = 0;                  // k_prolong_tile can run (coarse residuals staged in LDS)

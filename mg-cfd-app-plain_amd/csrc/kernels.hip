@@ -1036,15 +1036,27 @@ __global__ void k_append_scalar(const double *__restrict__ src, double *__restri
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_restrict(int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine, const int32_t *__restrict__ child_ptr,
-           const int32_t *__restrict__ child, const double *__restrict__ fine_q, double *__restrict__ coarse_q,
-           const double *__restrict__ cbrt_vol, double *__restrict__ partial_min /* nullptr, or: look ahead, see below */)
+           const int32_t *__restrict__ child, const int4 *__restrict__ child4, const double *__restrict__ fine_q,
+           double *__restrict__ coarse_q, const double *__restrict__ cbrt_vol,
+           double *__restrict__ partial_min /* nullptr, or: look ahead, see below */)
 {
     const int64_t c = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     double sf = __longlong_as_double(0x7FF0000000000000LL);          // +inf
     if (c < nel_coarse) {
+        // The first four children come from a fixed-stride table (-1 padded): their ids need no
+        // pointer look-up and their 20 loads are all in flight together; the sum keeps the reference's
+        // order (ascending original fine id, mg_loops.cpp:119-142).
+        const int4 k4 = child4[c];
         const int32_t b = child_ptr[c], e = child_ptr[c + 1];
+        const int32_t n = e - b;
+        const int64_t j0 = k4.x < 0 ? 0 : k4.x, j1 = k4.y < 0 ? 0 : k4.y, j2 = k4.z < 0 ? 0 : k4.z, j3 = k4.w < 0 ? 0 : k4.w;
+        const int64_t sfn = stride_fine;
+        const double a0 = fine_q[j0], a1 = fine_q[sfn + j0], a2 = fine_q[2 * sfn + j0], a3 = fine_q[3 * sfn + j0], a4 = fine_q[4 * sfn + j0];
+        const double b0 = fine_q[j1], b1 = fine_q[sfn + j1], b2 = fine_q[2 * sfn + j1], b3 = fine_q[3 * sfn + j1], b4 = fine_q[4 * sfn + j1];
+        const double c0 = fine_q[j2], c1 = fine_q[sfn + j2], c2 = fine_q[2 * sfn + j2], c3 = fine_q[3 * sfn + j2], c4 = fine_q[4 * sfn + j2];
+        const double d0 = fine_q[j3], d1 = fine_q[sfn + j3], d2 = fine_q[2 * sfn + j3], d3 = fine_q[3 * sfn + j3], d4 = fine_q[4 * sfn + j3];
         double n0, n1, n2, n3, n4;
-        if (b == e) {
+        if (n == 0) {
             // no children: the coarse node keeps its value (mg_loops.cpp:63-78,174-189)
             if (partial_min) {
                 n0 = coarse_q[c]; n1 = coarse_q[stride_coarse + c]; n2 = coarse_q[2 * stride_coarse + c];
@@ -1052,12 +1064,16 @@ k_restrict(int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine, const
             }
         } else {
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
-            for (int32_t k = b; k < e; k++) {
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3; s4 += a4;
+            if (n > 1) { s0 += b0; s1 += b1; s2 += b2; s3 += b3; s4 += b4; }
+            if (n > 2) { s0 += c0; s1 += c1; s2 += c2; s3 += c3; s4 += c4; }
+            if (n > 3) { s0 += d0; s1 += d1; s2 += d2; s3 += d3; s4 += d4; }
+            for (int32_t k = b + 4; k < e; k++) {                     // fifth child onwards (rare)
                 const int64_t j = child[k];
-                s0 += fine_q[j]; s1 += fine_q[stride_fine + j]; s2 += fine_q[2 * stride_fine + j];
-                s3 += fine_q[3 * stride_fine + j]; s4 += fine_q[4 * stride_fine + j];
+                s0 += fine_q[j]; s1 += fine_q[sfn + j]; s2 += fine_q[2 * sfn + j];
+                s3 += fine_q[3 * sfn + j]; s4 += fine_q[4 * sfn + j];
             }
-            const double average = 1.0 / double(e - b);
+            const double average = 1.0 / double(n);
             n0 = s0 * average; n1 = s1 * average; n2 = s2 * average; n3 = s3 * average; n4 = s4 * average;
             store_conserved(coarse_q, stride_coarse, c, n0, n1, n2, n3, n4);
         }
@@ -1338,11 +1354,12 @@ void launch_append_scalar(hipStream_t st, const double *src, double *ring, int *
 { hipLaunchKernelGGL(k_append_scalar, dim3(1), dim3(64), 0, st, src, ring, count, cap); }
 
 void launch_restrict(hipStream_t st, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,
-                     const int32_t *child_ptr, const int32_t *child, const double *fine_q, double *coarse_q,
-                     const double *cbrt_vol, double *partial_min)
+                     const int32_t *child_ptr, const int32_t *child, const int32_t *child4, const double *fine_q,
+                     double *coarse_q, const double *cbrt_vol, double *partial_min)
 {
     hipLaunchKernelGGL(k_restrict, dim3(grid_for(nel_coarse)), dim3(kBlock), 0, st, nel_coarse, stride_coarse,
-                       stride_fine, child_ptr, child, fine_q, coarse_q, cbrt_vol, partial_min);
+                       stride_fine, child_ptr, child, reinterpret_cast<const int4 *>(child4), fine_q, coarse_q, cbrt_vol,
+                       partial_min);
 }
 
 void launch_prolong(hipStream_t st, const DevicePlan &p, int64_t stride_coarse, const double *coarse_residuals,

@@ -32,7 +32,8 @@
                             double *field);                                                                          \
     void launch_append_scalar(hipStream_t, const double *src, double *ring, int *count, int cap);                    \
     void launch_restrict(hipStream_t, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,                \
-                         const int32_t *child_ptr, const int32_t *child, const double *fine_q, double *coarse_q,     \
+                         const int32_t *child_ptr, const int32_t *child, const int32_t *child4, const double *fine_q, \
+                         double *coarse_q,                                                                        \
                          const double *cbrt_vol, double *partial_min);                                              \
     void launch_prolong(hipStream_t, const DevicePlan &, int64_t stride_coarse, const double *coarse_residuals,      \
                         const double *fine_residuals, double *fine_q, const double *cbrt_vol,                       \

@@ -324,8 +324,8 @@ struct mgcfd_solver {
         const bool ahead = mesh_variant != MGCFD_MESH_FVCORR;
         double *pm = ahead ? C.partial_min : nullptr;
         Timed t(this, fine + 1, MGCFD_LOOP_RESTRICT);
-        if (opt_exact) exact::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q, C.cbrt_vol, pm);
-        else fast::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.q, C.q, C.cbrt_vol, pm);
+        if (opt_exact) exact::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.dp.child4, F.q, C.q, C.cbrt_vol, pm);
+        else fast::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.dp.child4, F.q, C.q, C.cbrt_vol, pm);
         C.min_ahead = ahead;
         C.iters[MGCFD_LOOP_RESTRICT] += 2 * F.info.mgc + C.info.nel;   // mg_loops.cpp:61,117,172
     }
@@ -371,7 +371,7 @@ mgcfd_solver::~mgcfd_solver()
     for (auto &lv : L) {
         void *ptrs[] = {lv.q_alt, lv.dp.nbr16, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
                         lv.cbrt_vol, lv.min_dt, lv.partial_min, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
-                        lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.pro_w, lv.dp.pro_p, lv.dp.pro_tile_n, lv.dp.pro_tile_ids, lv.dp.pro_s16, lv.dp.pro_own16,
+                        lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.child4, lv.dp.pro_w, lv.dp.pro_p, lv.dp.pro_tile_n, lv.dp.pro_tile_ids, lv.dp.pro_s16, lv.dp.pro_own16,
                         lv.dp.pro_parent, lv.dp.pro_wsum, lv.dp.te_chunk_ptr, lv.dp.te_count, lv.dp.te_slots, lv.dp.te_w,
                         lv.dp.gat16};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -528,6 +528,14 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         if (lv.has_transfer) {
             lv.dp.child_ptr = dev_upload(P.child_ptr);
             lv.dp.child = dev_upload(P.child);
+            {
+                const size_t nc = P.child_ptr.size() - 1;
+                std::vector<int32_t> c4(nc * 4, -1);
+                for (size_t c = 0; c < nc; c++)
+                    for (int32_t k = P.child_ptr[c]; k < P.child_ptr[c + 1] && k < P.child_ptr[c] + 4; k++)
+                        c4[c * 4 + static_cast<size_t>(k - P.child_ptr[c])] = P.child[static_cast<size_t>(k)];
+                lv.dp.child4 = dev_upload(c4);
+            }
             {
                 // prolongation entries as [row][component][lane]: every load of a wave is one contiguous run
                 const size_t rows_n = P.pro.size() / kSlice;

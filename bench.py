@@ -125,8 +125,8 @@ def vcycle_wall(fast: bool, cycles: int = 25):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)        # 0.15 s of GPU time: past the clock ramp of the first ms
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--lattice", type=int, default=LATTICE, help="nodes per side of the synthetic M6-L0-like level")
     ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
     ap.add_argument("--variant", type=int, default=0, help="MGCFD_OPT_FLUX_VARIANT (0 stream k, 1 recompute k)")
@@ -193,7 +193,8 @@ def main():
         step()
     barrier()
     solver.reset_monitoring()
-    solver.set_option("timing", 2)            # hipEvent pairs around the flux launches only
+    if os.environ.get("MGCFD_BENCH_NO_TIMING") != "1":      # (diagnostic: how much the live kernel timing costs)
+        solver.set_option("timing", 2)        # hipEvent pairs around the flux launches only
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -68,7 +68,11 @@ enum {
                                    mgcfd_level_has_edge_once).  All four give bit-identical results. */
     MGCFD_OPT_FUSE_UPDATE = 5, /* 1 (default): mgcfd_smooth / mgcfd_run_cycles run each Runge-Kutta stage as ONE
                                   launch (fluxes + time_step, same operations); 0: one launch per loop */
-    MGCFD_OPT_GRAPH = 6        /* 1 (default): replay each smoothing sweep from a captured hipGraph */
+    MGCFD_OPT_GRAPH = 6        /* 1: replay each smoothing sweep / multigrid cycle from a captured hipGraph (one host
+                                  call instead of 3 / ~24 launches).  0 (default): launch the kernels directly — on
+                                  ROCm 7.2 / MI355X the graph costs ~1.7 us per kernel node more than direct launches
+                                  (sweep 75 us replayed, 70 us launched), so it only pays when the host cannot keep
+                                  the queue full */
 };
 
 /* Same 40-byte layout as the reference's edge_neighbour (src/Base/definitions.h:83). */

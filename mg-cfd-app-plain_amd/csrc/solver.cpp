@@ -99,7 +99,7 @@ struct mgcfd_solver {
     FarField ff{};
     double ff17[17] = {0};
     unsigned long long *err = nullptr;       // device: packed (cell << 8 | code), ~0 = clean
-    int opt_exact = 1, opt_timing = 0, opt_indirect_rw = 0, opt_check = 1, opt_variant = 0, opt_fuse = 1, opt_graph = 1;
+    int opt_exact = 1, opt_timing = 0, opt_indirect_rw = 0, opt_check = 1, opt_variant = 0, opt_fuse = 1, opt_graph = 0;
     int timing_stride = 8;                  // OPT_TIMING == 2: bracket the flux launches of every Nth sweep
     int64_t sweep_counter = 0;
     bool in_timed_group = false;

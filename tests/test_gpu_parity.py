@@ -146,9 +146,10 @@ def test_restrict_and_prolong(setup, oracle, exact):
     solver.set_option("exact", 1)
 
 
-def _run_both(mgcfd, oracle, directory, cycles, exact, indirect_rw=False, duplicate=1, fuse=True, variant=0):
+def _run_both(mgcfd, oracle, directory, cycles, exact, indirect_rw=False, duplicate=1, fuse=True, variant=0, graph=0):
     mesh = mgcfd.Mesh("input.dat", directory, duplicate)
     solver = mgcfd.Solver.from_mesh(mesh)
+    solver.set_option("graph", graph)
     solver.set_option("exact", int(exact))
     solver.set_option("flux_variant", variant)
     solver.set_option("fuse_update", int(fuse))
@@ -237,6 +238,14 @@ def test_edge_once_on_ragged_tiles_and_fallback(oracle, variant):
         s.smooth(0, 2)
         assert np.array_equal(got.view(np.int64), s.get(0, "variables").view(np.int64))
         s.close()
+
+
+def test_vcycles_replayed_from_hipgraphs(oracle, mesh3_dir, fvcorr_dir):
+    """MGCFD_OPT_GRAPH=1: whole cycles captured once per buffer-rotation / look-ahead state and replayed
+    (7 cycles pass through every state of the 3-level case more than once)."""
+    import mgcfd
+    _run_both(mgcfd, oracle, mesh3_dir, 7, True, graph=1)
+    _run_both(mgcfd, oracle, fvcorr_dir, 20, True, graph=1)
 
 
 def test_vcycles_with_indirect_rw_and_duplication(oracle, mesh_dir):

@@ -65,7 +65,10 @@ enum {
                                    bit 1: 0 (default) node gather (every edge evaluated from both ends),
                                    2 edge-once tiles (every edge evaluated once per tile; levels whose tiles
                                    hold too many edges fall back to the node gather, see
-                                   mgcfd_level_has_edge_once).  All four give bit-identical results. */
+                                   mgcfd_level_has_edge_once);
+                                   bit 2 (4): two-phase design point — edge fluxes written to memory, then a node-centred
+                                   sum (the reference's FLUX_FISSION idea); kernel-granular and unfused sweeps only.
+                                   Every variant gives bit-identical results. */
     MGCFD_OPT_FUSE_UPDATE = 5, /* 1 (default): mgcfd_smooth / mgcfd_run_cycles run each Runge-Kutta stage as ONE
                                   launch (fluxes + time_step, same operations); 0: one launch per loop */
     MGCFD_OPT_GRAPH = 6        /* 1: replay each smoothing sweep / multigrid cycle from a captured hipGraph (one host

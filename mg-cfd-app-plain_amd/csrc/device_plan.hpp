@@ -61,6 +61,10 @@ struct DevicePlan {
     int32_t *te_chunk_ptr = nullptr, *te_count = nullptr;
     uint16_t *te_slots = nullptr, *gat16 = nullptr;
     double *te_w = nullptr;
+    // two-phase ("fission") design point: per-edge arrays, edge-flux scratch [5][n_edges_pad], rows' edge references
+    int64_t n_edges = 0, n_edges_pad = 0;
+    int32_t *fe_ab = nullptr, *row_edge = nullptr;
+    double *fe_w = nullptr, *edge_flux = nullptr;
     int32_t *old_of_new = nullptr;
     // transfer to/from the next-coarser level
     int32_t *child_ptr = nullptr, *child = nullptr;

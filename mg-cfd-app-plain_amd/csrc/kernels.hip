@@ -833,6 +833,72 @@ k_flux_edge_once(const double *__restrict__ q, const int32_t *__restrict__ tile_
 }
 
 // ------------------------------------------------------------------------------------------
+// Two-phase ("fission") design point, MGCFD_OPT_FLUX_VARIANT bit 2 — the GPU form of the
+// reference's FLUX_FISSION build (flux_kernel.elemfunc.c:193-204 + update_edges,
+// cfd_loops.cpp:159-213): phase 1 evaluates every internal edge once, edge-parallel, and writes its
+// five fluxes to memory; phase 2 is a node-centred sum of each node's incident edges in row order
+// (+F at the a end, -F at the b end) followed by the boundary rows.  Bit-identical to the other
+// variants; kept to put a number on the scatter-strategy choice.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_fission_edge_flux(int64_t n_edges, int64_t n_edges_pad, int64_t stride, const double *__restrict__ q,
+                    const int32_t *__restrict__ fe_ab, const double *__restrict__ fe_w, double *__restrict__ eflux)
+{
+    const int64_t e = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    if (e >= n_edges) return;
+    const int64_t a = fe_ab[e], b = fe_ab[n_edges + e];
+    EdgeRow er;
+    er.code = 0;                                                     // a-side form
+    er.fx = fe_w[e]; er.fy = fe_w[n_edges + e]; er.fz = fe_w[2 * n_edges + e]; er.k = fe_w[3 * n_edges + e];
+    const NodeQ A = load_and_derive(q, stride, a), B = load_and_derive(q, stride, b);
+    const Flux5 f = edge_flux<true>(A, flux_contribution(A), B, er);
+    eflux[e] = f.d; eflux[n_edges_pad + e] = f.mx; eflux[2 * n_edges_pad + e] = f.my;
+    eflux[3 * n_edges_pad + e] = f.mz; eflux[4 * n_edges_pad + e] = f.en;
+}
+
+template <bool ACC>
+__global__ void __launch_bounds__(kBlock)
+k_fission_node_sum(int64_t nel, int64_t stride, int64_t n_edges_pad, const double *__restrict__ q,
+                   const int32_t *__restrict__ slice_row0, const int32_t *__restrict__ rows_int,
+                   const int32_t *__restrict__ rows_bnd, const int32_t *__restrict__ row_edge,
+                   const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
+                   const double *__restrict__ eflux, FarField ff, double *__restrict__ fluxes, int classes)
+{
+    const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int64_t i = blk * int64_t(kBlock) + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
+    const int32_t row0 = slice_row0[slice];
+    const int32_t n_int = rows_int[slice];
+    const int32_t n_bnd = rows_bnd[slice];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+    if (ACC) {
+        a0 = fluxes[i]; a1 = fluxes[stride + i]; a2 = fluxes[2 * stride + i];
+        a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
+    }
+    if (classes & 1) {
+        const int32_t *re = row_edge + (int64_t(row0) << 6) + lane;
+        for (int32_t r = 0; r < n_int; r++) {
+            const int32_t code = re[int64_t(r) << 6];
+            if (code == -1) continue;                                // ELL padding
+            const int64_t e = code & 0x7FFFFFFF;
+            const double f0 = eflux[e], f1 = eflux[n_edges_pad + e], f2 = eflux[2 * n_edges_pad + e],
+                         f3 = eflux[3 * n_edges_pad + e], f4 = eflux[4 * n_edges_pad + e];
+            if (code < 0) { a0 -= f0; a1 -= f1; a2 -= f2; a3 -= f3; a4 -= f4; }      // this node is the b end
+            else { a0 += f0; a1 += f1; a2 += f2; a3 += f3; a4 += f4; }
+        }
+    }
+    if ((classes & 6) && n_bnd > 0) {
+        const NodeQ me = load_and_derive(q, stride, i);
+        boundary_rows(me, flux_contribution(me), ff, nbr16, w, int64_t(row0) + n_int, n_bnd, lane, classes, a0, a1, a2, a3, a4);
+    }
+    if (i < nel) {
+        fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
+        fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // indirect_rw (indirect_rw_kernel.elemfunc.c:4-94) in gather form: the reference's "same data
 // movement, minimal arithmetic" probe.  a-side gets q_b + (ex, ez, 0, 0, ey); b-side gets q_a.
 // The plan stores -0.5*e (a side), so e = -2*w exactly.  Neighbour state straight from HBM/L2.
@@ -1284,6 +1350,19 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     hipLaunchKernelGGL((k_flux_tile<3, LOADK, FUSE, ACC>), grid, block, 0, st, q, p.tile_halo,                 \
                        uint32_t(p.n_tiles), p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.rows_bnd,  \
                        p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs)
+    // variant bit 2: the two-phase design point (never for the fused stages: they keep the flux in registers)
+    if ((variant & 4) && !fused && p.edge_flux) {
+        if (classes & 1)
+            hipLaunchKernelGGL(k_fission_edge_flux, dim3(grid_for(p.n_edges)), block, 0, st, p.n_edges, p.n_edges_pad, p.stride, q,
+                               p.fe_ab, p.fe_w, p.edge_flux);
+        if (accumulate)
+            hipLaunchKernelGGL(k_fission_node_sum<true>, grid, block, 0, st, p.nel, p.stride, p.n_edges_pad, q, p.slice_row0,
+                               p.rows_int, p.rows_bnd, p.row_edge, p.nbr16, p.w, p.edge_flux, ff, fluxes, classes);
+        else
+            hipLaunchKernelGGL(k_fission_node_sum<false>, grid, block, 0, st, p.nel, p.stride, p.n_edges_pad, q, p.slice_row0,
+                               p.rows_int, p.rows_bnd, p.row_edge, p.nbr16, p.w, p.edge_flux, ff, fluxes, classes);
+        return;
+    }
     const bool loadk = (variant & 1) == 0;      // odd variants recompute k = -|e|*s*0.5 from the weights
     // variants 2, 3: every edge evaluated once per tile (needs the internal class and a level whose
     // tiles fit the edge-once limits; otherwise the node gather below)

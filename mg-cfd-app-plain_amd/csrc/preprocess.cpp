@@ -426,6 +426,24 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         }
     }
 
+    // two-phase design point: per-edge arrays in original order and the rows' edge references
+    {
+        const size_t ne = static_cast<size_t>(L.n_internal);
+        P.fe_ab.assign(2 * ne, 0);
+        P.fe_w.assign(4 * ne, 0.0);
+        for (size_t k = 0; k < ne; k++) {
+            const mgcfd_edge &E = edges[static_cast<size_t>(L.internal_start) + k];
+            P.fe_ab[k] = P.new_of_old[static_cast<size_t>(E.a)];
+            P.fe_ab[ne + k] = P.new_of_old[static_cast<size_t>(E.b)];
+            const double ewt = std::sqrt(E.x * E.x + E.y * E.y + E.z * E.z);
+            P.fe_w[k] = -0.5 * E.x; P.fe_w[ne + k] = -0.5 * E.y; P.fe_w[2 * ne + k] = -0.5 * E.z;
+            P.fe_w[3 * ne + k] = -ewt * kSmoothing * 0.5;
+        }
+        P.row_edge.assign(P.nbr.size(), -1);
+        for (size_t e = 0; e < entry_edge.size(); e++)
+            if (entry_edge[e] >= 0)
+                P.row_edge[e] = static_cast<int32_t>(static_cast<uint32_t>(entry_edge[e]) | ((P.nbr[e] & kRoleB) ? 0x80000000u : 0u));
+    }
     P.n_internal_entries = useful;
     int64_t int_slots = 0;
     for (int32_t s = 0; s < P.n_slices; s++) int_slots += static_cast<int64_t>(P.rows_int[static_cast<size_t>(s)]) * kSlice;

@@ -84,6 +84,11 @@ struct LevelPlan {
     std::vector<double> te_w;             // [chunk][4][256] a-side weights: -0.5*e (x,y,z) and k = -|e|*smoothing*0.5
     std::vector<uint16_t> gat16;          // [rows*64] internal rows: position p of the entry's edge in its tile's list
                                           //   | kT16RoleB when this node is the edge's b end (it gets -F); kT16Pad
+    // ---- two-phase ("fission") design point: edge fluxes to memory, then a node-centred sum ----
+    std::vector<int32_t> fe_ab;           // [2][n_internal] end points (new ids) of every internal edge, original order
+    std::vector<double> fe_w;             // [4][n_internal] a-side weights -0.5*e (x,y,z) and k
+    std::vector<int32_t> row_edge;        // [rows*64] internal rows: the entry's edge (index into fe_*) | bit 31 when this
+                                          //   node is its b end; -1 = padding / boundary rows
     int64_t n_internal_entries = 0;    // = 2 * internal edges
     double pad_fraction = 0.0;         // padding / useful entries in the internal rows
 

@@ -223,6 +223,8 @@ struct mgcfd_solver {
         Timed t(this, l, MGCFD_LOOP_FLUX, (classes & 1) != 0);
         if (classes != 7) settle_fluxes(lv);                // a partial launch leaves other nodes' memory as it is
         const int accumulate = lv.fluxes_zero ? 0 : 1;     // 0.0 + x: same bits either way
+        if ((opt_variant & 4) && !lv.dp.edge_flux)          // two-phase design point: edge-flux scratch on first use
+            lv.dp.edge_flux = dev_alloc<double>(static_cast<size_t>(lv.dp.n_edges_pad) * 5 + 8);
         if (opt_exact) exact::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant, nullptr);
         else fast::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant, nullptr);
         lv.fluxes_zero = false;
@@ -373,7 +375,7 @@ mgcfd_solver::~mgcfd_solver()
                         lv.cbrt_vol, lv.min_dt, lv.partial_min, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.child4, lv.dp.pro_w, lv.dp.pro_p, lv.dp.pro_tile_n, lv.dp.pro_tile_ids, lv.dp.pro_s16, lv.dp.pro_own16,
                         lv.dp.pro_parent, lv.dp.pro_wsum, lv.dp.te_chunk_ptr, lv.dp.te_count, lv.dp.te_slots, lv.dp.te_w,
-                        lv.dp.gat16};
+                        lv.dp.gat16, lv.dp.fe_ab, lv.dp.fe_w, lv.dp.row_edge, lv.dp.edge_flux};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         for (auto &hp : lv.halo_plans) if (hp.first) (void)hipFree(hp.first);
     }
@@ -510,6 +512,15 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.dp.tile_ovf = dev_upload(P.tile_ovf);
         lv.dp.pad_row = P.slice_row0.back();
         lv.dp.pad_chunk = P.te_chunk_ptr.empty() ? 0 : P.te_chunk_ptr.back();
+        lv.dp.n_edges = d.n_internal;
+        lv.dp.n_edges_pad = (d.n_internal + 255) / 256 * 256;
+        lv.dp.fe_ab = dev_upload(P.fe_ab);
+        lv.dp.fe_w = dev_upload(P.fe_w);
+        lv.plan.row_edge.resize(P.row_edge.size() + 2 * kSlice, -1);                     // two rows of padding
+        lv.dp.row_edge = dev_upload(P.row_edge);
+        lv.plan.fe_ab.clear(); lv.plan.fe_ab.shrink_to_fit();
+        lv.plan.fe_w.clear(); lv.plan.fe_w.shrink_to_fit();
+        lv.plan.row_edge.clear(); lv.plan.row_edge.shrink_to_fit();
         lv.dp.edge_once = (P.edge_once && !std::getenv("MGCFD_NO_EDGE_ONCE")) ? 1 : 0;
         if (lv.dp.edge_once) {
             lv.dp.te_chunk_ptr = dev_upload(P.te_chunk_ptr);
@@ -801,7 +812,7 @@ int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_c
 static void smooth_once(mgcfd_solver *s, int level)
 {
     DeviceLevel &lv = s->level(level);
-    if (s->opt_fuse && !s->opt_indirect_rw && s->opt_timing != 1 && lv.fluxes_zero) {
+    if (s->opt_fuse && !(s->opt_variant & 4) && !s->opt_indirect_rw && s->opt_timing != 1 && lv.fluxes_zero) {
         // Fused stages: flux + time_step in one launch each.  No copy<double>(old_variables, variables)
         // (:383): the sweep's start state stays where it is and BECOMES old_variables; the stages run
         // variables -> q_alt -> (the former old_variables buffer) -> q_alt, and the three buffers
@@ -1211,6 +1222,8 @@ int mgcfd_bench_flux(mgcfd_solver *s, int level, int launches, double *avg_secon
         s->use_device();
         DeviceLevel &lv = s->level(level);
         hipEvent_t a = s->get_event(), b = s->get_event();
+        if ((s->opt_variant & 4) && !lv.dp.edge_flux)
+            lv.dp.edge_flux = dev_alloc<double>(static_cast<size_t>(lv.dp.n_edges_pad) * 5 + 8);
         auto go = [&] {
             if (s->opt_exact) exact::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, s->opt_variant, nullptr);
             else fast::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, s->opt_variant, nullptr);

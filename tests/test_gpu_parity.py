@@ -179,10 +179,10 @@ def test_vcycles_three_levels(oracle, mesh3_dir, exact, fuse):
 
 
 @pytest.mark.parametrize("fuse", [True, False])
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_vcycles_flux_variants(oracle, mesh3_dir, variant, fuse):
-    """Every flux variant (length factor streamed / recomputed, node gather / edge-once tiles) runs the
-    same V-cycles bit-identically to the oracle."""
+    """Every flux variant (length factor streamed / recomputed, node gather / edge-once tiles / the
+    two-phase design point) runs the same V-cycles bit-identically to the oracle."""
     import mgcfd
     _run_both(mgcfd, oracle, mesh3_dir, 4, True, fuse=fuse, variant=variant)
     _run_both(mgcfd, oracle, mesh3_dir, 2, False, fuse=fuse, variant=variant)
@@ -698,6 +698,22 @@ def test_full_size_internal_flux_is_conservative(big):
     assert np.isfinite(f).all()
     assert np.all(np.abs(f.sum(axis=0)) <= 1e-12 * np.abs(f).sum(axis=0))
     assert s.loop_iters(0)["flux"] % levels[0]["n_internal"] == 0
+
+
+def test_full_size_flux_variants_agree(big):
+    """On the 300K-node level every flux variant writes the same bits (one launch, all edge classes)."""
+    mgcfd, s, q, levels = big
+    assert s.has_edge_once(0)
+    out = {}
+    for v in (0, 1, 2, 3, 4):
+        s.set_option("flux_variant", v)
+        s.set(0, "variables", q)
+        s.zero_fluxes(0)
+        s.compute_fluxes(0)
+        out[v] = s.get(0, "fluxes")
+    s.set_option("flux_variant", 0)
+    for v in (1, 2, 3, 4):
+        assert np.array_equal(out[0].view(np.int64), out[v].view(np.int64)), v
 
 
 def test_full_size_deterministic_and_modes_agree(big):

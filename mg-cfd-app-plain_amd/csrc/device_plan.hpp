@@ -40,7 +40,7 @@ struct FusedStep {
     // look-ahead for the NEXT sweep on this level, from the state this launch produces:
     double *next_partial_min = nullptr;       // first half of compute_step_factor: per-tile minima of 0.5*cbrt(vol)/(|v|+c)
     const double *cbrt_vol = nullptr;
-    int next_legacy = 0;                      // mesh_name = fvcorr: step_factors[i] = 0.5/(sqrt(vol)*(|v|+c)) (cfd_loops.cpp:37-61)
+    double *next_legacy_sf = nullptr;         // mesh_name = fvcorr: next sweep's step factors 0.5/(sqrt(vol)*(|v|+c)) (cfd_loops.cpp:37-61) go here
 };
 
 // Device pointers of one level's gather plan.

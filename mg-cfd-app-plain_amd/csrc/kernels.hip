@@ -408,9 +408,9 @@ __device__ __forceinline__ void finish_node(int64_t i, int64_t nel, int64_t stri
             const Derived d = derive(rho, mx, my, mz, en);
             const double dt = fs.cbrt_vol[i] / (d.speed + d.c);          // k_step_factor_local
             sf_next = 0.5 * dt;
-        } else if (fs.next_legacy) {
+        } else if (fs.next_legacy_sf) {
             const Derived d = derive(rho, mx, my, mz, en);
-            fs.step_factors[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
+            fs.next_legacy_sf[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
         }
     }
     if (fs.next_partial_min) {                      // uniform: every thread of the workgroup takes part
@@ -645,9 +645,9 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             const Derived d = derive(rho, mx, my, mz, en);
             const double dt = fs.cbrt_vol[i] / (d.speed + d.c);          // k_step_factor_local
             sf_next = 0.5 * dt;
-        } else if (fs.next_legacy) {
+        } else if (fs.next_legacy_sf) {
             const Derived d = derive(rho, mx, my, mz, en);
-            fs.step_factors[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
+            fs.next_legacy_sf[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
         }
     }
     if (fs.next_partial_min) {                      // uniform: every thread of the workgroup takes part

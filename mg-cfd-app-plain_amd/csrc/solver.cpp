@@ -66,8 +66,13 @@ struct DeviceLevel {
     double *state[3] = {nullptr, nullptr, nullptr};
     int rot = 0;
     void apply_rot() { q = state[rot % 3]; q_alt = state[(rot + 1) % 3]; old_variables = state[(rot + 2) % 3]; }
-    bool min_ahead = false;              // partial_min already holds the first half of compute_step_factor for the
-                                         // CURRENT variables (written by the stage that produced them)
+    bool min_ahead = false;              // the launch that produced the CURRENT variables looked ahead: partial_min holds the
+                                         // first half of compute_step_factor for them (global time step), or sf_alt holds
+                                         // their step factors (mesh_name = fvcorr, local time step)
+    double *sf_alt = nullptr;            // [stride] fvcorr look-ahead target; swapped with step_factors when consumed
+    int sf_par = 0;                      // parity of those swaps (part of the graph keys)
+    double *sfb[2] = {nullptr, nullptr};
+    void apply_sf() { step_factors = sfb[sf_par & 1]; sf_alt = sfb[(sf_par & 1) ^ 1]; }
     double *step_factors = nullptr, *volumes = nullptr, *cbrt_vol = nullptr;                  // [stride]
     double *min_dt = nullptr;            // global-min time step scalar (after the reduction)
     double *partial_min = nullptr;       // one partial minimum per step-factor workgroup
@@ -103,9 +108,9 @@ struct mgcfd_solver {
     int timing_stride = 8;                  // OPT_TIMING == 2: bracket the flux launches of every Nth sweep
     int64_t sweep_counter = 0;
     bool in_timed_group = false;
-    struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; bool ahead_after = false; int rot_after = 0; };
+    struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; bool ahead_after = false; int rot_after = 0; int sf_par_after = 0; };
     std::map<uint64_t, SweepGraph> sweep_graphs;   // captured smoothing sweeps, keyed by (level, options)
-    struct CycleGraph { hipGraphExec_t exec = nullptr; std::vector<std::vector<int64_t>> iters; std::vector<bool> ahead_after; std::vector<int> rot_after; };
+    struct CycleGraph { hipGraphExec_t exec = nullptr; std::vector<std::vector<int64_t>> iters; std::vector<bool> ahead_after; std::vector<int> rot_after, sf_par_after; };
     std::map<uint64_t, CycleGraph> cycle_graphs;   // captured whole multigrid cycles, keyed by options
     static constexpr int kRmsRing = 4096;
     double *rms_ring = nullptr;                    // level-0 sum of squares of the cycles run since the last read-back
@@ -247,7 +252,8 @@ struct mgcfd_solver {
         fs.old_variables = old ? old : lv.old_variables;
         fs.q_out = out;
         fs.old_out = old_out;
-        fs.next_partial_min = look_ahead ? lv.partial_min : nullptr;
+        fs.next_partial_min = (look_ahead && mesh_variant != MGCFD_MESH_FVCORR) ? lv.partial_min : nullptr;
+        fs.next_legacy_sf = (look_ahead && mesh_variant == MGCFD_MESH_FVCORR) ? lv.sf_alt : nullptr;
         fs.cbrt_vol = lv.cbrt_vol;
         if (out == lv.q) lv.min_ahead = false;      // (a caller that looks ahead sets it after its last stage)
         fs.partial_min = apply_min == 1 ? lv.partial_min : (apply_min == 2 ? lv.min_dt : nullptr);
@@ -371,7 +377,7 @@ mgcfd_solver::~mgcfd_solver()
     for (auto &p : pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto e : free_events) (void)hipEventDestroy(e);
     for (auto &lv : L) {
-        void *ptrs[] = {lv.q_alt, lv.dp.nbr16, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
+        void *ptrs[] = {lv.q_alt, lv.sf_alt, lv.dp.nbr16, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
                         lv.cbrt_vol, lv.min_dt, lv.partial_min, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.child4, lv.dp.pro_w, lv.dp.pro_p, lv.dp.pro_tile_n, lv.dp.pro_tile_ids, lv.dp.pro_s16, lv.dp.pro_own16,
                         lv.dp.pro_parent, lv.dp.pro_wsum, lv.dp.te_chunk_ptr, lv.dp.te_count, lv.dp.te_slots, lv.dp.te_w,
@@ -471,6 +477,8 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.fluxes = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.residuals = dev_alloc<double>(static_cast<size_t>(stride) * 5);
         lv.step_factors = dev_alloc<double>(static_cast<size_t>(stride));
+        lv.sf_alt = dev_alloc<double>(static_cast<size_t>(stride));
+        lv.sfb[0] = lv.step_factors; lv.sfb[1] = lv.sf_alt;
         lv.min_dt = dev_alloc<double>(1);
         lv.partial_min = dev_alloc<double>(static_cast<size_t>((nel + 255) / 256));
         lv.sumsq = dev_alloc<double>(1);
@@ -581,6 +589,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * stride, s->stream));
         HIP_CHECK(hipMemsetAsync(lv.residuals, 0, sizeof(double) * 5 * stride, s->stream));
         HIP_CHECK(hipMemsetAsync(lv.step_factors, 0, sizeof(double) * stride, s->stream));
+        HIP_CHECK(hipMemsetAsync(lv.sf_alt, 0, sizeof(double) * stride, s->stream));
         exact::launch_init_variables(s->stream, stride, s->ff, lv.q);
         exact::launch_init_variables(s->stream, stride, s->ff, lv.q_alt);     // valid numbers in the padded tail
     }
@@ -819,15 +828,16 @@ static void smooth_once(mgcfd_solver *s, int level)
         // change roles at the end (DeviceLevel::rot).
         const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
         bool apply_pending = global_dt;
-        if (global_dt && lv.min_ahead) {
-            // the launch that produced `variables` already left the first half of compute_step_factor
-            // (:388-395) in partial_min
+        if (lv.min_ahead) {
+            // the launch that produced `variables` already did compute_step_factor's work on them
+            // (:388-395): the per-workgroup minima are in partial_min, or (fvcorr) the factors in sf_alt
+            if (!global_dt) { lv.sf_par ^= 1; lv.apply_sf(); }
             lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;
         } else {
             apply_pending = s->op_step_factor(level, true, false);
         }
         // single level: the next sweep starts from this sweep's result, let the last stage look ahead
-        const bool look_ahead = global_dt && s->L.size() == 1;
+        const bool look_ahead = s->L.size() == 1;
         double *const start = lv.q, *const b1 = lv.q_alt, *const b2 = lv.old_variables;
         mgcfd_solver::Timed group(s, level, MGCFD_LOOP_FLUX, true, s->opt_timing == 2 ? MGCFD_RK : 1);
         s->op_fused_stage(level, 0, start, b1, apply_pending ? 1 : 0, false, start);
@@ -863,7 +873,7 @@ static void run_sweep(mgcfd_solver *s, int level)
         s->opt_timing = keep;
         return;
     }
-    const uint64_t key = (uint64_t(level) << 32) | (uint64_t(lv.rot) << 25) | (uint64_t(lv.min_ahead) << 24) | (uint64_t(s->opt_exact) << 16) | (uint64_t(s->opt_check) << 8) | uint64_t(s->opt_variant & 0xFF);
+    const uint64_t key = (uint64_t(level) << 32) | (uint64_t(lv.sf_par) << 27) | (uint64_t(lv.rot) << 25) | (uint64_t(lv.min_ahead) << 24) | (uint64_t(s->opt_exact) << 16) | (uint64_t(s->opt_check) << 8) | uint64_t(s->opt_variant & 0xFF);
     auto it = s->sweep_graphs.find(key);
     if (it == s->sweep_graphs.end()) {
         mgcfd_solver::SweepGraph g;
@@ -888,12 +898,15 @@ static void run_sweep(mgcfd_solver *s, int level)
         for (int k = 0; k < MGCFD_NUM_LOOPS; k++) { g.iters[k] = lv.iters[k] - before[k]; lv.iters[k] = before[k]; }
         g.ahead_after = lv.min_ahead;
         g.rot_after = lv.rot;
+        g.sf_par_after = lv.sf_par;
         it = s->sweep_graphs.emplace(key, g).first;
     }
     HIP_CHECK(hipGraphLaunch(it->second.exec, s->stream));
     lv.min_ahead = it->second.ahead_after;
     lv.rot = it->second.rot_after;
     lv.apply_rot();
+    lv.sf_par = it->second.sf_par_after;
+    lv.apply_sf();
     for (int k = 0; k < MGCFD_NUM_LOOPS; k++) lv.iters[k] += it->second.iters[k];
 }
 
@@ -908,8 +921,12 @@ int mgcfd_sweep_begin(mgcfd_solver *s, int level)
         // when sweep_end rotates the buffers), and no step-factor kernel when the launch that produced
         // `variables` already left the minima behind.
         const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
-        if (global_dt && lv.min_ahead) lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;
-        else s->op_step_factor(level, true, false);
+        if (lv.min_ahead) {
+            if (!global_dt) { lv.sf_par ^= 1; lv.apply_sf(); }
+            lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;
+        } else {
+            s->op_step_factor(level, true, false);
+        }
         if (global_dt) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
     });
 }
@@ -928,7 +945,7 @@ int mgcfd_sweep_end(mgcfd_solver *s, int level)
         DeviceLevel &lv = s->level(level);
         const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
         const int apply = global_dt ? 2 : 0;
-        const bool look_ahead = global_dt && s->L.size() == 1;
+        const bool look_ahead = s->L.size() == 1;
         double *const start = lv.q;
         double *const b1 = lv.q_alt;
         double *const b2 = lv.old_variables;
@@ -1002,17 +1019,18 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
                 // already computed (min_ahead), so that is part of the key and looked up per cycle.
                 for (int c = 0; c < chunk; c++) {
                     uint64_t key = (uint64_t(s->opt_exact) << 16) | (uint64_t(s->opt_check) << 8) | uint64_t(s->opt_variant & 0xFF);
-                    for (size_t l = 0; l < nl && l < 8; l++) key |= (uint64_t(s->L[l].min_ahead) << (24 + l)) | (uint64_t(s->L[l].rot) << (32 + 2 * l));
+                    for (size_t l = 0; l < nl && l < 8; l++) key |= (uint64_t(s->L[l].min_ahead) << (24 + l)) | (uint64_t(s->L[l].rot) << (32 + 2 * l)) | (uint64_t(s->L[l].sf_par) << (48 + l));
                     auto it = s->cycle_graphs.find(key);
                     if (it == s->cycle_graphs.end()) {
                         mgcfd_solver::CycleGraph g;
                         std::vector<std::vector<int64_t>> before(nl);
                         std::vector<bool> ahead_before;
-                        std::vector<int> rot_before;
+                        std::vector<int> rot_before, sf_before;
                         for (size_t l = 0; l < nl; l++) {
                             before[l].assign(s->L[l].iters, s->L[l].iters + MGCFD_NUM_LOOPS);
                             ahead_before.push_back(s->L[l].min_ahead);
                             rot_before.push_back(s->L[l].rot);
+                            sf_before.push_back(s->L[l].sf_par);
                         }
                         hipGraph_t graph = nullptr;
                         HIP_CHECK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
@@ -1034,9 +1052,12 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
                             }
                             g.ahead_after.push_back(s->L[l].min_ahead);
                             g.rot_after.push_back(s->L[l].rot);
+                            g.sf_par_after.push_back(s->L[l].sf_par);
                             s->L[l].min_ahead = ahead_before[l];          // nothing ran yet: capture only recorded
                             s->L[l].rot = rot_before[l];
                             s->L[l].apply_rot();
+                            s->L[l].sf_par = sf_before[l];
+                            s->L[l].apply_sf();
                         }
                         it = s->cycle_graphs.emplace(key, std::move(g)).first;
                     }
@@ -1046,6 +1067,8 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
                         s->L[l].min_ahead = it->second.ahead_after[l];
                         s->L[l].rot = it->second.rot_after[l];
                         s->L[l].apply_rot();
+                        s->L[l].sf_par = it->second.sf_par_after[l];
+                        s->L[l].apply_sf();
                     }
                 }
             } else {

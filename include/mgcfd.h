@@ -213,6 +213,15 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out);
 int mgcfd_get_array(mgcfd_solver *s, int level, int which, double *out);        /* [nel*5] or [nel] */
 int mgcfd_set_array(mgcfd_solver *s, int level, int which, const double *in);
 /* Edge weights after adjust/dampen, original edge order: [n_edges] records. */
+/* Device address of a node array as the library holds it: [ncols][stride] fp64, structure of arrays in the
+ * LIBRARY's node numbering (ncols = 5, or 1 for step factors / volumes); *count = ncols * stride elements.
+ * For moving a whole level's array between two solvers built from the SAME level data (same numbering), e.g. one
+ * multigrid level per GPU: send the coarse `variables` after mgcfd_restrict, the coarse `residuals` before
+ * mgcfd_prolong.  The address of `variables` / `old_variables` changes with every smoothing sweep (the state buffers
+ * rotate): ask again after each one.  A caller that WRITES through the pointer must say so with
+ * mgcfd_array_written before the next library call on that level. */
+int mgcfd_array_devptr(mgcfd_solver *s, int level, int which, void **devptr, int64_t *count);
+int mgcfd_array_written(mgcfd_solver *s, int level, int which);
 int mgcfd_get_edges(mgcfd_solver *s, int level, mgcfd_edge *out);
 
 /* ---------------------------------------------------------------------------------

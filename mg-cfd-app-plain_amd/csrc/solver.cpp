@@ -1147,6 +1147,31 @@ int mgcfd_set_array(mgcfd_solver *s, int level, int which, const double *in)
         if (which == MGCFD_ARR_VARIABLES) lv.min_ahead = false;
     });
 }
+int mgcfd_array_devptr(mgcfd_solver *s, int level, int which, void **devptr, int64_t *count)
+{
+    REQUIRE(s); REQUIRE(devptr); REQUIRE(count);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        int nc = 0;
+        double *p = array_ptr(lv, which, &nc);
+        if (which == MGCFD_ARR_FLUXES) s->settle_fluxes(lv);
+        *devptr = p;
+        *count = int64_t(nc) * lv.dp.stride;
+    });
+}
+int mgcfd_array_written(mgcfd_solver *s, int level, int which)
+{
+    REQUIRE(s);
+    return guarded([&] {
+        DeviceLevel &lv = s->level(level);
+        int nc = 0;
+        (void)array_ptr(lv, which, &nc);
+        if (which == MGCFD_ARR_VOLUMES) throw std::invalid_argument("volumes are fixed at creation");
+        if (which == MGCFD_ARR_FLUXES) { lv.fluxes_zero = false; lv.fluxes_stale = false; }
+        if (which == MGCFD_ARR_VARIABLES) lv.min_ahead = false;
+    });
+}
 int mgcfd_get_edges(mgcfd_solver *s, int level, mgcfd_edge *out)
 {
     REQUIRE(s); REQUIRE(out);

@@ -90,6 +90,8 @@ _SIGNATURES = [
     ("mgcfd_run_cycles", C.c_int, [_vp, C.c_int, _vp]),
     ("mgcfd_get_array", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     ("mgcfd_set_array", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    ("mgcfd_array_devptr", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int64)]),
+    ("mgcfd_array_written", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mgcfd_get_edges", C.c_int, [_vp, C.c_int, _vp]),
     ("mgcfd_get_loop_iters", C.c_int, [_vp, C.c_int, _vp]),
     ("mgcfd_get_loop_times", C.c_int, [_vp, C.c_int, _vp]),
@@ -259,6 +261,16 @@ class Solver:
 
     def set_option(self, name: str, value: int):
         self._c(self.lib.mgcfd_set_option(self.handle, OPT[name], int(value)))
+
+    def array_devptr(self, l: int, name: str):
+        """(device address, element count) of a node array as the library holds it ([ncols][stride] fp64,
+        library numbering); see mgcfd_array_devptr."""
+        p, n = _vp(), C.c_int64()
+        self._c(self.lib.mgcfd_array_devptr(self.handle, l, ARR[name], C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def array_written(self, l: int, name: str):
+        self._c(self.lib.mgcfd_array_written(self.handle, l, ARR[name]))
 
     def has_edge_once(self, l: int) -> bool:
         v = C.c_int()

@@ -31,6 +31,18 @@ class DevScalarView:
         return torch.as_tensor(self, device=device)
 
 
+class DevArrayView:
+    """Zero-copy torch view of an fp64 device array owned by libmgcfd_hip.so."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+    def tensor(self, device):
+        import torch
+        return torch.as_tensor(self, device=device)
+
+
 class HipSolverAdapter:
     """Adds the two scalar views to a :class:`mgcfd.api.Solver` (device tensors aliasing library memory)."""
 
@@ -50,6 +62,12 @@ class HipSolverAdapter:
     def sumsq_tensor(self, level):
         # launches the reduction; the returned tensor aliases its device result
         return DevScalarView(self.s.residual_sumsq_devptr(level)).tensor(self.device)
+
+    def array_tensor(self, level, name):
+        """A whole node array of a level as the library holds it (the address is asked for every time: the state
+        buffers rotate with every sweep)."""
+        ptr, count = self.s.array_devptr(level, name)
+        return DevArrayView(ptr, count).tensor(self.device)
 
 
 class ShardedSweep:
@@ -168,3 +186,50 @@ class PartitionedSweep:
             s.time_step(0, j)
             self.exchange("variables")
         s.residual(0)
+
+
+class LevelPerRankCycle:
+    """One multigrid level per rank (BASELINE config 4): rank r owns level l when rank_of(l) == r.  The V-cycle is
+    sequential in levels, so this buys placement, not concurrency; what moves is what the reference's cycle loop hands
+    from level to level (src/euler3d_cpu_double.cpp:527-688): the restricted coarse `variables` on the way up (computed
+    where the fine level lives, 40 B per coarse node) and the coarse `residuals` on the way down — whole-array
+    point-to-point messages between two solvers built from the same level data (torch.distributed send/recv: RCCL over
+    one xGMI link on the GPUs, gloo in the CPU tests).
+
+    `solver` holds every level (only the owned ones are ever swept) and provides smooth / restrict / prolong plus
+    array_tensor(level, name) -> tensor aliasing the level's array and array_written(level, name)."""
+
+    def __init__(self, solver, n_levels, rank, world, rank_of=None, send=None, recv=None, dist=None):
+        self.s, self.n, self.rank, self.world = solver, n_levels, rank, world
+        self.rank_of = rank_of or (lambda l: l % world)
+        self.dist = dist
+        self.send = send or (lambda t, dst: dist.send(t, dst))
+        self.recv = recv or (lambda t, src: dist.recv(t, src))
+
+    def _hand_over(self, level, name, src, dst):
+        if src == dst:
+            return
+        if self.rank == src:
+            self.send(self.s.array_tensor(level, name), dst)
+        elif self.rank == dst:
+            self.recv(self.s.array_tensor(level, name), src)
+            self.s.array_written(level, name)
+
+    def cycle(self):
+        """One multigrid cycle: sweeps on levels 0..n-1, n-2..1, restrictions going up, prolongations coming down."""
+        s, n, me = self.s, self.n, self.rank
+        for l in range(n):
+            owner = self.rank_of(l)
+            if me == owner:
+                s.smooth(l, 1)
+            if l + 1 < n:
+                if me == owner:
+                    s.restrict(l)                                   # fills level l+1's variables HERE
+                self._hand_over(l + 1, "variables", owner, self.rank_of(l + 1))
+        for l in range(n - 2, -1, -1):
+            owner = self.rank_of(l)
+            self._hand_over(l + 1, "residuals", self.rank_of(l + 1), owner)
+            if me == owner:
+                s.prolong(l)
+                if l > 0:
+                    s.smooth(l, 1)

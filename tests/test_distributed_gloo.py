@@ -280,3 +280,93 @@ def test_partitioned_level_over_gloo_equals_whole_mesh(tmp_path, oracle):
         assert np.array_equal(got.view(np.int64), whole.v[ids].view(np.int64))     # same order of sums => same bits
         seen += len(ids)
     assert seen == L["nel"]
+
+
+# ------------------------------------------------------------------------------------------
+# One multigrid level per rank (BASELINE config 4): restricted variables up, residuals down
+# ------------------------------------------------------------------------------------------
+GOLDEN_3LVL = os.path.join(ROOT, "tests", "golden", "m6_3lvl")
+
+
+class OracleMGSolver:
+    """Oracle-backed stand-in for a multi-level mgcfd.api.Solver: smooth / restrict / prolong on the
+    reference's own arrays, torch tensors aliasing them."""
+
+    def __init__(self, oracle):
+        import ctypes as C
+        self.O, self.C = oracle, C
+        self.lib = oracle.load()
+        self.case = oracle.OracleCase.from_input_dat(os.path.join(GOLDEN_3LVL, "input", "input.dat"))
+        self.ff = oracle.farfield()
+        for l in range(self.case.nlevels):
+            L = self.case.levels[l]
+            self.lib.ora_adjust_ewt(L.coords, L.n_edges, L.edges)
+            self.lib.ora_dampen_ewt(L.n_edges, L.edges, 5e-8)
+            self.lib.ora_initialize_variables(L.nel, L.variables, C.byref(self.ff))
+        self.written = []
+
+    def smooth(self, l, sweeps=1):
+        L, lib = self.case.levels[l], self.lib
+        for _ in range(sweeps):
+            self.case.array(l, "old_variables")[:] = self.case.array(l, "variables")
+            lib.ora_compute_step_factor(L.nel, L.variables, L.volumes, L.step_factors)
+            for j in range(3):
+                lib.ora_compute_flux_edge(L.internal_start, L.n_internal, L.edges, L.variables, L.fluxes)
+                lib.ora_compute_boundary_flux_edge(L.boundary_start, L.n_boundary, L.edges, L.variables, L.fluxes)
+                lib.ora_compute_wall_flux_edge(L.wall_start, L.n_wall, L.edges, L.variables, L.fluxes, self.C.byref(self.ff))
+                lib.ora_time_step(j, L.nel, L.step_factors, L.fluxes, L.old_variables, L.variables)
+            lib.ora_residual(L.nel, L.old_variables, L.variables, L.residuals)
+
+    def restrict(self, fine):
+        F, Cc = self.case.levels[fine], self.case.levels[fine + 1]
+        scratch = np.zeros(Cc.nel, dtype=np.int64)
+        self.lib.ora_mg_restrict(F.variables, Cc.variables, Cc.nel, F.mg_map, self.O.ptr(scratch), F.mgc)
+
+    def prolong(self, fine):
+        F, Cc = self.case.levels[fine], self.case.levels[fine + 1]
+        self.lib.ora_prolong_residuals_interpolate_proper(F.edges, F.n_internal, Cc.residuals, F.residuals, F.variables,
+                                                           F.nel, F.mg_map, Cc.coords, F.coords)
+
+    def array_tensor(self, l, name):
+        return torch.from_numpy(self.case.array(l, name))
+
+    def array_written(self, l, name):
+        self.written.append((l, name))
+
+
+def _level_worker(rank, world, port, cycles, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    from mgcfd.distributed import LevelPerRankCycle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    solver = OracleMGSolver(oracle_py)
+    cyc = LevelPerRankCycle(solver, solver.case.nlevels, rank, world, dist=dist)
+    for _ in range(cycles):
+        cyc.cycle()
+    for l in range(solver.case.nlevels):
+        if cyc.rank_of(l) == rank:
+            np.save(os.path.join(out_dir, f"lvl{l}.npy"), solver.case.array(l, "variables").copy())
+    np.save(os.path.join(out_dir, f"written_{rank}.npy"), np.array([f"{l}:{n}" for l, n in solver.written]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_one_level_per_rank_equals_the_reference_binary(tmp_path, oracle):
+    """Three levels on two ranks (levels 0 and 2 on rank 0, level 1 on rank 1): after the golden case's two
+    cycles level 0 must equal the reference binary's dump bit for bit, and every level the single-process oracle."""
+    world, cycles = 2, 2
+    mp.spawn(_level_worker, args=(world, _free_port(), cycles, str(tmp_path)), nprocs=world, join=True)
+    want = np.loadtxt(os.path.join(GOLDEN_3LVL, "variables.level0.txt"))
+    got = np.load(tmp_path / "lvl0.npy").reshape(-1, 5)
+    assert np.array_equal(got.view(np.int64), want.view(np.int64))
+    oc = oracle.OracleCase.from_input_dat(os.path.join(GOLDEN_3LVL, "input", "input.dat"))
+    rc, _, _ = oc.solve(cycles, run_indirect_rw=False)
+    assert rc == 0
+    for l in range(oc.nlevels):
+        assert np.array_equal(np.load(tmp_path / f"lvl{l}.npy").view(np.int64), oc.array(l, "variables").view(np.int64)), l
+    # the receiving side told its solver about every array it received
+    assert set(np.load(tmp_path / "written_1.npy")) == {"1:variables", "2:residuals"}
+    assert set(np.load(tmp_path / "written_0.npy")) == {"2:variables", "1:residuals"}

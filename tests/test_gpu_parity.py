@@ -646,6 +646,56 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant):
     assert abs(np.sqrt(sumsq / L["nel"]) - want_rms) <= 1e-12 * want_rms
 
 
+def test_one_level_per_solver_equals_run_cycles(mesh3_dir):
+    """BASELINE config 4 in miniature: the three levels of the case split over two solvers (two "ranks": levels 0
+    and 2 on one, level 1 on the other), the restricted variables and the coarse residuals handed over as whole
+    arrays through tensors that alias library memory (threads for ranks, a queue for RCCL send/recv).  Three
+    cycles must equal mgcfd_run_cycles on one solver bit for bit, on every level."""
+    import queue
+    import threading
+    import torch
+    import mgcfd
+    from mgcfd.distributed import HipSolverAdapter, LevelPerRankCycle
+    dev = torch.device("cuda", 0)
+    cycles, world = 3, 2
+    whole = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", mesh3_dir))
+    whole.run_cycles(cycles)
+    want = [whole.get(l, "variables") for l in range(whole.num_levels)]
+    n_levels = whole.num_levels
+    whole.close()
+
+    tstream = torch.cuda.Stream()
+    solvers = [mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", mesh3_dir)) for _ in range(world)]
+    for s in solvers:
+        s.set_stream(tstream.cuda_stream)
+    boxes = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    errors = []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            torch.cuda.set_stream(tstream)
+            send = lambda t, dst: boxes[(rank, dst)].put(t.clone())
+            recv = lambda t, src: t.copy_(boxes[(src, rank)].get(timeout=60))
+            cyc = LevelPerRankCycle(HipSolverAdapter(solvers[rank], dev), n_levels, rank, world, send=send, recv=recv)
+            for _ in range(cycles):
+                cyc.cycle()
+        except Exception as e:                               # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for l in range(n_levels):
+        got = solvers[l % world].get(l, "variables")
+        assert np.array_equal(got.view(np.int64), want[l].view(np.int64)), f"level {l}"
+    for s in solvers:
+        s.close()
+
+
 def test_min_scalar_aliases_device_memory(mesh3_dir):
     """The all-reduce acts on a torch tensor that must alias the library's device scalar."""
     import torch

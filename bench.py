@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--lattice", type=int, default=LATTICE, help="nodes per side of the synthetic M6-L0-like level")
     ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
-    ap.add_argument("--variant", type=int, default=0, help="MGCFD_OPT_FLUX_VARIANT (0 stream k, 1 recompute k)")
+    ap.add_argument("--variant", type=int, default=-1, help="MGCFD_OPT_FLUX_VARIANT (-1 automatic, 0 stream k, 1 recompute k, 2/3 edge-once tiles)")
     ap.add_argument("--vcycle", action="store_true",
                     help="also measure wall seconds per 4-level MG V-cycle (off by default so that a rocprofv3 "
                          "summary of the default command holds only the timed workload's launches)")

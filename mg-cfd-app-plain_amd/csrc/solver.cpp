@@ -66,6 +66,7 @@ struct DeviceLevel {
     double *state[3] = {nullptr, nullptr, nullptr};
     int rot = 0;
     void apply_rot() { q = state[rot % 3]; q_alt = state[(rot + 1) % 3]; old_variables = state[(rot + 2) % 3]; }
+    int64_t row_bytes = 0;               // bytes of the incidence rows (ids + weights): decides the automatic flux variant
     bool min_ahead = false;              // the launch that produced the CURRENT variables looked ahead: partial_min holds the
                                          // first half of compute_step_factor for them (global time step), or sf_alt holds
                                          // their step factors (mesh_name = fvcorr, local time step)
@@ -104,7 +105,7 @@ struct mgcfd_solver {
     FarField ff{};
     double ff17[17] = {0};
     unsigned long long *err = nullptr;       // device: packed (cell << 8 | code), ~0 = clean
-    int opt_exact = 1, opt_timing = 0, opt_indirect_rw = 0, opt_check = 1, opt_variant = 0, opt_fuse = 1, opt_graph = 0;
+    int opt_exact = 1, opt_timing = 0, opt_indirect_rw = 0, opt_check = 1, opt_variant = -1, opt_fuse = 1, opt_graph = 0;
     int timing_stride = 8;                  // OPT_TIMING == 2: bracket the flux launches of every Nth sweep
     int64_t sweep_counter = 0;
     bool in_timed_group = false;
@@ -221,6 +222,14 @@ struct mgcfd_solver {
         lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;
         return apply_pending;
     }
+    // MGCFD_OPT_FLUX_VARIANT = -1 (auto): stream the edge-length factor while a level's incidence rows fit the
+    // Infinity Cache, recompute it from the weights (8 of 34 bytes per entry less) once they do not — measured
+    // cross-over at about 1 M nodes / 3 M edges (equal at 0.3-1.0 M nodes, +13 % at 1.5 M, +17 % at 2.4 M)
+    int variant_for(const DeviceLevel &lv) const
+    {
+        if (opt_variant >= 0) return opt_variant;
+        return lv.row_bytes > (int64_t(192) << 20) ? 1 : 0;
+    }
     // classes: bit0 internal, bit1 solid wall (-1), bit2 far field (-2)
     void op_flux(int l, int classes)
     {
@@ -228,10 +237,11 @@ struct mgcfd_solver {
         Timed t(this, l, MGCFD_LOOP_FLUX, (classes & 1) != 0);
         if (classes != 7) settle_fluxes(lv);                // a partial launch leaves other nodes' memory as it is
         const int accumulate = lv.fluxes_zero ? 0 : 1;     // 0.0 + x: same bits either way
-        if ((opt_variant & 4) && !lv.dp.edge_flux)          // two-phase design point: edge-flux scratch on first use
+        const int variant = variant_for(lv);
+        if ((variant & 4) && !lv.dp.edge_flux)              // two-phase design point: edge-flux scratch on first use
             lv.dp.edge_flux = dev_alloc<double>(static_cast<size_t>(lv.dp.n_edges_pad) * 5 + 8);
-        if (opt_exact) exact::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant, nullptr);
-        else fast::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, opt_variant, nullptr);
+        if (opt_exact) exact::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, variant, nullptr);
+        else fast::launch_flux(stream, lv.dp, lv.q, ff, lv.fluxes, classes, accumulate, variant, nullptr);
         lv.fluxes_zero = false;
         lv.fluxes_stale = false;
         if (classes & 1) lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
@@ -264,8 +274,8 @@ struct mgcfd_solver {
         fs.err = err;
         fs.check = opt_check;
         Timed t(this, l, MGCFD_LOOP_FLUX, true);
-        if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, opt_variant, &fs);
-        else fast::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, opt_variant, &fs);
+        if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs);
+        else fast::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs);
         lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
         lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
     }
@@ -518,6 +528,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         }
         lv.dp.tile_ovf_ptr = dev_upload(P.tile_ovf_ptr);
         lv.dp.tile_ovf = dev_upload(P.tile_ovf);
+        lv.row_bytes = int64_t(P.slice_row0.back()) * kSlice * 34;
         lv.dp.pad_row = P.slice_row0.back();
         lv.dp.pad_chunk = P.te_chunk_ptr.empty() ? 0 : P.te_chunk_ptr.back();
         lv.dp.n_edges = d.n_internal;
@@ -821,7 +832,7 @@ int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_c
 static void smooth_once(mgcfd_solver *s, int level)
 {
     DeviceLevel &lv = s->level(level);
-    if (s->opt_fuse && !(s->opt_variant & 4) && !s->opt_indirect_rw && s->opt_timing != 1 && lv.fluxes_zero) {
+    if (s->opt_fuse && !(s->variant_for(lv) & 4) && !s->opt_indirect_rw && s->opt_timing != 1 && lv.fluxes_zero) {
         // Fused stages: flux + time_step in one launch each.  No copy<double>(old_variables, variables)
         // (:383): the sweep's start state stays where it is and BECOMES old_variables; the stages run
         // variables -> q_alt -> (the former old_variables buffer) -> q_alt, and the three buffers
@@ -1270,11 +1281,12 @@ int mgcfd_bench_flux(mgcfd_solver *s, int level, int launches, double *avg_secon
         s->use_device();
         DeviceLevel &lv = s->level(level);
         hipEvent_t a = s->get_event(), b = s->get_event();
-        if ((s->opt_variant & 4) && !lv.dp.edge_flux)
+        const int variant = s->variant_for(lv);
+        if ((variant & 4) && !lv.dp.edge_flux)
             lv.dp.edge_flux = dev_alloc<double>(static_cast<size_t>(lv.dp.n_edges_pad) * 5 + 8);
         auto go = [&] {
-            if (s->opt_exact) exact::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, s->opt_variant, nullptr);
-            else fast::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, s->opt_variant, nullptr);
+            if (s->opt_exact) exact::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, variant, nullptr);
+            else fast::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, variant, nullptr);
         };
         go();
         HIP_CHECK(hipEventRecord(a, s->stream));

@@ -696,6 +696,47 @@ def test_one_level_per_solver_equals_run_cycles(mesh3_dir):
         s.close()
 
 
+def test_rccl_accepts_the_aliased_tensors(mesh3_dir):
+    """A one-rank RCCL group (backend "nccl"): the collectives the multi-rank paths issue — all-reduce(MIN) on the
+    time-step scalar (async, as ShardedSweep does around sweep_flux0), all-reduce(SUM) on the RMS scalar and a
+    broadcast on a whole level array — run on tensors that alias library memory and leave the values intact."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import mgcfd
+    from mgcfd.distributed import HipSolverAdapter
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        st = torch.cuda.Stream()
+        torch.cuda.set_stream(st)
+        s = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", mesh3_dir))
+        s.set_stream(st.cuda_stream)
+        s.set(0, "variables", perturbed_state(s.nel(0), s.far_field()[:5], seed=3))
+        ad = HipSolverAdapter(s, torch.device("cuda", 0))
+        ref = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", mesh3_dir))
+        ref.set(0, "variables", perturbed_state(s.nel(0), s.far_field()[:5], seed=3))
+        ref.smooth(0, 2)
+        for _ in range(2):
+            s.sweep_begin(0)
+            work = dist.all_reduce(ad.min_tensor(0), op=dist.ReduceOp.MIN, async_op=True)
+            s.sweep_flux0(0)
+            work.wait()
+            s.sweep_end(0)
+        t = ad.sumsq_tensor(0).clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.broadcast(ad.array_tensor(0, "variables"), src=0)
+        assert np.array_equal(s.get(0, "variables").view(np.int64), ref.get(0, "variables").view(np.int64))
+        assert abs(np.sqrt(float(t.item()) / s.nel(0)) - ref.calc_rms(0)) <= 1e-12 * ref.calc_rms(0)
+        s.close(); ref.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        dist.destroy_process_group()
+
+
 def test_min_scalar_aliases_device_memory(mesh3_dir):
     """The all-reduce acts on a torch tensor that must alias the library's device scalar."""
     import torch

@@ -374,6 +374,7 @@ __device__ __forceinline__ void finish_node(int64_t i, int64_t nel, int64_t stri
     // (operands fetched here, not under the row loop: the loop already sits at the register budget
     //  of 3 waves per SIMD and hoisting these twelve registers makes it spill)
     double sf_next = __longlong_as_double(0x7FF0000000000000LL);          // +inf: lanes past nel
+    double ss = 0.0;                                                      // this node's share of the residual sum of squares
     if (i < nel) {
         const double r0 = fs.old_variables[i], r1 = fs.old_variables[stride + i], r2 = fs.old_variables[2 * stride + i],
                      r3 = fs.old_variables[3 * stride + i], r4 = fs.old_variables[4 * stride + i];
@@ -392,8 +393,10 @@ __device__ __forceinline__ void finish_node(int64_t i, int64_t nel, int64_t stri
         store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
         if (fs.old_out) store_conserved(fs.old_out, stride, i, r0, r1, r2, r3, r4);
         if (fs.residuals) {
-            fs.residuals[i] = rho - r0; fs.residuals[stride + i] = mx - r1; fs.residuals[2 * stride + i] = my - r2;
-            fs.residuals[3 * stride + i] = mz - r3; fs.residuals[4 * stride + i] = en - r4;
+            const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
+            fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
+            fs.residuals[3 * stride + i] = d3; fs.residuals[4 * stride + i] = d4;
+            if (fs.sumsq_partial) ss = (((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3) + d4 * d4;
         }
         if (fs.check) {
             const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
@@ -413,15 +416,17 @@ __device__ __forceinline__ void finish_node(int64_t i, int64_t nel, int64_t stri
             fs.next_legacy_sf[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
         }
     }
-    if (fs.next_partial_min) {                      // uniform: every thread of the workgroup takes part
-        __shared__ double s_next[kBlock / 64];
+    if (fs.next_partial_min || fs.sumsq_partial) {  // uniform: every thread of the workgroup takes part
+        __shared__ double s_next[2][kBlock / 64];
         sf_next = wave_min(sf_next);
-        if ((threadIdx.x & 63) == 0) s_next[threadIdx.x >> 6] = sf_next;
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) { s_next[0][threadIdx.x >> 6] = sf_next; s_next[1][threadIdx.x >> 6] = ss; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            double m = s_next[0];
-            for (int wv = 1; wv < kBlock / 64; wv++) m = fmin(m, s_next[wv]);
-            fs.next_partial_min[t] = m;
+            double m = s_next[0][0], sum = s_next[1][0];
+            for (int wv = 1; wv < kBlock / 64; wv++) { m = fmin(m, s_next[0][wv]); sum += s_next[1][wv]; }
+            if (fs.next_partial_min) fs.next_partial_min[t] = m;
+            if (fs.sumsq_partial) fs.sumsq_partial[t] = sum;
         }
     }
 }
@@ -611,6 +616,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     // (operands fetched here, not under the row loop: the loop already sits at the register budget
     //  of 3 waves per SIMD and hoisting these twelve registers makes it spill)
     double sf_next = __longlong_as_double(0x7FF0000000000000LL);          // +inf: lanes past nel
+    double ss = 0.0;                                                      // this node's share of the residual sum of squares
     if (i < nel) {
         const double r0 = fs.old_variables[i], r1 = fs.old_variables[stride + i], r2 = fs.old_variables[2 * stride + i],
                      r3 = fs.old_variables[3 * stride + i], r4 = fs.old_variables[4 * stride + i];
@@ -629,8 +635,10 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
         if (fs.old_out) store_conserved(fs.old_out, stride, i, r0, r1, r2, r3, r4);
         if (fs.residuals) {
-            fs.residuals[i] = rho - r0; fs.residuals[stride + i] = mx - r1; fs.residuals[2 * stride + i] = my - r2;
-            fs.residuals[3 * stride + i] = mz - r3; fs.residuals[4 * stride + i] = en - r4;
+            const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
+            fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
+            fs.residuals[3 * stride + i] = d3; fs.residuals[4 * stride + i] = d4;
+            if (fs.sumsq_partial) ss = (((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3) + d4 * d4;
         }
         if (fs.check) {
             const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
@@ -650,15 +658,17 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             fs.next_legacy_sf[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
         }
     }
-    if (fs.next_partial_min) {                      // uniform: every thread of the workgroup takes part
-        __shared__ double s_next[kBlock / 64];
+    if (fs.next_partial_min || fs.sumsq_partial) {  // uniform: every thread of the workgroup takes part
+        __shared__ double s_next[2][kBlock / 64];
         sf_next = wave_min(sf_next);
-        if ((threadIdx.x & 63) == 0) s_next[threadIdx.x >> 6] = sf_next;
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) { s_next[0][threadIdx.x >> 6] = sf_next; s_next[1][threadIdx.x >> 6] = ss; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            double m = s_next[0];
-            for (int wv = 1; wv < kBlock / 64; wv++) m = fmin(m, s_next[wv]);
-            fs.next_partial_min[t] = m;
+            double m = s_next[0][0], sum = s_next[1][0];
+            for (int wv = 1; wv < kBlock / 64; wv++) { m = fmin(m, s_next[0][wv]); sum += s_next[1][wv]; }
+            if (fs.next_partial_min) fs.next_partial_min[t] = m;
+            if (fs.sumsq_partial) fs.sumsq_partial[t] = sum;
         }
     }
 }
@@ -1049,7 +1059,8 @@ k_sumsq(int64_t nel, int64_t stride, const double *__restrict__ x, double *__res
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_sum_partials(int n, const double *__restrict__ partial, double *__restrict__ out)
+k_sum_partials(int n, const double *__restrict__ partial, double *__restrict__ out,
+               double *__restrict__ ring /* nullptr, or: also append the sum to the rms history */, int *__restrict__ count, int cap)
 {
     __shared__ double s[kBlock / 64];
     double acc = 0.0;
@@ -1061,6 +1072,11 @@ k_sum_partials(int n, const double *__restrict__ partial, double *__restrict__ o
         double t = 0.0;
         for (int w = 0; w < kBlock / 64; w++) t += s[w];
         out[0] = t;
+        if (ring) {
+            const int c = *count;
+            if (c < cap) ring[c] = t;
+            *count = c + 1;
+        }
     }
 }
 
@@ -1420,7 +1436,8 @@ void launch_sumsq(hipStream_t st, int64_t nel, int64_t stride, const double *x, 
 {
     hipLaunchKernelGGL(k_sumsq, dim3(n_partial), dim3(kBlock), 0, st, nel, stride, x, partial,
                        n_owned < nel ? old_of_new : nullptr, n_owned);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, n_partial, partial, out);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, n_partial, partial, out, static_cast<double *>(nullptr),
+                       static_cast<int *>(nullptr), 0);
 }
 
 void launch_halo_pack(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const double *field, double *msg)
@@ -1428,6 +1445,9 @@ void launch_halo_pack(hipStream_t st, int64_t n, int64_t stride, const int32_t *
 
 void launch_halo_unpack(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const double *msg, double *field)
 { if (n > 0) hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, msg, field); }
+
+void launch_sum_partials_append(hipStream_t st, int n, const double *partial, double *out, double *ring, int *count, int cap)
+{ hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, n, partial, out, ring, count, cap); }
 
 void launch_append_scalar(hipStream_t st, const double *src, double *ring, int *count, int cap)
 { hipLaunchKernelGGL(k_append_scalar, dim3(1), dim3(64), 0, st, src, ring, count, cap); }

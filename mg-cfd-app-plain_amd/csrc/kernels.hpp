@@ -31,6 +31,8 @@
     void launch_halo_unpack(hipStream_t, int64_t n, int64_t stride, const int32_t *idx, const double *msg,           \
                             double *field);                                                                          \
     void launch_append_scalar(hipStream_t, const double *src, double *ring, int *count, int cap);                    \
+    void launch_sum_partials_append(hipStream_t, int n, const double *partial, double *out, double *ring,            \
+                                    int *count, int cap);                                                            \
     void launch_restrict(hipStream_t, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,                \
                          const int32_t *child_ptr, const int32_t *child, const int32_t *child4, const double *fine_q, \
                          double *coarse_q,                                                                        \

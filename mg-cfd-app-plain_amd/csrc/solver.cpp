@@ -66,6 +66,9 @@ struct DeviceLevel {
     double *state[3] = {nullptr, nullptr, nullptr};
     int rot = 0;
     void apply_rot() { q = state[rot % 3]; q_alt = state[(rot + 1) % 3]; old_variables = state[(rot + 2) % 3]; }
+    double *tile_sumsq = nullptr;        // [n_tiles] per-tile sums of squares of the residuals, written by a last stage on request
+    bool want_sumsq = false;             // the next fused sweep's last stage also fills tile_sumsq (cycle driver, level 0)
+    bool have_sumsq = false;             // ... and did
     int64_t row_bytes = 0;               // bytes of the incidence rows (ids + weights): decides the automatic flux variant
     bool min_ahead = false;              // the launch that produced the CURRENT variables looked ahead: partial_min holds the
                                          // first half of compute_step_factor for them (global time step), or sf_alt holds
@@ -109,7 +112,7 @@ struct mgcfd_solver {
     int timing_stride = 8;                  // OPT_TIMING == 2: bracket the flux launches of every Nth sweep
     int64_t sweep_counter = 0;
     bool in_timed_group = false;
-    struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; bool ahead_after = false; int rot_after = 0; int sf_par_after = 0; };
+    struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; bool ahead_after = false; int rot_after = 0; int sf_par_after = 0; bool sumsq_after = false; };
     std::map<uint64_t, SweepGraph> sweep_graphs;   // captured smoothing sweeps, keyed by (level, options)
     struct CycleGraph { hipGraphExec_t exec = nullptr; std::vector<std::vector<int64_t>> iters; std::vector<bool> ahead_after; std::vector<int> rot_after, sf_par_after; };
     std::map<uint64_t, CycleGraph> cycle_graphs;   // captured whole multigrid cycles, keyed by options
@@ -253,7 +256,8 @@ struct mgcfd_solver {
     // stage also writes that state (a sweep that aliased old to variables materialises old_variables
     // in its last stage); look_ahead: the stage leaves the next sweep's partial minima in partial_min
     void op_fused_stage(int l, int j, const double *in, double *out, int apply_min, bool with_residual,
-                        const double *old = nullptr, double *old_out = nullptr, bool look_ahead = false)
+                        const double *old = nullptr, double *old_out = nullptr, bool look_ahead = false,
+                        bool sumsq = false)
     {
         DeviceLevel &lv = level(l);
         FusedStep fs;
@@ -270,6 +274,7 @@ struct mgcfd_solver {
         fs.n_partial = apply_min == 2 ? 1 : static_cast<int>((lv.info.nel + 255) / 256);
         fs.volumes = lv.volumes;
         fs.residuals = with_residual ? lv.residuals : nullptr;
+        fs.sumsq_partial = (with_residual && sumsq) ? lv.tile_sumsq : nullptr;
         fs.old_of_new = lv.dp.old_of_new;
         fs.err = err;
         fs.check = opt_check;
@@ -387,7 +392,7 @@ mgcfd_solver::~mgcfd_solver()
     for (auto &p : pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto e : free_events) (void)hipEventDestroy(e);
     for (auto &lv : L) {
-        void *ptrs[] = {lv.q_alt, lv.sf_alt, lv.dp.nbr16, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
+        void *ptrs[] = {lv.q_alt, lv.sf_alt, lv.tile_sumsq, lv.dp.nbr16, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
                         lv.cbrt_vol, lv.min_dt, lv.partial_min, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.child4, lv.dp.pro_w, lv.dp.pro_p, lv.dp.pro_tile_n, lv.dp.pro_tile_ids, lv.dp.pro_s16, lv.dp.pro_own16,
                         lv.dp.pro_parent, lv.dp.pro_wsum, lv.dp.te_chunk_ptr, lv.dp.te_count, lv.dp.te_slots, lv.dp.te_w,
@@ -491,6 +496,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.sfb[0] = lv.step_factors; lv.sfb[1] = lv.sf_alt;
         lv.min_dt = dev_alloc<double>(1);
         lv.partial_min = dev_alloc<double>(static_cast<size_t>((nel + 255) / 256));
+        lv.tile_sumsq = dev_alloc<double>(static_cast<size_t>((nel + 255) / 256));
         lv.sumsq = dev_alloc<double>(1);
         lv.n_partials = static_cast<int>(std::min<int64_t>(1024, (nel * 5 + 255) / 256));
         lv.partials = dev_alloc<double>(static_cast<size_t>(lv.n_partials));
@@ -853,7 +859,9 @@ static void smooth_once(mgcfd_solver *s, int level)
         mgcfd_solver::Timed group(s, level, MGCFD_LOOP_FLUX, true, s->opt_timing == 2 ? MGCFD_RK : 1);
         s->op_fused_stage(level, 0, start, b1, apply_pending ? 1 : 0, false, start);
         s->op_fused_stage(level, 1, b1, b2, 0, false, start);
-        s->op_fused_stage(level, 2, b2, b1, 0, true, start, nullptr, look_ahead);   // + :508
+        const bool sumsq = lv.want_sumsq && lv.n_owned == lv.info.nel;
+        s->op_fused_stage(level, 2, b2, b1, 0, true, start, nullptr, look_ahead, sumsq);   // + :508
+        lv.have_sumsq = sumsq;
         lv.rot = (lv.rot + 1) % 3;                 // variables = b1, q_alt = b2, old_variables = start
         lv.apply_rot();
         lv.min_ahead = look_ahead;
@@ -884,7 +892,7 @@ static void run_sweep(mgcfd_solver *s, int level)
         s->opt_timing = keep;
         return;
     }
-    const uint64_t key = (uint64_t(level) << 32) | (uint64_t(lv.sf_par) << 27) | (uint64_t(lv.rot) << 25) | (uint64_t(lv.min_ahead) << 24) | (uint64_t(s->opt_exact) << 16) | (uint64_t(s->opt_check) << 8) | uint64_t(s->opt_variant & 0xFF);
+    const uint64_t key = (uint64_t(level) << 32) | (uint64_t(lv.want_sumsq) << 28) | (uint64_t(lv.sf_par) << 27) | (uint64_t(lv.rot) << 25) | (uint64_t(lv.min_ahead) << 24) | (uint64_t(s->opt_exact) << 16) | (uint64_t(s->opt_check) << 8) | uint64_t(s->opt_variant & 0xFF);
     auto it = s->sweep_graphs.find(key);
     if (it == s->sweep_graphs.end()) {
         mgcfd_solver::SweepGraph g;
@@ -910,6 +918,7 @@ static void run_sweep(mgcfd_solver *s, int level)
         g.ahead_after = lv.min_ahead;
         g.rot_after = lv.rot;
         g.sf_par_after = lv.sf_par;
+        g.sumsq_after = lv.have_sumsq;
         it = s->sweep_graphs.emplace(key, g).first;
     }
     HIP_CHECK(hipGraphLaunch(it->second.exec, s->stream));
@@ -918,6 +927,7 @@ static void run_sweep(mgcfd_solver *s, int level)
     lv.apply_rot();
     lv.sf_par = it->second.sf_par_after;
     lv.apply_sf();
+    lv.have_sumsq = it->second.sumsq_after;
     for (int k = 0; k < MGCFD_NUM_LOOPS; k++) lv.iters[k] += it->second.iters[k];
 }
 
@@ -992,10 +1002,19 @@ static void cycle_once(mgcfd_solver *s, bool capturing)
     const int n = static_cast<int>(s->L.size());
     auto sweep = [&](int l) { if (capturing) smooth_once(s, l); else run_sweep(s, l); };
     for (int l = 0; l < n; l++) {
+        if (l == 0) { s->L[0].want_sumsq = true; s->L[0].have_sumsq = false; }
         sweep(l);                                                          // :383-508
         if (l == 0) {                                                      // :509-512
-            s->op_sumsq(0);
-            exact::launch_append_scalar(s->stream, s->L[0].sumsq, s->rms_ring, s->rms_count, mgcfd_solver::kRmsRing);
+            DeviceLevel &l0 = s->L[0];
+            l0.want_sumsq = false;
+            if (l0.have_sumsq) {
+                // the last stage left per-tile sums of squares: one small launch adds them up and appends
+                exact::launch_sum_partials_append(s->stream, static_cast<int>((l0.info.nel + 255) / 256), l0.tile_sumsq, l0.sumsq,
+                                                  s->rms_ring, s->rms_count, mgcfd_solver::kRmsRing);
+            } else {
+                s->op_sumsq(0);
+                exact::launch_append_scalar(s->stream, l0.sumsq, s->rms_ring, s->rms_count, mgcfd_solver::kRmsRing);
+            }
         }
         if (l + 1 < n) s->op_restrict(l);                                  // :527-559
     }

@@ -298,6 +298,58 @@ def test_fvcorr_like_97k_nodes_developed_flow(oracle):
     assert lib.ora_identify_differences(oracle.ptr(np.ascontiguousarray(got)), oracle.ptr(state[0]), L["nel"], 0) == -1
 
 
+def _oracle_solve_arrays(oracle, levels, mesh_variant, cycles):
+    """ora_solve on in-memory level dicts (the generator's arrays): returns (per-level variables, rms, iters)."""
+    lib = oracle.load()
+    n = len(levels)
+    lv = (oracle.OraLevel * n)()
+    keep = []
+    for l, L in enumerate(levels):
+        vol = np.ascontiguousarray(L["volumes"], dtype=np.float64)
+        coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+        edges = np.ascontiguousarray(L["edges"]).copy()
+        state = [np.zeros((L["nel"], 5)) for _ in range(4)] + [np.zeros(L["nel"])]
+        keep.append((vol, coords, edges, state))
+        lv[l].nel, lv[l].n_edges = L["nel"], len(edges)
+        lv[l].n_internal, lv[l].n_boundary, lv[l].n_wall = L["n_internal"], L["n_boundary"], L["n_wall"]
+        lv[l].internal_start, lv[l].boundary_start, lv[l].wall_start = 0, L["n_internal"], L["n_internal"] + L["n_boundary"]
+        lv[l].volumes, lv[l].coords, lv[l].edges = oracle.ptr(vol), oracle.ptr(coords), oracle.ptr(edges)
+        lv[l].variables, lv[l].old_variables, lv[l].residuals, lv[l].fluxes = (oracle.ptr(a) for a in state[:4])
+        lv[l].step_factors = oracle.ptr(state[4])
+        if L.get("mg_map") is not None and l + 1 < n:
+            m = np.ascontiguousarray(L["mg_map"], dtype=np.int64)
+            keep.append(m)
+            lv[l].mg_map, lv[l].mgc = oracle.ptr(m), len(m)
+    rms = np.zeros(cycles)
+    iters = (oracle.OraIters * n)() if hasattr(oracle, "OraIters") else None
+    rc = lib.ora_solve(lv, n, mesh_variant, cycles, 0, oracle.ptr(rms), iters)
+    assert rc == 0
+    return [k[3][0] for k in keep if isinstance(k, tuple)], rms
+
+
+@pytest.mark.parametrize("sizes,name", [((2,), "fvcorr"), ((3,), "fvcorr"), ((5,), "m6wing"), ((6, 3), "m6wing"),
+                                        ((7, 4, 2), "m6wing"), ((9, 5), "rotor37"), ((8, 4), "la_cascade"),
+                                        ((17, 9, 5, 3), "m6wing")])
+def test_tiny_and_odd_hierarchies(oracle, sizes, name):
+    """Levels far smaller than a tile (8 nodes), node counts that are no multiple of 64, every mesh_name
+    (damping 5e-8 / 1e-7 / 2e-7 / none), up to four levels: a few cycles, eager and graph-replayed, against
+    the oracle bit for bit on every level."""
+    import mgcfd
+    from mgcfd import meshgen
+    mg = meshgen.make_multigrid(sizes, name, seed=3, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    levels = mgcfd.generated_to_levels(mg)
+    cycles = 4
+    want, want_rms = _oracle_solve_arrays(oracle, levels, mg.mesh_variant, cycles)
+    for graph in (0, 1):
+        s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+        s.set_option("graph", graph)
+        rms = s.run_cycles(cycles)
+        for l in range(len(levels)):
+            _assert_close(s.get(l, "variables"), want[l], True, f"{sizes} {name} level {l} graph={graph}")
+        assert np.allclose(rms, want_rms, rtol=1e-12, atol=0)
+        s.close()
+
+
 def test_invalid_state_is_reported(setup, oracle):
     mgcfd, mesh, solver, case, lib = setup
     ff = oracle.farfield()

@@ -475,7 +475,19 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     // registers; time_step (cfd_loops.cpp:241-268) is applied to it at the end and the new state
     // goes to fs.q_out (a different buffer: neighbours still read the stage's input from q).
     double min_dt = 0.0;
-    if (FUSE && fs.partial_min) min_dt = block_min_of_partials(fs.partial_min, fs.n_partial);
+    // First stage: the minimum over the step-factor partials.  Their loads are the first this kernel
+    // issues (small, L2 hits), the reduction happens after the records are staged and shares the
+    // staging barrier, so none of it adds to the prologue's latency chain.
+    constexpr int kPartPre = 6;                                           // partials per thread held in registers (1,536 tiles)
+    __shared__ double s_pm[kBlock / 64];
+    double pmv[kPartPre];
+    if (FUSE && fs.partial_min) {
+#pragma unroll
+        for (int u = 0; u < kPartPre; u++) {
+            const int k = threadIdx.x + u * kBlock;
+            pmv[u] = fs.partial_min[k < fs.n_partial ? k : fs.n_partial - 1];     // clamped: a repeat does not change a minimum
+        }
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -518,7 +530,19 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
     }
     const int32_t ovf0 = tile_ovf_ptr[t];
+    if (FUSE && fs.partial_min) {
+        double pm = pmv[0];
+#pragma unroll
+        for (int u = 1; u < kPartPre; u++) pm = fmin(pm, pmv[u]);
+        for (int k = threadIdx.x + kPartPre * kBlock; k < fs.n_partial; k += kBlock) pm = fmin(pm, fs.partial_min[k]);
+        pm = wave_min(pm);
+        if (lane == 0) s_pm[tid >> 6] = pm;
+    }
     __syncthreads();
+    if (FUSE && fs.partial_min) {
+        min_dt = s_pm[0];
+        for (int wv = 1; wv < kBlock / 64; wv++) min_dt = fmin(min_dt, s_pm[wv]);
+    }
 
     // ---- phase 2: incidence rows two at a time (independent arithmetic, ordered accumulation),
     //      ids/weights fetched two rows ahead ----

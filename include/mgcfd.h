@@ -262,6 +262,14 @@ int mgcfd_step_factor_apply(mgcfd_solver *s, int level);
  * depend on the time step, and may run while the collective is in flight; sweep_end then starts
  * with time_step on them. */
 int mgcfd_sweep_begin(mgcfd_solver *s, int level);
+/* The same split with the PARTIAL minima as the exchanged quantity: *devptr = the level's per-workgroup minima
+ * (*count fp64 values, a few KB), to be all-reduced (MIN, element-wise) in place of the scalar.  sweep_begin_partials
+ * then launches nothing when an earlier launch already left the minima behind, and sweep_end_partials lets the first
+ * stage take the minimum over the (now global) partials — one small kernel and 5 us less on the way to the collective.
+ * Same results as sweep_begin / sweep_end. */
+int mgcfd_step_factor_partials_devptr(mgcfd_solver *s, int level, void **devptr, int *count);
+int mgcfd_sweep_begin_partials(mgcfd_solver *s, int level);
+int mgcfd_sweep_end_partials(mgcfd_solver *s, int level);
 int mgcfd_sweep_flux0(mgcfd_solver *s, int level);
 int mgcfd_sweep_end(mgcfd_solver *s, int level);
 /* Halo exchange of a partitioned level.  A plan is a list of local node ids (the nodes this rank

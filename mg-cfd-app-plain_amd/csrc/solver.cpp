@@ -932,7 +932,7 @@ static void run_sweep(mgcfd_solver *s, int level)
 }
 
 // The same sweep split around the one collective a multi-GPU run needs (see mgcfd.h).
-int mgcfd_sweep_begin(mgcfd_solver *s, int level)
+static int sweep_begin_impl(mgcfd_solver *s, int level, bool scalar)
 {
     OP({
         DeviceLevel &lv = s->level(level);
@@ -948,7 +948,7 @@ int mgcfd_sweep_begin(mgcfd_solver *s, int level)
         } else {
             s->op_step_factor(level, true, false);
         }
-        if (global_dt) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
+        if (global_dt && scalar) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
     });
 }
 int mgcfd_sweep_flux0(mgcfd_solver *s, int level)
@@ -960,12 +960,12 @@ int mgcfd_sweep_flux0(mgcfd_solver *s, int level)
         lv.sweep_flux0_done = true;
     });
 }
-int mgcfd_sweep_end(mgcfd_solver *s, int level)
+static int sweep_end_impl(mgcfd_solver *s, int level, bool scalar)
 {
     OP({
         DeviceLevel &lv = s->level(level);
         const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
-        const int apply = global_dt ? 2 : 0;
+        const int apply = global_dt ? (scalar ? 2 : 1) : 0;
         const bool look_ahead = s->L.size() == 1;
         double *const start = lv.q;
         double *const b1 = lv.q_alt;
@@ -983,6 +983,16 @@ int mgcfd_sweep_end(mgcfd_solver *s, int level)
         lv.apply_rot();
         lv.min_ahead = look_ahead;
     });
+}
+
+int mgcfd_sweep_begin(mgcfd_solver *s, int level) { return sweep_begin_impl(s, level, true); }
+int mgcfd_sweep_end(mgcfd_solver *s, int level) { return sweep_end_impl(s, level, true); }
+int mgcfd_sweep_begin_partials(mgcfd_solver *s, int level) { return sweep_begin_impl(s, level, false); }
+int mgcfd_sweep_end_partials(mgcfd_solver *s, int level) { return sweep_end_impl(s, level, false); }
+int mgcfd_step_factor_partials_devptr(mgcfd_solver *s, int level, void **devptr, int *count)
+{
+    REQUIRE(devptr); REQUIRE(count);
+    OP({ DeviceLevel &lv = s->level(level); *devptr = lv.partial_min; *count = static_cast<int>((lv.info.nel + 255) / 256); });
 }
 
 int mgcfd_smooth(mgcfd_solver *s, int level, int sweeps)

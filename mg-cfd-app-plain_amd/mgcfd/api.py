@@ -100,6 +100,9 @@ _SIGNATURES = [
     ("mgcfd_bench_flux", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_step_factor_local", C.c_int, [_vp, C.c_int]),
     ("mgcfd_step_factor_min_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    ("mgcfd_step_factor_partials_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]),
+    ("mgcfd_sweep_begin_partials", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_sweep_end_partials", C.c_int, [_vp, C.c_int]),
     ("mgcfd_step_factor_apply", C.c_int, [_vp, C.c_int]),
     ("mgcfd_sweep_begin", C.c_int, [_vp, C.c_int]),
     ("mgcfd_sweep_flux0", C.c_int, [_vp, C.c_int]),
@@ -410,6 +413,14 @@ class Solver:
         p = _vp()
         self._c(self.lib.mgcfd_step_factor_min_devptr(self.handle, l, C.byref(p)))
         return p.value
+
+    def step_factor_partials_devptr(self, l):
+        p, n = _vp(), C.c_int()
+        self._c(self.lib.mgcfd_step_factor_partials_devptr(self.handle, l, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def sweep_begin_partials(self, l): self._c(self.lib.mgcfd_sweep_begin_partials(self.handle, l))
+    def sweep_end_partials(self, l): self._c(self.lib.mgcfd_sweep_end_partials(self.handle, l))
 
     def residual_sumsq_devptr(self, l) -> int:
         p = _vp()

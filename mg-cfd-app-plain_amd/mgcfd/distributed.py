@@ -59,6 +59,14 @@ class HipSolverAdapter:
             self._min[level] = DevScalarView(self.s.step_factor_min_devptr(level)).tensor(self.device)
         return self._min[level]
 
+    def partial_min_tensor(self, level):
+        """The level's per-workgroup step-factor minima (a few KB): all-reducing THEM (MIN, element-wise) instead of
+        the scalar saves the reduction kernel in front of the collective."""
+        if ("p", level) not in self._min:
+            ptr, count = self.s.step_factor_partials_devptr(level)
+            self._min[("p", level)] = DevArrayView(ptr, count).tensor(self.device)
+        return self._min[("p", level)]
+
     def sumsq_tensor(self, level):
         # launches the reduction; the returned tensor aliases its device result
         return DevScalarView(self.s.residual_sumsq_devptr(level)).tensor(self.device)
@@ -77,6 +85,7 @@ class ShardedSweep:
         self.solver = solver
         self.fused = fused and hasattr(solver, "sweep_begin")   # one launch per RK stage (mgcfd_sweep_begin/_end)
         self.overlap_even_alone = False     # tests: take the sweep_flux0 path without a process group
+        self.reduce_partials = True         # all-reduce the partial minima (see sweep)
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.global_time_step = global_time_step      # False for mesh_name = fvcorr (local time step)
 
@@ -89,17 +98,21 @@ class ShardedSweep:
         the per-level body of the reference's cycle loop, src/euler3d_cpu_double.cpp:383-508."""
         s = self.solver
         if self.fused:
-            # fused kernels: everything before the collective, the collective, everything after
-            s.sweep_begin(level)
+            # fused kernels: everything before the collective, the collective, everything after.  Where the solver
+            # offers them, the per-workgroup PARTIAL minima (a few KB) are all-reduced instead of the scalar: no
+            # reduction kernel in front of the collective, the first stage takes the minimum over the global partials.
+            partials = self.reduce_partials and hasattr(s, "partial_min_tensor")
+            (s.sweep_begin_partials if partials else s.sweep_begin)(level)
             if self.global_time_step and self.dist:
-                # The first stage's fluxes do not depend on the time step: run them while the
-                # 8-byte all-reduce (latency bound, tens of microseconds over xGMI) is in flight.
-                work = self.dist.all_reduce(s.min_tensor(level), op=self.dist.ReduceOp.MIN, async_op=True)
+                # The first stage's fluxes do not depend on the time step: run them while the all-reduce
+                # (latency bound, tens of microseconds over xGMI) is in flight.
+                t = s.partial_min_tensor(level) if partials else s.min_tensor(level)
+                work = self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, async_op=True)
                 s.sweep_flux0(level)
                 work.wait()          # stream-level wait: later kernels are ordered after the collective
             elif self.overlap_even_alone:
                 s.sweep_flux0(level)
-            s.sweep_end(level)
+            (s.sweep_end_partials if partials else s.sweep_end)(level)
             return
         s.copy_old_variables(level)
         if self.global_time_step:

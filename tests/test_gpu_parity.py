@@ -529,7 +529,8 @@ def test_sharded_sweep_hooks_equal_smooth(mesh3_dir):
     from mgcfd.distributed import HipSolverAdapter, ShardedSweep
     mesh = mgcfd.Mesh("input.dat", mesh3_dir)
     results = []
-    for mode in ("smooth", "sharded-fused", "sharded-fused-overlap", "sharded-unfused"):
+    for mode in ("smooth", "sharded-fused", "sharded-fused-overlap", "sharded-fused-scalar", "sharded-fused-scalar-overlap",
+                 "sharded-unfused"):
         s = mgcfd.Solver.from_mesh(mesh)
         q = perturbed_state(s.nel(0), s.far_field()[:5], seed=77)
         s.set(0, "variables", q)
@@ -542,6 +543,7 @@ def test_sharded_sweep_hooks_equal_smooth(mesh3_dir):
             s.set_stream(st.cuda_stream)
             sw = ShardedSweep(HipSolverAdapter(s, torch.device("cuda", 0)), None, fused=mode.startswith("sharded-fused"))
             sw.overlap_even_alone = mode.endswith("overlap")      # the path a multi-rank run takes
+            sw.reduce_partials = "scalar" not in mode             # default: the partial minima are what is all-reduced
             for _ in range(3):
                 sw.sweep(0)
             rms = sw.rms(0, s.nel(0))
@@ -772,12 +774,17 @@ def test_rccl_accepts_the_aliased_tensors(mesh3_dir):
         ref = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", mesh3_dir))
         ref.set(0, "variables", perturbed_state(s.nel(0), s.far_field()[:5], seed=3))
         ref.smooth(0, 2)
-        for _ in range(2):
-            s.sweep_begin(0)
-            work = dist.all_reduce(ad.min_tensor(0), op=dist.ReduceOp.MIN, async_op=True)
-            s.sweep_flux0(0)
-            work.wait()
-            s.sweep_end(0)
+        s.sweep_begin(0)
+        work = dist.all_reduce(ad.min_tensor(0), op=dist.ReduceOp.MIN, async_op=True)
+        s.sweep_flux0(0)
+        work.wait()
+        s.sweep_end(0)
+        s.sweep_begin_partials(0)                            # the partial minima as the exchanged quantity
+        assert ad.partial_min_tensor(0).numel() == (s.nel(0) + 255) // 256
+        work = dist.all_reduce(ad.partial_min_tensor(0), op=dist.ReduceOp.MIN, async_op=True)
+        s.sweep_flux0(0)
+        work.wait()
+        s.sweep_end_partials(0)
         t = ad.sumsq_tensor(0).clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dist.broadcast(ad.array_tensor(0, "variables"), src=0)

@@ -876,9 +876,10 @@ static void smooth_once(mgcfd_solver *s, int level)
     }
 }
 
-// A sweep with the fused stages is four kernel launches with fixed arguments: capture it once
-// per (level, options) into a hipGraph and replay it — one host call per sweep instead of four
-// launches.  Sweeps that are being timed per kernel (OPT_TIMING) run eagerly.
+// One smoothing sweep.  With MGCFD_OPT_GRAPH the three (or four) launches of a fused sweep are captured once
+// per (level, options, buffer rotation, look-ahead state) into a hipGraph and replayed — one host call per
+// sweep; by default they are launched directly, which is faster here.  Sweeps that are being
+// timed per kernel (OPT_TIMING) always run eagerly.
 static void run_sweep(mgcfd_solver *s, int level)
 {
     DeviceLevel &lv = s->level(level);

@@ -94,8 +94,35 @@ def cpu_baseline(levels, sample_seconds: float):
     for _ in range(passes):
         fn()
     dt = time.perf_counter() - t0
-    return {"value": round(n_int * passes / dt / 1e6, 3), "unit": "Medges/s", "cores": 1, "kind": kind,
-            "sample": f"{passes} passes of compute_flux_edge over the same {n_int}-edge level ({dt:.1f} s), {how}"}
+    out = {"value": round(n_int * passes / dt / 1e6, 3), "unit": "Medges/s", "cores": 1, "kind": kind,
+           "sample": f"{passes} passes of compute_flux_edge over the same {n_int}-edge level ({dt:.1f} s), {how}"}
+    # ... and on all the host cores this process may use, the reference's own race-free way to use threads: one
+    # private copy of the mesh state per thread (its -m duplication, src/Base/io_enhanced.cpp:89-201).  The oracle's
+    # restatement is used here (same arithmetic, no global counters to race on); a reported baseline like the first.
+    try:
+        import threading
+        cores = max(1, min(len(os.sched_getaffinity(0)), 16))     # a one-GPU box's CPU share is 16 cores
+        per = max(2, int(sample_seconds / 4.0 / max(one, 1e-6)))
+        state = [(q.copy(), np.zeros_like(q)) for _ in range(cores)]
+
+        def work(k):
+            qk, fk = state[k]
+            for _ in range(per):
+                lib.ora_compute_flux_edge(0, n_int, O.ptr(edges), O.ptr(qk), O.ptr(fk))
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+        t0 = time.perf_counter()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        dt_all = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(n_int * per * cores / dt_all / 1e6, 3), "unit": "Medges/s", "cores": cores, "kind": "port",
+                            "sample": f"{cores} threads x {per} passes, one private copy of the level's state per thread ({dt_all:.1f} s), "
+                                      "oracle/mgcfd_oracle.c ora_compute_flux_edge, gcc -O3 -fno-fast-math -march=native"}
+    except Exception as e:                                   # the single-core figure stands on its own
+        out["all_cores"] = {"error": str(e)}
+    return out
 
 
 def vcycle_wall(fast: bool, cycles: int = 25):

@@ -35,8 +35,6 @@ struct FusedStep {
     unsigned long long *err = nullptr;
     int check = 0;
     // last stage extras
-    double *old_out = nullptr;                // != nullptr: the sweep's start state (this launch's old_variables values) is written here
-                                              // (a sweep that aliases old_variables to the state it started from materialises the array here)
     double *sumsq_partial = nullptr;          // != nullptr (last stage): per-tile sums of squares of the residuals (calc_rms, validation.cpp:91-105)
     // look-ahead for the NEXT sweep on this level, from the state this launch produces:
     double *next_partial_min = nullptr;       // first half of compute_step_factor: per-tile minima of 0.5*cbrt(vol)/(|v|+c)

@@ -391,7 +391,6 @@ __device__ __forceinline__ void finish_node(int64_t i, int64_t nel, int64_t stri
         // q_out may be the array old_variables points at (last stage, in place): this thread has read
         // its node's old values above and nobody else reads them
         store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
-        if (fs.old_out) store_conserved(fs.old_out, stride, i, r0, r1, r2, r3, r4);
         if (fs.residuals) {
             const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
             fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
@@ -657,7 +656,6 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         // q_out may be the array old_variables points at (last stage, in place): this thread has read
         // its node's old values above and nobody else reads them
         store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
-        if (fs.old_out) store_conserved(fs.old_out, stride, i, r0, r1, r2, r3, r4);
         if (fs.residuals) {
             const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
             fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;

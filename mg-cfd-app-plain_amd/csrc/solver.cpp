@@ -252,12 +252,10 @@ struct mgcfd_solver {
     // One whole Runge-Kutta stage in one launch: fluxes of all edge classes from `in`, then
     // time_step into `out` (in != out).  fluxes[] stays logically zero, as after time_step.
     // apply_min: 0 no, 1 from the workgroups' partial minima, 2 from the (all-reduced) scalar
-    // old: where the sweep's start state is read from (default: old_variables); old_out: where the
-    // stage also writes that state (a sweep that aliased old to variables materialises old_variables
-    // in its last stage); look_ahead: the stage leaves the next sweep's partial minima in partial_min
+    // old: where the sweep's start state is read from (default: old_variables); look_ahead: the stage leaves
+    // the next sweep's step-factor work behind (partial minima in partial_min, or fvcorr's factors in sf_alt)
     void op_fused_stage(int l, int j, const double *in, double *out, int apply_min, bool with_residual,
-                        const double *old = nullptr, double *old_out = nullptr, bool look_ahead = false,
-                        bool sumsq = false)
+                        const double *old = nullptr, bool look_ahead = false, bool sumsq = false)
     {
         DeviceLevel &lv = level(l);
         FusedStep fs;
@@ -265,7 +263,6 @@ struct mgcfd_solver {
         fs.step_factors = lv.step_factors;
         fs.old_variables = old ? old : lv.old_variables;
         fs.q_out = out;
-        fs.old_out = old_out;
         fs.next_partial_min = (look_ahead && mesh_variant != MGCFD_MESH_FVCORR) ? lv.partial_min : nullptr;
         fs.next_legacy_sf = (look_ahead && mesh_variant == MGCFD_MESH_FVCORR) ? lv.sf_alt : nullptr;
         fs.cbrt_vol = lv.cbrt_vol;
@@ -860,7 +857,7 @@ static void smooth_once(mgcfd_solver *s, int level)
         s->op_fused_stage(level, 0, start, b1, apply_pending ? 1 : 0, false, start);
         s->op_fused_stage(level, 1, b1, b2, 0, false, start);
         const bool sumsq = lv.want_sumsq && lv.n_owned == lv.info.nel;
-        s->op_fused_stage(level, 2, b2, b1, 0, true, start, nullptr, look_ahead, sumsq);   // + :508
+        s->op_fused_stage(level, 2, b2, b1, 0, true, start, look_ahead, sumsq);   // + :508
         lv.have_sumsq = sumsq;
         lv.rot = (lv.rot + 1) % 3;                 // variables = b1, q_alt = b2, old_variables = start
         lv.apply_rot();
@@ -979,7 +976,7 @@ static int sweep_end_impl(mgcfd_solver *s, int level, bool scalar)
             s->op_fused_stage(level, 0, start, b1, apply, false, start);
         }
         s->op_fused_stage(level, 1, b1, b2, 0, false, start);
-        s->op_fused_stage(level, 2, b2, b1, 0, true, start, nullptr, look_ahead);
+        s->op_fused_stage(level, 2, b2, b1, 0, true, start, look_ahead);
         lv.rot = (lv.rot + 1) % 3;                 // variables = b1, q_alt = b2, old_variables = start
         lv.apply_rot();
         lv.min_ahead = look_ahead;

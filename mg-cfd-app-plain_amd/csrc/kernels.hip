@@ -457,7 +457,9 @@ __device__ __forceinline__ void boundary_rows(const NodeQ &me, const FluxC &fm, 
     }
 }
 
-template <int MINW, bool LOADK, bool FUSE, bool ACC>
+// ROLE (fused stages only): 0 = may finish compute_step_factor (first stage), 2 = may write the residual, its
+// squares and the look-ahead (last stage), 1 = neither: the paths a stage cannot take are compiled out.
+template <int MINW, bool LOADK, bool FUSE, bool ACC, int ROLE>
 __global__ void __launch_bounds__(kBlock, MINW)
 k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at wave launch (Makefile:
             // -amdgpu-kernarg-preload-count): what the first loads of the prologue need comes first
@@ -480,7 +482,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     constexpr int kPartPre = 6;                                           // partials per thread held in registers (1,536 tiles)
     __shared__ double s_pm[kBlock / 64];
     double pmv[kPartPre];
-    if (FUSE && fs.partial_min) {
+    if (FUSE && ROLE == 0 && fs.partial_min) {
 #pragma unroll
         for (int u = 0; u < kPartPre; u++) {
             const int k = threadIdx.x + u * kBlock;
@@ -529,7 +531,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
     }
     const int32_t ovf0 = tile_ovf_ptr[t];
-    if (FUSE && fs.partial_min) {
+    if (FUSE && ROLE == 0 && fs.partial_min) {
         double pm = pmv[0];
 #pragma unroll
         for (int u = 1; u < kPartPre; u++) pm = fmin(pm, pmv[u]);
@@ -538,7 +540,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         if (lane == 0) s_pm[tid >> 6] = pm;
     }
     __syncthreads();
-    if (FUSE && fs.partial_min) {
+    if (FUSE && ROLE == 0 && fs.partial_min) {
         min_dt = s_pm[0];
         for (int wv = 1; wv < kBlock / 64; wv++) min_dt = fmin(min_dt, s_pm[wv]);
     }
@@ -644,7 +646,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         const double r0 = fs.old_variables[i], r1 = fs.old_variables[stride + i], r2 = fs.old_variables[2 * stride + i],
                      r3 = fs.old_variables[3 * stride + i], r4 = fs.old_variables[4 * stride + i];
         double sf;
-        if (fs.partial_min) {                       // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
+        if (ROLE == 0 && fs.partial_min) {          // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
             sf = min_dt / fs.volumes[i];
             fs.step_factors[i] = sf;
         } else {
@@ -656,7 +658,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         // q_out may be the array old_variables points at (last stage, in place): this thread has read
         // its node's old values above and nobody else reads them
         store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
-        if (fs.residuals) {
+        if (ROLE == 2 && fs.residuals) {
             const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
             fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
             fs.residuals[3 * stride + i] = d3; fs.residuals[4 * stride + i] = d4;
@@ -671,16 +673,16 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
         }
         // look-ahead: the next sweep's compute_step_factor starts from the state just produced
-        if (fs.next_partial_min) {
+        if (ROLE == 2 && fs.next_partial_min) {
             const Derived d = derive(rho, mx, my, mz, en);
             const double dt = fs.cbrt_vol[i] / (d.speed + d.c);          // k_step_factor_local
             sf_next = 0.5 * dt;
-        } else if (fs.next_legacy_sf) {
+        } else if (ROLE == 2 && fs.next_legacy_sf) {
             const Derived d = derive(rho, mx, my, mz, en);
             fs.next_legacy_sf[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
         }
     }
-    if (fs.next_partial_min || fs.sumsq_partial) {  // uniform: every thread of the workgroup takes part
+    if (ROLE == 2 && (fs.next_partial_min || fs.sumsq_partial)) {  // uniform: every thread of the workgroup takes part
         __shared__ double s_next[2][kBlock / 64];
         sf_next = wave_min(sf_next);
         ss = wave_sum(ss);
@@ -1384,10 +1386,18 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     FusedStep fs{};
     if (fused) fs = *fused;
     // 3 tiles of 52.5 KiB LDS fit a CU => at least 3 waves per SIMD wanted
-#define MGCFD_TILE_LAUNCH(LOADK, FUSE, ACC)                                                                    \
-    hipLaunchKernelGGL((k_flux_tile<3, LOADK, FUSE, ACC>), grid, block, 0, st, q, p.tile_halo,                 \
+#define MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, ROLE)                                                            \
+    hipLaunchKernelGGL((k_flux_tile<3, LOADK, FUSE, ACC, ROLE>), grid, block, 0, st, q, p.tile_halo,           \
                        uint32_t(p.n_tiles), p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.rows_bnd,  \
                        p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs)
+    // fused stages: the role decides which optional paths exist in the launched kernel
+    const int role = !fused ? 1 : (fs.partial_min ? 0 : ((fs.residuals || fs.next_partial_min || fs.next_legacy_sf) ? 2 : 1));
+#define MGCFD_TILE_LAUNCH(LOADK, FUSE, ACC)                                                                    \
+    do {                                                                                                       \
+        if (role == 0) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 0);                                               \
+        else if (role == 2) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 2);                                          \
+        else MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 1);                                                         \
+    } while (0)
     // variant bit 2: the two-phase design point (never for the fused stages: they keep the flux in registers)
     if ((variant & 4) && !fused && p.edge_flux) {
         if (classes & 1)
@@ -1428,6 +1438,7 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
         if (loadk) MGCFD_TILE_LAUNCH(true, false, false); else MGCFD_TILE_LAUNCH(false, false, false);
     }
 #undef MGCFD_TILE_LAUNCH
+#undef MGCFD_TILE_LAUNCH_R
 }
 
 void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, double *fluxes)

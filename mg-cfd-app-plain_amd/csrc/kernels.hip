@@ -566,21 +566,8 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             n1 = lds_load_record(tile, v1 ? s1 : uint32_t(tid));
         }
         Flux5 f0, f1;
-        if (FUSE) {
-            // The fused stage also holds the time_step operands: recompute this node's 9 flux
-            // contributions per row pair (13 flops) instead of keeping 18 more registers live
-            // across the loop, which would spill at 3 waves per SIMD.
-            double vx = me.vx;
-            asm volatile("" : "+v"(vx));
-            NodeQ m2 = me;
-            m2.vx = vx;
-            const FluxC fm2 = flux_contribution(m2);
-            f0 = edge_flux<LOADK>(me, fm2, n0, e0);
-            f1 = edge_flux<LOADK>(me, fm2, n1, e1);
-        } else {
-            f0 = edge_flux<LOADK>(me, fm_pre, n0, e0);
-            f1 = edge_flux<LOADK>(me, fm_pre, n1, e1);
-        }
+        f0 = edge_flux<LOADK>(me, fm_pre, n0, e0);
+        f1 = edge_flux<LOADK>(me, fm_pre, n1, e1);
         // accumulate strictly in row order (the reference's summation order)
         if (ACC) {
             // the sum may start from -0.0 read from memory: padding must leave it untouched
@@ -601,14 +588,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         // The reference runs ALL solid-wall faces, then ALL far-field faces; the plan lists a
         // node's faces in exactly that order, so one walk over the rows keeps the per-node order.
         const int32_t first_bnd = rows_int[slice];
-        FluxC fm = fm_pre;
-        if (FUSE) {                                  // see the row loop: keep fm out of the loop's live set
-            double vx = me.vx;
-            asm volatile("" : "+v"(vx));
-            NodeQ m2 = me;
-            m2.vx = vx;
-            fm = flux_contribution(m2);
-        }
+        const FluxC fm = fm_pre;
         for (int32_t r = 0; r < n_bnd; r++) {
             const EdgeRow e = load_row<false>(nbr16, w, int64_t(row0) + first_bnd + r, lane);
             const double fx = e.fx, fy = e.fy, fz = e.fz;

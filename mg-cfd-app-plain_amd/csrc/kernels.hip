@@ -135,10 +135,33 @@ __device__ __forceinline__ FluxC flux_contribution(const NodeQ &q)
     return f;
 }
 
+// Minimum over the 64 lanes of a wave, in every lane.  Cross-lane moves by DPP inside each row of 16
+// lanes (no trip through the LDS crossbar as __shfl_xor takes, which would also queue behind the
+// record stores of the tile kernels), then the four row minima are read as scalars.
+template <int ctrl>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp(static_cast<int>(b), ctrl, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(static_cast<int>(b >> 32), ctrl, 0xF, 0xF, true);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
+}
+
+__device__ __forceinline__ double read_lane(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane(static_cast<int>(b), lane);
+    const int hi = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), lane);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
+}
+
 __device__ __forceinline__ double wave_min(double v)
 {
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
-    return v;
+    v = fmin(v, dpp_move<0xB1>(v));      // quad_perm [1,0,3,2]: lane ^ 1
+    v = fmin(v, dpp_move<0x4E>(v));      // quad_perm [2,3,0,1]: lane ^ 2  -> quads uniform
+    v = fmin(v, dpp_move<0x141>(v));     // row_half_mirror: i <-> 7-i     -> groups of 8 uniform
+    v = fmin(v, dpp_move<0x140>(v));     // row_mirror: i <-> 15-i         -> rows of 16 uniform
+    return fmin(fmin(read_lane(v, 0), read_lane(v, 16)), fmin(read_lane(v, 32), read_lane(v, 48)));
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -476,19 +499,12 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     // registers; time_step (cfd_loops.cpp:241-268) is applied to it at the end and the new state
     // goes to fs.q_out (a different buffer: neighbours still read the stage's input from q).
     double min_dt = 0.0;
-    // First stage: the minimum over the step-factor partials.  Their loads are the first this kernel
-    // issues (small, L2 hits), the reduction happens after the records are staged and shares the
-    // staging barrier, so none of it adds to the prologue's latency chain.
+    // First stage: the minimum over the step-factor partials.  Their loads go out with the prologue's (last, they
+    // are not on its dependent chain), the reduction happens after the records are staged and shares the staging
+    // barrier, so none of it adds to the prologue's latency chain.
     constexpr int kPartPre = 6;                                           // partials per thread held in registers (1,536 tiles)
     __shared__ double s_pm[kBlock / 64];
     double pmv[kPartPre];
-    if (FUSE && ROLE == 0 && fs.partial_min) {
-#pragma unroll
-        for (int u = 0; u < kPartPre; u++) {
-            const int k = threadIdx.x + u * kBlock;
-            pmv[u] = fs.partial_min[k < fs.n_partial ? k : fs.n_partial - 1];     // clamped: a repeat does not change a minimum
-        }
-    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -516,6 +532,14 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     //  load itself is never conditional, so the compiler can count the loads in flight exactly)
     EdgeRow e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
     EdgeRow e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
+    // (the step-factor partials: wanted only at the staging barrier, so requested after everything on the critical chain)
+    if (FUSE && ROLE == 0) {                         // (role 0 is launched only with fs.partial_min set)
+#pragma unroll
+        for (int u = 0; u < kPartPre; u++) {
+            const int k = threadIdx.x + u * kBlock;
+            pmv[u] = fs.partial_min[k < fs.n_partial ? k : fs.n_partial - 1];     // clamped: a repeat does not change a minimum
+        }
+    }
     const NodeQ me = make_nodeq(o0, o1, o2, o3, o4);
     lds_store_record(tile, uint32_t(tid), me);
     // Unconditional: a thread without a halo node re-reads its own node and parks the copy in its
@@ -531,7 +555,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
     }
     const int32_t ovf0 = tile_ovf_ptr[t];
-    if (FUSE && ROLE == 0 && fs.partial_min) {
+    if (FUSE && ROLE == 0) {                         // (role 0 is launched only with fs.partial_min set)
         double pm = pmv[0];
 #pragma unroll
         for (int u = 1; u < kPartPre; u++) pm = fmin(pm, pmv[u]);
@@ -540,10 +564,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         if (lane == 0) s_pm[tid >> 6] = pm;
     }
     __syncthreads();
-    if (FUSE && ROLE == 0 && fs.partial_min) {
-        min_dt = s_pm[0];
-        for (int wv = 1; wv < kBlock / 64; wv++) min_dt = fmin(min_dt, s_pm[wv]);
-    }
+    // (the four per-wave minima stay in LDS until the epilogue: nothing of them occupies a register across the row loop)
 
     // ---- phase 2: incidence rows two at a time (independent arithmetic, ordered accumulation),
     //      ids/weights fetched two rows ahead ----
@@ -626,7 +647,9 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         const double r0 = fs.old_variables[i], r1 = fs.old_variables[stride + i], r2 = fs.old_variables[2 * stride + i],
                      r3 = fs.old_variables[3 * stride + i], r4 = fs.old_variables[4 * stride + i];
         double sf;
-        if (ROLE == 0 && fs.partial_min) {          // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
+        if (ROLE == 0) {                            // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
+            min_dt = s_pm[0];
+            for (int wv = 1; wv < kBlock / 64; wv++) min_dt = fmin(min_dt, s_pm[wv]);
             sf = min_dt / fs.volumes[i];
             fs.step_factors[i] = sf;
         } else {
@@ -638,7 +661,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         // q_out may be the array old_variables points at (last stage, in place): this thread has read
         // its node's old values above and nobody else reads them
         store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
-        if (ROLE == 2 && fs.residuals) {
+        if (ROLE >= 2) {                            // last stage: residual (validation.cpp:77-89)
             const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
             fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
             fs.residuals[3 * stride + i] = d3; fs.residuals[4 * stride + i] = d4;
@@ -653,31 +676,30 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
         }
         // look-ahead: the next sweep's compute_step_factor starts from the state just produced
-        if (ROLE == 2 && fs.next_partial_min) {
+        if (ROLE == 3) {
             const Derived d = derive(rho, mx, my, mz, en);
             const double dt = fs.cbrt_vol[i] / (d.speed + d.c);          // k_step_factor_local
             sf_next = 0.5 * dt;
-        } else if (ROLE == 2 && fs.next_legacy_sf) {
+        } else if (ROLE == 4) {
             const Derived d = derive(rho, mx, my, mz, en);
             fs.next_legacy_sf[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
         }
     }
-    if (ROLE == 2 && (fs.next_partial_min || fs.sumsq_partial)) {  // uniform: every thread of the workgroup takes part
+    if (ROLE == 3 || (ROLE >= 2 && fs.sumsq_partial)) {  // uniform: every thread of the workgroup takes part
         __shared__ double s_next[2][kBlock / 64];
-        sf_next = wave_min(sf_next);
-        ss = wave_sum(ss);
+        if (ROLE == 3) sf_next = wave_min(sf_next);
+        if (fs.sumsq_partial) ss = wave_sum(ss);
         if ((threadIdx.x & 63) == 0) { s_next[0][threadIdx.x >> 6] = sf_next; s_next[1][threadIdx.x >> 6] = ss; }
         __syncthreads();
         if (threadIdx.x == 0) {
             double m = s_next[0][0], sum = s_next[1][0];
             for (int wv = 1; wv < kBlock / 64; wv++) { m = fmin(m, s_next[0][wv]); sum += s_next[1][wv]; }
-            if (fs.next_partial_min) fs.next_partial_min[t] = m;
+            if (ROLE == 3) fs.next_partial_min[t] = m;
             if (fs.sumsq_partial) fs.sumsq_partial[t] = sum;
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------
 // flux_edge_once: the same three loops with every internal edge evaluated ONCE per tile.
 //
 // k_flux_tile reads an edge's weights and evaluates its flux twice, once from each end.  Here a
@@ -1371,11 +1393,13 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
                        uint32_t(p.n_tiles), p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.rows_bnd,  \
                        p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs)
     // fused stages: the role decides which optional paths exist in the launched kernel
-    const int role = !fused ? 1 : (fs.partial_min ? 0 : ((fs.residuals || fs.next_partial_min || fs.next_legacy_sf) ? 2 : 1));
+    const int role = !fused ? 1 : (fs.partial_min ? 0 : (fs.next_partial_min ? 3 : (fs.next_legacy_sf ? 4 : (fs.residuals ? 2 : 1))));
 #define MGCFD_TILE_LAUNCH(LOADK, FUSE, ACC)                                                                    \
     do {                                                                                                       \
         if (role == 0) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 0);                                               \
         else if (role == 2) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 2);                                          \
+        else if (role == 3) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 3);                                          \
+        else if (role == 4) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 4);                                          \
         else MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 1);                                                         \
     } while (0)
     // variant bit 2: the two-phase design point (never for the fused stages: they keep the flux in registers)

@@ -350,6 +350,38 @@ def test_tiny_and_odd_hierarchies(oracle, sizes, name):
         s.close()
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_old_variables_hold_the_sweep_start_state(mesh3_dir, fvcorr_dir, fuse):
+    """The fused sweeps never copy variables to old_variables (the three state buffers change roles instead) and may
+    skip compute_step_factor's kernel because an earlier launch looked ahead: after every sweep old_variables must
+    still be the state the sweep started from, residuals = variables - old_variables, and writing variables from
+    outside must invalidate whatever was computed ahead."""
+    import mgcfd
+    for directory in (mesh3_dir, fvcorr_dir):
+        s = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", directory))
+        s.set_option("fuse_update", fuse)
+        q = perturbed_state(s.nel(0), s.far_field()[:5], seed=21)
+        s.set(0, "variables", q)
+        prev = q
+        for _ in range(4):                                  # more than one period of the buffer rotation
+            s.smooth(0, 1)
+            cur, old, res = s.get(0, "variables"), s.get(0, "old_variables"), s.get(0, "residuals")
+            assert np.array_equal(old.view(np.int64), prev.view(np.int64))
+            assert np.array_equal(res.view(np.int64), (cur - old).view(np.int64))
+            prev = cur
+        # a state written from outside: the next sweep must recompute its step factors from it
+        q2 = perturbed_state(s.nel(0), s.far_field()[:5], seed=22)
+        s.set(0, "variables", q2)
+        s.smooth(0, 1)
+        fresh = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", directory))
+        fresh.set_option("fuse_update", fuse)
+        fresh.set(0, "variables", q2)
+        fresh.smooth(0, 1)
+        assert np.array_equal(s.get(0, "variables").view(np.int64), fresh.get(0, "variables").view(np.int64))
+        assert np.array_equal(s.get(0, "step_factors").view(np.int64), fresh.get(0, "step_factors").view(np.int64))
+        s.close(); fresh.close()
+
+
 def test_invalid_state_is_reported(setup, oracle):
     mgcfd, mesh, solver, case, lib = setup
     ff = oracle.farfield()

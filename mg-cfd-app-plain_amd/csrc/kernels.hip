@@ -700,6 +700,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     }
 }
 
+// ------------------------------------------------------------------------------------------
 // flux_edge_once: the same three loops with every internal edge evaluated ONCE per tile.
 //
 // k_flux_tile reads an edge's weights and evaluates its flux twice, once from each end.  Here a

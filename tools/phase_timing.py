@@ -40,7 +40,7 @@ __device__ unsigned long long g_phase[4096 * 8];
       body = rep(body, "    double *fb = reinterpret_cast<double *>(tile);\n    __syncthreads();\n", "    double *fb = reinterpret_cast<double *>(tile);\n    PH_MARK(1);\n    __syncthreads();\n    PH_MARK(2);\n")
       body = rep(body, "    __syncthreads();\n\n    // ---- phase 4", "    __syncthreads();\n    PH_MARK(3);\n\n    // ---- phase 4")
       body = rep(body, "    if ((classes & 6) && n_bnd > 0) {\n        // boundary faces need", "    PH_MARK(4);\n    if ((classes & 6) && n_bnd > 0) {\n        // boundary faces need")
-      body = rep(body, "    finish_node<FUSE>(i, nel, stride, a0, a1, a2, a3, a4, fluxes, fs, min_dt);\n}", "    finish_node<FUSE>(i, nel, stride, a0, a1, a2, a3, a4, fluxes, fs, min_dt);\n    PH_MARK(5);\n}")
+      body = rep(body, "    finish_node<FUSE>(i, nel, stride, a0, a1, a2, a3, a4, fluxes, fs, min_dt, t);\n}", "    finish_node<FUSE>(i, nel, stride, a0, a1, a2, a3, a4, fluxes, fs, min_dt, t);\n    PH_MARK(5);\n}")
       src = src[:j] + body
     src += '''
 #ifdef MGCFD_PHASE_EXPORT
@@ -99,20 +99,19 @@ def compile_lib(src, host_dir=None):
     print("built", lib)
 
 def build_tile(src):
-    i = src.index("template <int MINW, bool LOADK, bool FUSE, bool ACC>\n__global__ void __launch_bounds__(kBlock, MINW)\nk_flux_tile")
+    i = src.index("template <int MINW, bool LOADK, bool FUSE, bool ACC, int ROLE>\n__global__ void __launch_bounds__(kBlock, MINW)\nk_flux_tile")
     src = src[:i] + HEAD + src[i:]
     j = src.index("k_flux_tile", i)
-    k = src.index("\n}\n", src.index("finish_node<FUSE>(i, nel", j) if "finish_node<FUSE>(i, nel" in src[j:] else j)
     body = src[j:]
     body = rep(body, "    double min_dt = 0.0;\n", "    PH_BEGIN();\n    double min_dt = 0.0;\n")
-    body = rep(body, "    __syncthreads();\n\n    // ---- phase 2", "    __syncthreads();\n    PH_MARK(0);\n\n    // ---- phase 2")
+    body = rep(body, "    // ---- phase 2: incidence rows two at a time", "    PH_MARK(0);\n    // ---- phase 2: incidence rows two at a time")
     body = rep(body, "    if ((classes & 6) && n_bnd > 0) {\n", "    PH_MARK(1);\n    if ((classes & 6) && n_bnd > 0) {\n")
     # only k_flux_tile's own text (up to the edge-once kernel's banner)
     end = body.index("// flux_edge_once: the same three loops")
     tile_body, rest = body[:end], body[end:]
     tile_body = rep(tile_body, "            fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;\n        }\n        return;\n    }",
                     "            fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;\n        }\n        PH_MARK(2);\n        return;\n    }")
-    k_end = tile_body.rindex("}\n\n// ---")
+    k_end = tile_body.rindex("}\n\n")                       # the closing brace of k_flux_tile
     tile_body = tile_body[:k_end] + "    PH_MARK(2);\n" + tile_body[k_end:]
     body = tile_body + rest
     src = src[:j] + body + TAIL

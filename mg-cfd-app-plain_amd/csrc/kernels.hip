@@ -568,42 +568,63 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
 
     // ---- phase 2: incidence rows two at a time (independent arithmetic, ordered accumulation),
     //      ids/weights fetched two rows ahead ----
-    for (int32_t r = 0; r < n_int; r += 2) {
-        const EdgeRow e2 = load_row<LOADK>(nbr16, w, r + 2 < n_int ? row0 + r + 2 : pad_row, lane);
-        const EdgeRow e3 = load_row<LOADK>(nbr16, w, r + 3 < n_int ? row0 + r + 3 : pad_row, lane);
-
-        const uint32_t s0 = e0.code & kT16SlotMask, s1 = e1.code & kT16SlotMask;
-        const bool v0 = s0 != kT16Pad, v1 = s1 != kT16Pad;               // ELL padding contributes nothing
-        const bool o0 = v0 && s0 >= uint32_t(kTileCap), o1 = v1 && s1 >= uint32_t(kTileCap);
-        NodeQ n0, n1;
-        if (__builtin_expect(__any(o0 || o1), 0)) {
-            // ragged cluster: some neighbour did not fit the LDS tile, read it from HBM
-            n0 = o0 ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s0) - kTileCap])
-                    : lds_load_record(tile, v0 ? s0 : uint32_t(tid));
-            n1 = o1 ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s1) - kTileCap])
-                    : lds_load_record(tile, v1 ? s1 : uint32_t(tid));
-        } else {
-            n0 = lds_load_record(tile, v0 ? s0 : uint32_t(tid));
-            n1 = lds_load_record(tile, v1 ? s1 : uint32_t(tid));
+    // The row pair's work (rows e0, e1 -> a0..a4, strictly in row order = the reference's summation order).
+    // ELL padding carries zero weights, so on a sum that started at +0.0 its +-0.0 contribution changes no
+    // bit (x + y = -0.0 only if both are); a sum read from memory (ACC) may be -0.0 and skips padding.
+    // Halo nodes beyond the LDS tile (ragged clusters) are read from HBM.
+#define MGCFD_ROW_PAIR()                                                                                     \
+    do {                                                                                                     \
+            const uint32_t s0 = e0.code & kT16SlotMask, s1 = e1.code & kT16SlotMask;                         \
+            const bool v0 = s0 != kT16Pad, v1 = s1 != kT16Pad;                                               \
+            const bool o0 = v0 && s0 >= uint32_t(kTileCap), o1 = v1 && s1 >= uint32_t(kTileCap);             \
+            NodeQ n0, n1;                                                                                    \
+            if (__builtin_expect(__any(o0 || o1), 0)) {                                                      \
+                n0 = o0 ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s0) - kTileCap])                \
+                        : lds_load_record(tile, v0 ? s0 : uint32_t(tid));                                    \
+                n1 = o1 ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s1) - kTileCap])                \
+                        : lds_load_record(tile, v1 ? s1 : uint32_t(tid));                                    \
+            } else {                                                                                         \
+                n0 = lds_load_record(tile, v0 ? s0 : uint32_t(tid));                                         \
+                n1 = lds_load_record(tile, v1 ? s1 : uint32_t(tid));                                         \
+            }                                                                                                \
+            Flux5 f0, f1;                                                                                    \
+            f0 = edge_flux<LOADK>(me, fm_pre, n0, e0);                                                       \
+            f1 = edge_flux<LOADK>(me, fm_pre, n1, e1);                                                       \
+            if (ACC) {                                                                                       \
+                a0 = v0 ? a0 + f0.d : a0;   a1 = v0 ? a1 + f0.mx : a1;   a2 = v0 ? a2 + f0.my : a2;          \
+                a3 = v0 ? a3 + f0.mz : a3;  a4 = v0 ? a4 + f0.en : a4;                                       \
+                a0 = v1 ? a0 + f1.d : a0;   a1 = v1 ? a1 + f1.mx : a1;   a2 = v1 ? a2 + f1.my : a2;          \
+                a3 = v1 ? a3 + f1.mz : a3;  a4 = v1 ? a4 + f1.en : a4;                                       \
+            } else {                                                                                         \
+                a0 += f0.d; a1 += f0.mx; a2 += f0.my; a3 += f0.mz; a4 += f0.en;                              \
+                a0 += f1.d; a1 += f1.mx; a2 += f1.my; a3 += f1.mz; a4 += f1.en;                              \
+            }                                                                                                \
+    } while (0)
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, sfv = 0.0;       // fused stages: the time_step operands
+    if (FUSE) {
+        // every pair but the last, each prefetching the pair after it
+        int32_t r = 0;
+        for (; r + 2 < n_int; r += 2) {
+            const EdgeRow e2 = load_row<LOADK>(nbr16, w, row0 + r + 2, lane);
+            const EdgeRow e3 = load_row<LOADK>(nbr16, w, r + 3 < n_int ? row0 + r + 3 : pad_row, lane);
+            MGCFD_ROW_PAIR();
+            e0 = e2; e1 = e3;
         }
-        Flux5 f0, f1;
-        f0 = edge_flux<LOADK>(me, fm_pre, n0, e0);
-        f1 = edge_flux<LOADK>(me, fm_pre, n1, e1);
-        // accumulate strictly in row order (the reference's summation order)
-        if (ACC) {
-            // the sum may start from -0.0 read from memory: padding must leave it untouched
-            a0 = v0 ? a0 + f0.d : a0;   a1 = v0 ? a1 + f0.mx : a1;   a2 = v0 ? a2 + f0.my : a2;
-            a3 = v0 ? a3 + f0.mz : a3;  a4 = v0 ? a4 + f0.en : a4;
-            a0 = v1 ? a0 + f1.d : a0;   a1 = v1 ? a1 + f1.mx : a1;   a2 = v1 ? a2 + f1.my : a2;
-            a3 = v1 ? a3 + f1.mz : a3;  a4 = v1 ? a4 + f1.en : a4;
-        } else {
-            // ELL padding carries zero weights, so its contribution is +-0.0, and a sum that started
-            // at +0.0 can never be -0.0 (x + y = -0.0 only if both are): adding it changes no bit.
-            a0 += f0.d; a1 += f0.mx; a2 += f0.my; a3 += f0.mz; a4 += f0.en;
-            a0 += f1.d; a1 += f1.mx; a2 += f1.my; a3 += f1.mz; a4 += f1.en;
+        // The last pair has nothing left to prefetch: the registers its prefetch would have used take the
+        // time_step operands instead, which arrive while the pair is being summed.
+        r0 = fs.old_variables[i]; r1 = fs.old_variables[stride + i]; r2 = fs.old_variables[2 * stride + i];
+        r3 = fs.old_variables[3 * stride + i]; r4 = fs.old_variables[4 * stride + i];
+        sfv = (ROLE == 0 ? fs.volumes : fs.step_factors)[i];
+        if (r < n_int) MGCFD_ROW_PAIR();
+    } else {
+        for (int32_t r = 0; r < n_int; r += 2) {
+            const EdgeRow e2 = load_row<LOADK>(nbr16, w, r + 2 < n_int ? row0 + r + 2 : pad_row, lane);
+            const EdgeRow e3 = load_row<LOADK>(nbr16, w, r + 3 < n_int ? row0 + r + 3 : pad_row, lane);
+            MGCFD_ROW_PAIR();
+            e0 = e2; e1 = e3;
         }
-        e0 = e2; e1 = e3;
     }
+#undef MGCFD_ROW_PAIR
 
     if ((classes & 6) && n_bnd > 0) {
         // The reference runs ALL solid-wall faces, then ALL far-field faces; the plan lists a
@@ -639,21 +660,15 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         return;
     }
     // ---- fused time_step: same operations as k_time_step on the flux just summed ----
-    // (operands fetched here, not under the row loop: the loop already sits at the register budget
-    //  of 3 waves per SIMD and hoisting these twelve registers makes it spill)
     double sf_next = __longlong_as_double(0x7FF0000000000000LL);          // +inf: lanes past nel
     double ss = 0.0;                                                      // this node's share of the residual sum of squares
     if (i < nel) {
-        const double r0 = fs.old_variables[i], r1 = fs.old_variables[stride + i], r2 = fs.old_variables[2 * stride + i],
-                     r3 = fs.old_variables[3 * stride + i], r4 = fs.old_variables[4 * stride + i];
-        double sf;
+        double sf = sfv;                            // (operands: requested before the last row pair)
         if (ROLE == 0) {                            // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
             min_dt = s_pm[0];
             for (int wv = 1; wv < kBlock / 64; wv++) min_dt = fmin(min_dt, s_pm[wv]);
-            sf = min_dt / fs.volumes[i];
+            sf = min_dt / sfv;                      // sfv holds the volume
             fs.step_factors[i] = sf;
-        } else {
-            sf = fs.step_factors[i];
         }
         const double factor = sf / fs.rk_div;
         const double rho = r0 + factor * a0, mx = r1 + factor * a1, my = r2 + factor * a2, mz = r3 + factor * a3,

@@ -601,7 +601,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             }                                                                                                \
     } while (0)
     double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, sfv = 0.0;       // fused stages: the time_step operands
-    if (FUSE) {
+    {
         // every pair but the last, each prefetching the pair after it
         int32_t r = 0;
         for (; r + 2 < n_int; r += 2) {
@@ -610,19 +610,14 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             MGCFD_ROW_PAIR();
             e0 = e2; e1 = e3;
         }
-        // The last pair has nothing left to prefetch: the registers its prefetch would have used take the
-        // time_step operands instead, which arrive while the pair is being summed.
-        r0 = fs.old_variables[i]; r1 = fs.old_variables[stride + i]; r2 = fs.old_variables[2 * stride + i];
-        r3 = fs.old_variables[3 * stride + i]; r4 = fs.old_variables[4 * stride + i];
-        sfv = (ROLE == 0 ? fs.volumes : fs.step_factors)[i];
-        if (r < n_int) MGCFD_ROW_PAIR();
-    } else {
-        for (int32_t r = 0; r < n_int; r += 2) {
-            const EdgeRow e2 = load_row<LOADK>(nbr16, w, r + 2 < n_int ? row0 + r + 2 : pad_row, lane);
-            const EdgeRow e3 = load_row<LOADK>(nbr16, w, r + 3 < n_int ? row0 + r + 3 : pad_row, lane);
-            MGCFD_ROW_PAIR();
-            e0 = e2; e1 = e3;
+        // The last pair has nothing left to prefetch: in the fused stages the registers its prefetch would
+        // have used take the time_step operands instead, which arrive while the pair is being summed.
+        if (FUSE) {
+            r0 = fs.old_variables[i]; r1 = fs.old_variables[stride + i]; r2 = fs.old_variables[2 * stride + i];
+            r3 = fs.old_variables[3 * stride + i]; r4 = fs.old_variables[4 * stride + i];
+            sfv = (ROLE == 0 ? fs.volumes : fs.step_factors)[i];
         }
+        if (r < n_int) MGCFD_ROW_PAIR();
     }
 #undef MGCFD_ROW_PAIR
 

@@ -1335,24 +1335,32 @@ k_prolong_tile(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t
         const uint16_t *sr = pro_s16 + (int64_t(row0) << 6) + lane;
         double wa0 = wr[0], wb0 = wr[64], wa1 = wr[128], wb1 = wr[192];
         uint32_t sl0 = sr[0], sl1 = sr[64];
-        for (int32_t r = 0; r < n_int; r += 2, wr += 256, sr += 128) {
+#define MGCFD_PRO_PAIR(R)                                                                                      \
+        do {                                                                                                   \
+            const bool v0 = wa0 != 0.0 || wb0 != 0.0;                                                          \
+            const bool v1 = ((R) + 1 < n_int) && (wa1 != 0.0 || wb1 != 0.0);                                   \
+            const double *xd0 = cr + (v0 ? sl0 : own_slot) * 5, *xd1 = cr + (v1 ? sl1 : own_slot) * 5;         \
+            const double x00 = xd0[0], x01 = xd0[1], x02 = xd0[2], x03 = xd0[3], x04 = xd0[4];                 \
+            const double x10 = xd1[0], x11 = xd1[1], x12 = xd1[2], x13 = xd1[3], x14 = xd1[4];                 \
+            if (v0) {                                                                                          \
+                r0 += wa0 * o0; r1 += wa0 * o1; r2 += wa0 * o2; r3 += wa0 * o3; r4 += wa0 * o4;                \
+                r0 += wb0 * x00; r1 += wb0 * x01; r2 += wb0 * x02; r3 += wb0 * x03; r4 += wb0 * x04;           \
+            }                                                                                                  \
+            if (v1) {                                                                                          \
+                r0 += wa1 * o0; r1 += wa1 * o1; r2 += wa1 * o2; r3 += wa1 * o3; r4 += wa1 * o4;                \
+                r0 += wb1 * x10; r1 += wb1 * x11; r2 += wb1 * x12; r3 += wb1 * x13; r4 += wb1 * x14;           \
+            }                                                                                                  \
+        } while (0)
+        // every pair but the last prefetches the pair after it (ELL padding carries zero weights)
+        int32_t r = 0;
+        for (; r + 2 < n_int; r += 2, wr += 256, sr += 128) {
             const double wa2 = wr[256], wb2 = wr[320], wa3 = wr[384], wb3 = wr[448];
             const uint32_t sl2 = sr[128], sl3 = sr[192];
-            const bool v0 = wa0 != 0.0 || wb0 != 0.0;                  // ELL padding carries zero weights
-            const bool v1 = (r + 1 < n_int) && (wa1 != 0.0 || wb1 != 0.0);
-            const double *xd0 = cr + (v0 ? sl0 : own_slot) * 5, *xd1 = cr + (v1 ? sl1 : own_slot) * 5;
-            const double x00 = xd0[0], x01 = xd0[1], x02 = xd0[2], x03 = xd0[3], x04 = xd0[4];
-            const double x10 = xd1[0], x11 = xd1[1], x12 = xd1[2], x13 = xd1[3], x14 = xd1[4];
-            if (v0) {
-                r0 += wa0 * o0; r1 += wa0 * o1; r2 += wa0 * o2; r3 += wa0 * o3; r4 += wa0 * o4;
-                r0 += wb0 * x00; r1 += wb0 * x01; r2 += wb0 * x02; r3 += wb0 * x03; r4 += wb0 * x04;
-            }
-            if (v1) {
-                r0 += wa1 * o0; r1 += wa1 * o1; r2 += wa1 * o2; r3 += wa1 * o3; r4 += wa1 * o4;
-                r0 += wb1 * x10; r1 += wb1 * x11; r2 += wb1 * x12; r3 += wb1 * x13; r4 += wb1 * x14;
-            }
+            MGCFD_PRO_PAIR(r);
             wa0 = wa2; wb0 = wb2; wa1 = wa3; wb1 = wb3; sl0 = sl2; sl1 = sl3;
         }
+        if (r < n_int) MGCFD_PRO_PAIR(r);
+#undef MGCFD_PRO_PAIR
     }
     double sf = __longlong_as_double(0x7FF0000000000000LL);          // +inf
     if (active) {

@@ -35,6 +35,10 @@ struct FusedStep {
     unsigned long long *err = nullptr;
     int check = 0;
     // last stage extras
+    // role 5 (a middle stage that applies the FIRST stage's time_step while it stages its input): the first stage's
+    // fluxes and its divisor RK+1-0; the input state is then old_variables + (min_dt/volume/vin_div) * vin_flux
+    const double *vin_flux = nullptr;
+    double vin_div = 4.0;
     double *sumsq_partial = nullptr;          // != nullptr (last stage): per-tile sums of squares of the residuals (calc_rms, validation.cpp:91-105)
     // look-ahead for the NEXT sweep on this level, from the state this launch produces:
     double *next_partial_min = nullptr;       // first half of compute_step_factor: per-tile minima of 0.5*cbrt(vol)/(|v|+c)
@@ -56,6 +60,7 @@ struct DevicePlan {
     int32_t *tile_halo = nullptr;        // [n_tiles][kHaloStride] ids of the staged halo nodes, -1 padded
     int32_t *tile_ovf_ptr = nullptr, *tile_ovf = nullptr;
     // edge-once tiles (preprocess.hpp: LevelPlan::te_*); edge_once == 0: not available on this level
+    int vin_ok = 0;                     // no tile has overflow nodes or more than 256 halo nodes: role-5 launches allowed
     int edge_once = 0;
     int32_t *te_chunk_ptr = nullptr, *te_count = nullptr;
     uint16_t *te_slots = nullptr, *gat16 = nullptr;

@@ -519,19 +519,62 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     // — then the own node's state, the first two rows' ids and weights, and the halo state by id.
     const int32_t *hrow = tile_halo + int64_t(t) * kHaloStride;
     const int32_t hid = hrow[tid];                                     // -1: no halo node for this thread
-    const int32_t hid2 = tid < kHaloStride - kBlock ? hrow[kBlock + tid] : -1;   // halo larger than the workgroup (rare)
-    const double o0 = q[i], o1 = q[stride + i], o2 = q[2 * stride + i], o3 = q[3 * stride + i], o4 = q[4 * stride + i];
+    const int32_t hid2 = (ROLE != 5 && tid < kHaloStride - kBlock) ? hrow[kBlock + tid] : -1;   // halo larger than the workgroup (rare)
     const int32_t row0 = slice_row0[slice];
     const int32_t n_int = (classes & 1) ? rows_int[slice] : 0;
     const int32_t n_bnd = rows_bnd[slice];
     const bool has_halo = hid >= 0;
     const int64_t hnode = has_halo ? int64_t(hid) : i;
-    const double g0 = q[hnode], g1 = q[stride + hnode], g2 = q[2 * stride + hnode], g3 = q[3 * stride + hnode],
-                 g4 = q[4 * stride + hnode];
-    // (a row the slice does not have is read from pad_row, a row of padding after the last one: the
-    //  load itself is never conditional, so the compiler can count the loads in flight exactly)
-    EdgeRow e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
-    EdgeRow e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
+    double o0, o1, o2, o3, o4, g0, g1, g2, g3, g4;
+    EdgeRow e0, e1;
+    if (FUSE && ROLE == 5) {
+        // The input state of this stage does not exist in memory: it is the first stage's time_step,
+        // old + (min_dt/volume/vin_div) * flux, applied here to every staged node (own and halo) from the
+        // first stage's fluxes — the split sweep of a multi-rank run saves its separate time_step launch.
+#pragma unroll
+        for (int u = 0; u < kPartPre; u++) {
+            const int k = threadIdx.x + u * kBlock;
+            pmv[u] = fs.partial_min[k < fs.n_partial ? k : fs.n_partial - 1];
+        }
+        const double *od = fs.old_variables, *fl = fs.vin_flux;
+        const double b0 = od[i], b1 = od[stride + i], b2 = od[2 * stride + i], b3 = od[3 * stride + i], b4 = od[4 * stride + i];
+        const double f0 = fl[i], f1 = fl[stride + i], f2 = fl[2 * stride + i], f3 = fl[3 * stride + i], f4 = fl[4 * stride + i];
+        const double vo = fs.volumes[i];
+        const double c0 = od[hnode], c1 = od[stride + hnode], c2 = od[2 * stride + hnode], c3 = od[3 * stride + hnode],
+                     c4 = od[4 * stride + hnode];
+        const double h0 = fl[hnode], h1 = fl[stride + hnode], h2 = fl[2 * stride + hnode], h3 = fl[3 * stride + hnode],
+                     h4 = fl[4 * stride + hnode];
+        const double vh = fs.volumes[hnode];
+        e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
+        e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
+        double pm = pmv[0];
+#pragma unroll
+        for (int u = 1; u < kPartPre; u++) pm = fmin(pm, pmv[u]);
+        for (int k = threadIdx.x + kPartPre * kBlock; k < fs.n_partial; k += kBlock) pm = fmin(pm, fs.partial_min[k]);
+        pm = wave_min(pm);
+        if (lane == 0) s_pm[tid >> 6] = pm;
+        __syncthreads();
+        min_dt = s_pm[0];
+        for (int wv = 1; wv < kBlock / 64; wv++) min_dt = fmin(min_dt, s_pm[wv]);
+        const double fo = (min_dt / vo) / fs.vin_div, fh = (min_dt / vh) / fs.vin_div;      // k_time_step: factor = sf / rk_div
+        o0 = b0 + fo * f0; o1 = b1 + fo * f1; o2 = b2 + fo * f2; o3 = b3 + fo * f3; o4 = b4 + fo * f4;
+        g0 = c0 + fh * h0; g1 = c1 + fh * h1; g2 = c2 + fh * h2; g3 = c3 + fh * h3; g4 = c4 + fh * h4;
+        if (fs.check && i < nel) {                                      // the first stage's check_for_invalid_variables
+            const bool finite = isfinite(o0) && isfinite(o1) && isfinite(o2) && isfinite(o3) && isfinite(o4);
+            int code = 0;
+            if (!finite) code = 1;
+            else if (o0 < 0.0) code = 2;
+            else if (o4 < 0.0) code = 3;
+            if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
+        }
+    } else {
+        o0 = q[i]; o1 = q[stride + i]; o2 = q[2 * stride + i]; o3 = q[3 * stride + i]; o4 = q[4 * stride + i];
+        g0 = q[hnode]; g1 = q[stride + hnode]; g2 = q[2 * stride + hnode]; g3 = q[3 * stride + hnode]; g4 = q[4 * stride + hnode];
+        // (a row the slice does not have is read from pad_row, a row of padding after the last one: the
+        //  load itself is never conditional, so the compiler can count the loads in flight exactly)
+        e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
+        e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
+    }
     // (the step-factor partials: wanted only at the staging barrier, so requested after everything on the critical chain)
     if (FUSE && ROLE == 0) {                         // (role 0 is launched only with fs.partial_min set)
 #pragma unroll
@@ -615,7 +658,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         if (FUSE) {
             r0 = fs.old_variables[i]; r1 = fs.old_variables[stride + i]; r2 = fs.old_variables[2 * stride + i];
             r3 = fs.old_variables[3 * stride + i]; r4 = fs.old_variables[4 * stride + i];
-            sfv = (ROLE == 0 ? fs.volumes : fs.step_factors)[i];
+            sfv = ((ROLE == 0 || ROLE == 5) ? fs.volumes : fs.step_factors)[i];
         }
         if (r < n_int) MGCFD_ROW_PAIR();
     }
@@ -659,7 +702,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     double ss = 0.0;                                                      // this node's share of the residual sum of squares
     if (i < nel) {
         double sf = sfv;                            // (operands: requested before the last row pair)
-        if (ROLE == 0) {                            // first stage: finish compute_step_factor (cfd_loops.cpp:137-156)
+        if (ROLE == 0 || ROLE == 5) {               // first stage (or the stage that absorbed it): finish compute_step_factor (cfd_loops.cpp:137-156)
             min_dt = s_pm[0];
             for (int wv = 1; wv < kBlock / 64; wv++) min_dt = fmin(min_dt, s_pm[wv]);
             sf = min_dt / sfv;                      // sfv holds the volume
@@ -671,7 +714,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         // q_out may be the array old_variables points at (last stage, in place): this thread has read
         // its node's old values above and nobody else reads them
         store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
-        if (ROLE >= 2) {                            // last stage: residual (validation.cpp:77-89)
+        if (ROLE >= 2 && ROLE <= 4) {               // last stage: residual (validation.cpp:77-89)
             const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
             fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
             fs.residuals[3 * stride + i] = d3; fs.residuals[4 * stride + i] = d4;
@@ -695,7 +738,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             fs.next_legacy_sf[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
         }
     }
-    if (ROLE == 3 || (ROLE >= 2 && fs.sumsq_partial)) {  // uniform: every thread of the workgroup takes part
+    if (ROLE == 3 || (ROLE >= 2 && ROLE <= 4 && fs.sumsq_partial)) {  // uniform: every thread of the workgroup takes part
         __shared__ double s_next[2][kBlock / 64];
         if (ROLE == 3) sf_next = wave_min(sf_next);
         if (fs.sumsq_partial) ss = wave_sum(ss);
@@ -1412,13 +1455,14 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
                        uint32_t(p.n_tiles), p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.rows_bnd,  \
                        p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs)
     // fused stages: the role decides which optional paths exist in the launched kernel
-    const int role = !fused ? 1 : (fs.partial_min ? 0 : (fs.next_partial_min ? 3 : (fs.next_legacy_sf ? 4 : (fs.residuals ? 2 : 1))));
+    const int role = !fused ? 1 : (fs.vin_flux ? 5 : fs.partial_min ? 0 : (fs.next_partial_min ? 3 : (fs.next_legacy_sf ? 4 : (fs.residuals ? 2 : 1))));
 #define MGCFD_TILE_LAUNCH(LOADK, FUSE, ACC)                                                                    \
     do {                                                                                                       \
         if (role == 0) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 0);                                               \
         else if (role == 2) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 2);                                          \
         else if (role == 3) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 3);                                          \
         else if (role == 4) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 4);                                          \
+        else if (role == 5) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 5);                                          \
         else MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 1);                                                         \
     } while (0)
     // variant bit 2: the two-phase design point (never for the fused stages: they keep the flux in registers)

@@ -255,7 +255,8 @@ struct mgcfd_solver {
     // old: where the sweep's start state is read from (default: old_variables); look_ahead: the stage leaves
     // the next sweep's step-factor work behind (partial minima in partial_min, or fvcorr's factors in sf_alt)
     void op_fused_stage(int l, int j, const double *in, double *out, int apply_min, bool with_residual,
-                        const double *old = nullptr, bool look_ahead = false, bool sumsq = false)
+                        const double *old = nullptr, bool look_ahead = false, bool sumsq = false,
+                        const double *vin_flux = nullptr)
     {
         DeviceLevel &lv = level(l);
         FusedStep fs;
@@ -272,6 +273,8 @@ struct mgcfd_solver {
         fs.volumes = lv.volumes;
         fs.residuals = with_residual ? lv.residuals : nullptr;
         fs.sumsq_partial = (with_residual && sumsq) ? lv.tile_sumsq : nullptr;
+        fs.vin_flux = vin_flux;                     // role 5: the input is the first stage's time_step of (old, vin_flux)
+        fs.vin_div = double(MGCFD_RK + 1);
         fs.old_of_new = lv.dp.old_of_new;
         fs.err = err;
         fs.check = opt_check;
@@ -543,6 +546,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.plan.fe_ab.clear(); lv.plan.fe_ab.shrink_to_fit();
         lv.plan.fe_w.clear(); lv.plan.fe_w.shrink_to_fit();
         lv.plan.row_edge.clear(); lv.plan.row_edge.shrink_to_fit();
+        lv.dp.vin_ok = (P.halo_overflow_refs == 0 && P.halo_max <= kTile) ? 1 : 0;
         lv.dp.edge_once = (P.edge_once && !std::getenv("MGCFD_NO_EDGE_ONCE")) ? 1 : 0;
         if (lv.dp.edge_once) {
             lv.dp.te_chunk_ptr = dev_upload(P.te_chunk_ptr);
@@ -968,14 +972,24 @@ static int sweep_end_impl(mgcfd_solver *s, int level, bool scalar)
         double *const start = lv.q;
         double *const b1 = lv.q_alt;
         double *const b2 = lv.old_variables;
-        if (lv.sweep_flux0_done) {
-            s->op_time_step(level, 0, apply, false, true, start, b1);   // time_step on the fluxes of sweep_flux0
+        if (lv.sweep_flux0_done && global_dt && lv.dp.vin_ok && !((s->variant_for(lv) & 2) && lv.dp.edge_once)) {
+            // the second stage applies the first stage's time_step (on the fluxes of sweep_flux0) to its own
+            // input while it stages it: no separate time_step launch, the first stage's result never touches memory
+            s->op_fused_stage(level, 1, start, b2, apply, false, start, false, false, lv.fluxes);
+            lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;      // the first stage's time_step
+            lv.fluxes_zero = true;                               // ... which leaves fluxes[] logically zero
+            lv.fluxes_stale = true;
             lv.sweep_flux0_done = false;
         } else {
-            s->settle_fluxes(lv);
-            s->op_fused_stage(level, 0, start, b1, apply, false, start);
+            if (lv.sweep_flux0_done) {
+                s->op_time_step(level, 0, apply, false, true, start, b1);   // time_step on the fluxes of sweep_flux0
+                lv.sweep_flux0_done = false;
+            } else {
+                s->settle_fluxes(lv);
+                s->op_fused_stage(level, 0, start, b1, apply, false, start);
+            }
+            s->op_fused_stage(level, 1, b1, b2, 0, false, start);
         }
-        s->op_fused_stage(level, 1, b1, b2, 0, false, start);
         s->op_fused_stage(level, 2, b2, b1, 0, true, start, look_ahead);
         lv.rot = (lv.rot + 1) % 3;                 // variables = b1, q_alt = b2, old_variables = start
         lv.apply_rot();

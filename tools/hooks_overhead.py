@@ -18,7 +18,7 @@ def timeit(fn, n=300):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e6
-print("smooth (graph)      us/step", round(timeit(lambda: s.smooth(0, 1)), 1))
+print("smooth              us/step", round(timeit(lambda: s.smooth(0, 1)), 1))
 print("split sweep (hooks) us/step", round(timeit(lambda: sw.sweep(0)), 1))
 t = s_min = HipSolverAdapter(s, torch.device("cuda", 0)).min_tensor(0)
 def with_dummy_collective():

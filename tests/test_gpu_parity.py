@@ -782,6 +782,32 @@ def test_one_level_per_solver_equals_run_cycles(mesh3_dir):
         s.close()
 
 
+def test_split_sweep_on_a_ragged_level_equals_smooth():
+    """The split sweep (mgcfd_sweep_begin / _flux0 / _end, both exchanged quantities) on a random graph whose tiles
+    overflow the LDS halo: the second stage cannot absorb the first stage's time_step there (role 5 needs every
+    staged node in LDS) and the separate time_step launch is used — same bits as mgcfd_smooth."""
+    import mgcfd
+    from mgcfd import meshgen
+    lvl = meshgen.make_random_graph_level(3000, degree=6, seed=5)
+    mg = meshgen.MultigridMesh(mesh_name="m6wing", levels=[lvl])
+    L = mgcfd.generated_to_levels(mg)[0]
+    ref = mgcfd.Solver.from_arrays([L], mg.mesh_variant)
+    q = perturbed_state(L["nel"], ref.far_field()[:5], seed=31)
+    ref.set(0, "variables", q)
+    ref.smooth(0, 3)
+    want = ref.get(0, "variables")
+    ref.close()
+    for partials in (True, False):
+        s = mgcfd.Solver.from_arrays([L], mg.mesh_variant)
+        s.set(0, "variables", q)
+        for _ in range(3):
+            (s.sweep_begin_partials if partials else s.sweep_begin)(0)
+            s.sweep_flux0(0)
+            (s.sweep_end_partials if partials else s.sweep_end)(0)
+        assert np.array_equal(s.get(0, "variables").view(np.int64), want.view(np.int64)), partials
+        s.close()
+
+
 def test_rccl_accepts_the_aliased_tensors(mesh3_dir):
     """A one-rank RCCL group (backend "nccl"): the collectives the multi-rank paths issue — all-reduce(MIN) on the
     time-step scalar (async, as ShardedSweep does around sweep_flux0), all-reduce(SUM) on the RMS scalar and a

@@ -247,7 +247,7 @@ def main():
     # cannot collect hardware counters itself); None when the workload differs from the profiled one
     traffic = {}
     try:
-        if args.lattice == LATTICE and not args.fast and args.variant == 0:
+        if args.lattice == LATTICE and not args.fast and args.variant in (-1, 0):   # -1 resolves to 0 at this size
             traffic = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
     except (OSError, ValueError):
         traffic = {}

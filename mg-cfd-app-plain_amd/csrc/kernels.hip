@@ -135,7 +135,8 @@ __device__ __forceinline__ FluxC flux_contribution(const NodeQ &q)
     return f;
 }
 
-// Minimum over the 64 lanes of a wave, in every lane.  Cross-lane moves by DPP inside each row of 16
+// Minimum over the 64 lanes of a wave, in every lane; call it with all 64 lanes active (a disabled lane would
+// be read as 0 by the DPP moves).  Cross-lane moves by DPP inside each row of 16
 // lanes (no trip through the LDS crossbar as __shfl_xor takes, which would also queue behind the
 // record stores of the tile kernels), then the four row minima are read as scalars.
 template <int ctrl>

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""The drop-in binary end to end at BASELINE size: write the 4-level M6-like hierarchy in the reference's file
+formats, run euler3d_gpu_double on it (default = per-loop timers as the reference's -DTIME build, and --no-timers),
+print its own 'Total runtime' line and the wall time of the whole process (file parsing and plan building included)."""
+import os, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd"))
+from mgcfd import meshgen
+exe = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
+d = tempfile.mkdtemp(prefix="mgcfd_scale_")
+t0 = time.time()
+mg = meshgen.make_multigrid((67, 55, 48, 43), "m6wing", seed=0, jitter=0.2, area_noise=0.02, volume_noise=0.02)
+meshgen.write_input(mg, d)
+print(f"generated + wrote the input files in {time.time() - t0:.1f} s ({sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)) / 1e6:.0f} MB)")
+for extra in ([], ["--no-timers"]):
+    t0 = time.time()
+    r = subprocess.run([exe, "-i", "input.dat", "-d", d, "-o", d + "/", "-g", "25"] + extra, capture_output=True, text=True)
+    wall = time.time() - t0
+    lines = [l for l in r.stdout.splitlines() if "Total runtime" in l or "RMS" in l]
+    print(" ".join(["euler3d_gpu_double -g 25"] + extra), "-> rc", r.returncode, f"process wall {wall:.2f} s;", lines[-1] if lines else r.stdout[-200:], "|", (lines[-2] if len(lines) > 1 else ""))
+    if r.returncode != 0:
+        print(r.stdout[-500:], r.stderr[-500:])

@@ -646,8 +646,8 @@ def test_ragged_tiles_overflow_the_lds_halo(oracle, exact):
     s.close()
 
 
-@pytest.mark.parametrize("variant", [0, 2])
-def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant):
+@pytest.mark.parametrize("variant,n_parts,partitioner", [(0, 3, "slab"), (2, 3, "slab"), (0, 4, "rcb")])
+def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts, partitioner):
     """BASELINE config 5 in miniature: one level split into 3 parts with ghost nodes, every RK stage
     followed by a halo exchange (packed / unpacked on the GPU), global-min time step over all parts.
     The three parts run as three solvers on this one GPU, threads standing in for ranks and an
@@ -657,12 +657,13 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant):
     import mgcfd
     from mgcfd import meshgen
     from mgcfd.distributed import HipSolverAdapter, PartitionedSweep
-    from mgcfd.partition import partition_level, slab_partition
+    from mgcfd.partition import partition_level, rcb_partition, slab_partition
     dev = torch.device("cuda", 0)
     mg = meshgen.make_multigrid((14,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
     L = mgcfd.generated_to_levels(mg)[0]
-    n_parts, sweeps = 3, 3
-    parts = partition_level(L, slab_partition(np.asarray(L["coords"]), n_parts))
+    sweeps = 3
+    split = slab_partition if partitioner == "slab" else rcb_partition
+    parts = partition_level(L, split(np.asarray(L["coords"]), n_parts))
     assert sum(p.n_owned for p in parts) == L["nel"] and all(p.send and p.recv for p in parts)
 
     whole = mgcfd.Solver.from_arrays([L], mg.mesh_variant)

@@ -147,3 +147,30 @@ def test_driver_cli_errors():
     assert r.returncode == 1 and "--input-file" in r.stderr
     r = subprocess.run([exe, "-i", "nope.dat"], capture_output=True, text=True)
     assert r.returncode != 0 and "Could not open input file" in r.stderr
+
+
+def test_rcb_partition_is_balanced_and_compact():
+    """Recursive coordinate bisection (the partitioner for BASELINE config 5's 8-way split): every node assigned,
+    part sizes equal to within a node, the same owned/ghost bookkeeping as any partition, and on a box its
+    2 x 2 x 2 blocks need far fewer ghost copies than 8 slabs."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd"))
+    import mgcfd
+    from mgcfd import meshgen
+    from mgcfd.partition import halo_volume, partition_level, rcb_partition, slab_partition
+    mg = meshgen.make_multigrid((16,), "m6wing", seed=2, jitter=0.2, area_noise=0.02, volume_noise=0.02)
+    L = mgcfd.generated_to_levels(mg)[0]
+    coords = np.asarray(L["coords"])
+    for n in (1, 2, 3, 5, 8):
+        part = rcb_partition(coords, n)
+        counts = np.bincount(part, minlength=n)
+        assert part.min() == 0 and part.max() == n - 1 and counts.max() - counts.min() <= 1
+    rcb, slab = rcb_partition(coords, 8), slab_partition(coords, 8)
+    assert halo_volume(L, rcb) < 0.6 * halo_volume(L, slab)
+    parts = partition_level(L, rcb)
+    assert sum(p.n_owned for p in parts) == L["nel"]
+    owned = np.concatenate([p.global_ids[:p.n_owned] for p in parts])
+    assert np.array_equal(np.sort(owned), np.arange(L["nel"]))
+    for p in parts:                                   # what a part receives from a peer is what that peer sends to it
+        for peer, ids in p.recv.items():
+            assert np.array_equal(p.global_ids[ids], parts[peer].global_ids[parts[peer].send[p.rank]])

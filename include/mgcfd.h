@@ -143,9 +143,17 @@ int mgcfd_create_from_mesh(const mgcfd_mesh *m, int device, mgcfd_solver **out);
  * its owned nodes numbered first, then ghost copies of the other ranks' nodes its edges touch, and
  * every edge with at least one owned end point (relative order as in the whole mesh, so sums keep
  * the reference's order).  n_owned[l] = number of owned nodes of level l (nodes with id >= n_owned
- * are ghosts: gathered from, never updated; excluded from the RMS).  Single level for now. */
+ * are ghosts: gathered from, never updated; excluded from the RMS). */
 int mgcfd_create_partitioned(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device,
                              const int64_t *n_owned, mgcfd_solver **out);
+/* The same for a partitioned HIERARCHY (every level split over the ranks, mg_map in local numbering: the parent of
+ * every local fine node must be a local coarse node).  order_keys[l] (may be NULL) gives, per node of level l, the key by
+ * which a coarse node's children are summed in mgcfd_restrict — global ids, so the mean keeps the whole mesh's order.
+ * The caller exchanges ghost values where the hierarchy needs them: `variables` after every time_step, after
+ * mgcfd_restrict (coarse level) and after mgcfd_prolong (fine level); coarse `residuals` before mgcfd_prolong
+ * (mgcfd/partition.py: partition_hierarchy, mgcfd/distributed.py: PartitionedCycle). */
+int mgcfd_create_partitioned_mg(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device,
+                                const int64_t *n_owned, const int64_t *const *order_keys, mgcfd_solver **out);
 void mgcfd_destroy(mgcfd_solver *s);
 int mgcfd_set_option(mgcfd_solver *s, int option, int value);
 /* *yes = 1 when level `level` can run the edge-once flux variant (MGCFD_OPT_FLUX_VARIANT bit 1). */

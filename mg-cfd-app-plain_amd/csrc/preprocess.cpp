@@ -452,7 +452,8 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
 
 void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge> &fine_edges,
                          const double *coarse_coords, int64_t nel_coarse,
-                         const std::vector<int32_t> &coarse_new_of_old, LevelPlan &P)
+                         const std::vector<int32_t> &coarse_new_of_old, LevelPlan &P,
+                         const int64_t *child_order_key, int64_t n_owned_fine)
 {
     if (!F.mg_map) throw std::runtime_error("level has no multigrid map");
     const int64_t nel = F.nel, mgc = F.mgc;
@@ -467,11 +468,17 @@ void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge
     P.child.assign(static_cast<size_t>(mgc), 0);
     {
         std::vector<int32_t> fill(P.child_ptr.begin(), P.child_ptr.end() - 1);
-        for (int64_t i = 0; i < mgc; i++) {
+        std::vector<int64_t> order(static_cast<size_t>(mgc));
+        std::iota(order.begin(), order.end(), int64_t(0));
+        if (child_order_key)
+            std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return child_order_key[x] < child_order_key[y]; });
+        for (int64_t k = 0; k < mgc; k++) {
+            const int64_t i = order[static_cast<size_t>(k)];
             const int32_t c = coarse_new_of_old[static_cast<size_t>(F.mg_map[i])];
             P.child[static_cast<size_t>(fill[static_cast<size_t>(c)]++)] = P.new_of_old[static_cast<size_t>(i)];
         }
     }
+    const int64_t n_owned = (n_owned_fine < 0 || n_owned_fine > nel) ? nel : n_owned_fine;
 
     // ---- prolongation weights (mg_loops.cpp:730-812), static because geometry is ----
     if (mgc < nel) throw std::runtime_error("prolongation needs a parent for every fine node (mgc < nel)");
@@ -501,8 +508,8 @@ void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge
         const double *ca2 = F.coords + 3 * a2, *cb2 = F.coords + 3 * b2;
         const int32_t a1n = coarse_new_of_old[static_cast<size_t>(a1)], b1n = coarse_new_of_old[static_cast<size_t>(b1)];
         const int32_t an = P.new_of_old[static_cast<size_t>(a2)], bn = P.new_of_old[static_cast<size_t>(b2)];
-        // a2's entry: own parent a1, then b1
-        {
+        // a2's entry: own parent a1, then b1 (ghosts of a partitioned level hold no rows)
+        if (a2 < n_owned) {
             ProlongW w{0.0, 0.0, a1n, b1n};
             if (!is_coincident[static_cast<size_t>(a2)]) {
                 w.w_own = inv_distance(ca2, ca1);      // :754
@@ -513,7 +520,7 @@ void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge
             P.pro[static_cast<size_t>(entry_index(an, fill[static_cast<size_t>(an)]++))] = w;
         }
         // b2's entry: own parent b1, then "a1" — which the reference reads from b1 (:805-809)
-        {
+        if (b2 < n_owned) {
             ProlongW w{0.0, 0.0, b1n, b1n};
             if (!is_coincident[static_cast<size_t>(b2)]) {
                 w.w_own = inv_distance(cb2, cb1);      // :792

@@ -125,9 +125,14 @@ struct PlanOptions {
 // on the last level.
 void build_level_plan(const mgcfd_level_desc &lvl, const std::vector<mgcfd_edge> &edges,
                       const PlanOptions &opt, LevelPlan &plan);
+// child_order_key (may be null): per fine node, the key by which a coarse node's children are summed (ascending);
+// null = the node's own index, the reference's order.  A partitioned level passes global ids, so the mean over the
+// children keeps the whole mesh's summation order whatever the local numbering.  n_owned_fine < nel: fine nodes with
+// index >= n_owned_fine are ghosts (no incidence rows, hence no prolongation entries).
 void build_transfer_plan(const mgcfd_level_desc &fine, const std::vector<mgcfd_edge> &fine_edges,
                          const double *coarse_coords, int64_t nel_coarse,
-                         const std::vector<int32_t> &coarse_new_of_old, LevelPlan &fine_plan);
+                         const std::vector<int32_t> &coarse_new_of_old, LevelPlan &fine_plan,
+                         const int64_t *child_order_key = nullptr, int64_t n_owned_fine = -1);
 
 // Edge-weight preconditioning exactly as the reference does before its loop
 // (src/Kernels/validation.cpp:28-75, src/euler3d_cpu_double.cpp:337-352).

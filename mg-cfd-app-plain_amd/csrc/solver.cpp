@@ -344,7 +344,8 @@ struct mgcfd_solver {
         // so restriction is booked to the COARSE level.
         // the coarse sweep that follows starts with compute_step_factor on the restricted state: the
         // kernel leaves its first half (per-workgroup minima) in partial_min (global time step only)
-        const bool ahead = mesh_variant != MGCFD_MESH_FVCORR;
+        // (not on a partitioned level: its ghosts are stale until the halo exchange that follows)
+        const bool ahead = mesh_variant != MGCFD_MESH_FVCORR && C.n_owned == C.info.nel;
         double *pm = ahead ? C.partial_min : nullptr;
         Timed t(this, fine + 1, MGCFD_LOOP_RESTRICT);
         if (opt_exact) exact::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.dp.child4, F.q, C.q, C.cbrt_vol, pm);
@@ -357,7 +358,7 @@ struct mgcfd_solver {
         DeviceLevel &F = level(fine);
         DeviceLevel &C = level(fine + 1);
         if (!F.has_transfer) throw std::invalid_argument("level has no multigrid map");
-        const bool ahead = mesh_variant != MGCFD_MESH_FVCORR;      // as in op_restrict, for the fine sweep that follows
+        const bool ahead = mesh_variant != MGCFD_MESH_FVCORR && F.n_owned == F.info.nel;   // as in op_restrict
         double *pm = ahead ? F.partial_min : nullptr;
         Timed t(this, fine, MGCFD_LOOP_PROLONG);
         if (opt_exact) exact::launch_prolong(stream, F.dp, C.dp.stride, C.residuals, F.residuals, F.q, F.cbrt_vol, pm);
@@ -408,7 +409,7 @@ mgcfd_solver::~mgcfd_solver()
 // construction
 // ------------------------------------------------------------------------------------------
 static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device,
-                                                  const int64_t *n_owned = nullptr)
+                                                  const int64_t *n_owned = nullptr, const int64_t *const *order_keys = nullptr)
 {
     if (!levels || nlevels <= 0) throw std::invalid_argument("no levels given");
     if (mesh_variant != MGCFD_MESH_FVCORR && mesh_variant != MGCFD_MESH_M6_WING &&
@@ -450,7 +451,6 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.n_owned = d.nel;
         popt.n_owned = -1;
         if (n_owned && n_owned[l] >= 0 && n_owned[l] < d.nel) {
-            if (nlevels > 1) throw std::invalid_argument("partitioned (ghosted) levels are single-level for now: no multigrid transfer across partitions");
             lv.n_owned = n_owned[l];
             popt.n_owned = n_owned[l];
         }
@@ -465,7 +465,8 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         const mgcfd_level_desc &d = levels[l];
         if (!d.mg_map) throw std::invalid_argument("multigrid map missing between levels");
         build_transfer_plan(d, s->L[static_cast<size_t>(l)].edges, levels[l + 1].coords, levels[l + 1].nel,
-                            s->L[static_cast<size_t>(l) + 1].plan.new_of_old, s->L[static_cast<size_t>(l)].plan);
+                            s->L[static_cast<size_t>(l) + 1].plan.new_of_old, s->L[static_cast<size_t>(l)].plan,
+                            order_keys ? order_keys[l] : nullptr, s->L[static_cast<size_t>(l)].n_owned);
         s->L[static_cast<size_t>(l)].has_transfer = true;
     }
     // device upload
@@ -698,6 +699,12 @@ int mgcfd_create_partitioned(const mgcfd_level_desc *levels, int nlevels, int me
 {
     REQUIRE(out); REQUIRE(n_owned);
     return guarded([&] { *out = build_solver(levels, nlevels, mesh_variant, device, n_owned).release(); });
+}
+int mgcfd_create_partitioned_mg(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device,
+                                const int64_t *n_owned, const int64_t *const *order_keys, mgcfd_solver **out)
+{
+    REQUIRE(out); REQUIRE(n_owned);
+    return guarded([&] { *out = build_solver(levels, nlevels, mesh_variant, device, n_owned, order_keys).release(); });
 }
 int mgcfd_create_from_mesh(const mgcfd_mesh *m, int device, mgcfd_solver **out)
 {

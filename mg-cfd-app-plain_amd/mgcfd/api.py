@@ -57,6 +57,8 @@ _SIGNATURES = [
     ("mgcfd_write_array", C.c_int, [C.c_char_p, _vp, _i64, C.c_int]),
     ("mgcfd_identify_differences", C.c_int, [_vp, _vp, _i64, C.c_int, C.POINTER(_i64)]),
     ("mgcfd_create", C.c_int, [C.POINTER(LevelDesc), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("mgcfd_create_partitioned_mg", C.c_int, [C.POINTER(LevelDesc), C.c_int, C.c_int, C.c_int, C.POINTER(_i64),
+                                                 C.POINTER(C.POINTER(_i64)), C.POINTER(_vp)]),
     ("mgcfd_create_from_mesh", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_create_partitioned", C.c_int, [C.POINTER(LevelDesc), C.c_int, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_vp)]),
     ("mgcfd_halo_plan", C.c_int, [_vp, C.c_int, _i64, _vp, C.POINTER(C.c_int)]),
@@ -211,9 +213,10 @@ class Solver:
         return cls(h, lib)
 
     @classmethod
-    def from_arrays(cls, levels: Sequence[dict], mesh_variant: int, device: int = 0, n_owned=None) -> "Solver":
+    def from_arrays(cls, levels: Sequence[dict], mesh_variant: int, device: int = 0, n_owned=None, order_keys=None) -> "Solver":
         """levels[l] = dict(nel, volumes, coords|None, edges[EDGE_DTYPE], n_internal, n_boundary, n_wall,
-        mg_map|None) — the reference's read_grid()/read_mg_connectivity() outputs."""
+        mg_map|None) — the reference's read_grid()/read_mg_connectivity() outputs.  n_owned / order_keys: a partitioned
+        level or hierarchy (mgcfd_create_partitioned / _mg)."""
         lib = load_library()
         descs = (LevelDesc * len(levels))()
         keep = []
@@ -238,9 +241,15 @@ class Solver:
         h = _vp()
         if n_owned is None:
             _check(lib, lib.mgcfd_create(descs, len(levels), mesh_variant, device, C.byref(h)))
-        else:
+        elif order_keys is None:
             owned = (_i64 * len(levels))(*[int(v) for v in n_owned])
             _check(lib, lib.mgcfd_create_partitioned(descs, len(levels), mesh_variant, device, owned, C.byref(h)))
+        else:
+            owned = (_i64 * len(levels))(*[int(v) for v in n_owned])
+            keys = [None if k is None else np.ascontiguousarray(k, dtype=np.int64) for k in order_keys]
+            keep += keys
+            kp = (C.POINTER(_i64) * len(levels))(*[C.cast(_ptr(k), C.POINTER(_i64)) if k is not None else C.POINTER(_i64)() for k in keys])
+            _check(lib, lib.mgcfd_create_partitioned_mg(descs, len(levels), mesh_variant, device, owned, kp, C.byref(h)))
         return cls(h, lib)
 
     @classmethod

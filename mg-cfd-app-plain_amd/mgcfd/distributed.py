@@ -246,3 +246,73 @@ class LevelPerRankCycle:
                 s.prolong(l)
                 if l > 0:
                     s.smooth(l, 1)
+
+
+class PartitionedCycle:
+    """Multigrid V-cycles on a hierarchy partitioned over ranks (mgcfd.partition.partition_hierarchy): every level is
+    split, each rank sweeps its owned nodes, and ghost values move wherever the next operation reads them —
+    `variables` after every time_step, after mgcfd_restrict (the coarse level's ghosts) and after mgcfd_prolong (the
+    fine level's), coarse `residuals` before mgcfd_prolong — as packed point-to-point messages (mgcfd_halo_pack /
+    _unpack around torch.distributed.batch_isend_irecv, or the injected `exchange`).  One all-reduce(MIN) of the time
+    step per sweep as in PartitionedSweep."""
+
+    def __init__(self, solver, hpart, dist=None, make_buffer=None, exchange=None, allreduce_min=None):
+        self.s, self.h = solver, hpart
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.exchange_fn = exchange
+        self.allreduce_min_fn = allreduce_min
+        self.n = len(hpart.levels)
+        self.plan_send, self.plan_recv, self.buf_send, self.buf_recv = [], [], [], []
+        for l, P in enumerate(hpart.levels):
+            self.plan_send.append({p: solver.halo_plan(l, P.send[p]) for p in P.send})
+            self.plan_recv.append({p: solver.halo_plan(l, P.recv[p]) for p in P.recv})
+            self.buf_send.append({p: make_buffer(len(P.send[p]) * 5) for p in P.send})
+            self.buf_recv.append({p: make_buffer(len(P.recv[p]) * 5) for p in P.recv})
+
+    def exchange(self, level, name):
+        s = self.s
+        for p, plan in self.plan_send[level].items():
+            s.halo_pack(level, plan, name, self.buf_send[level][p].data_ptr())
+        if self.exchange_fn:
+            self.exchange_fn(self, level)
+        elif self.dist:
+            d, ops = self.dist, []
+            for p in sorted(set(self.buf_send[level]) | set(self.buf_recv[level])):
+                if p in self.buf_send[level]:
+                    ops.append(d.P2POp(d.isend, self.buf_send[level][p], p))
+                if p in self.buf_recv[level]:
+                    ops.append(d.P2POp(d.irecv, self.buf_recv[level][p], p))
+            for req in d.batch_isend_irecv(ops):
+                req.wait()
+        for p, plan in self.plan_recv[level].items():
+            s.halo_unpack(level, plan, name, self.buf_recv[level][p].data_ptr())
+
+    def sweep(self, level):
+        s = self.s
+        s.copy_old_variables(level)
+        s.step_factor_local(level)
+        if self.allreduce_min_fn:
+            self.allreduce_min_fn(self, level)
+        elif self.dist:
+            self.dist.all_reduce(s.min_tensor(level), op=self.dist.ReduceOp.MIN)
+        s.step_factor_apply(level)
+        for j in range(RK):
+            s.compute_fluxes(level)
+            s.time_step(level, j)
+            self.exchange(level, "variables")
+        s.residual(level)
+
+    def cycle(self):
+        """Sweeps on levels 0..n-1, n-2..1 with the transfers between them (src/euler3d_cpu_double.cpp:371-694)."""
+        s, n = self.s, self.n
+        for l in range(n):
+            self.sweep(l)
+            if l + 1 < n:
+                s.restrict(l)
+                self.exchange(l + 1, "variables")
+        for l in range(n - 2, -1, -1):
+            self.exchange(l + 1, "residuals")
+            s.prolong(l)
+            self.exchange(l, "variables")
+            if l > 0:
+                self.sweep(l)

@@ -733,6 +733,83 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts
     assert abs(np.sqrt(sumsq / L["nel"]) - want_rms) <= 1e-12 * want_rms
 
 
+@pytest.mark.parametrize("sizes,n_parts", [((12, 6, 3), 3), ((14, 7), 4)])
+def test_partitioned_hierarchy_vcycles_equal_whole_mesh(sizes, n_parts):
+    """Every level of a hierarchy split over "ranks" (threads, one solver each, in-process copies for send/recv):
+    flux ghosts, the children a rank's coarse nodes need for mgcfd_restrict and the parents mgcfd_prolong reads are
+    ghosts that the cycle keeps current by halo exchanges; children are averaged in global-id order.  Three V-cycles
+    must equal mgcfd_run_cycles on the whole mesh bit for bit on the owned nodes of every level."""
+    import threading
+    import torch
+    import mgcfd
+    from mgcfd import meshgen
+    from mgcfd.distributed import HipSolverAdapter, PartitionedCycle
+    from mgcfd.partition import partition_hierarchy, rcb_partition
+    dev = torch.device("cuda", 0)
+    cycles = 3
+    mg = meshgen.make_multigrid(sizes, "m6wing", seed=4, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    levels = mgcfd.generated_to_levels(mg)
+    whole = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    whole.run_cycles(cycles)
+    want = [whole.get(l, "variables") for l in range(len(levels))]
+    want_res0 = whole.get(0, "residuals")
+    whole.close()
+
+    H = partition_hierarchy(levels, rcb_partition(np.asarray(levels[0]["coords"]), n_parts))
+    assert all(sum(h.levels[l].n_owned for h in H) == levels[l]["nel"] for l in range(len(levels)))
+    tstream = torch.cuda.Stream()
+    solvers, cyclers = [], []
+    barrier = threading.Barrier(n_parts)
+
+    def exchange(cy, level):
+        barrier.wait()
+        for peer, buf in cy.buf_recv[level].items():
+            buf.copy_(cyclers[peer].buf_send[level][cy.h.rank])
+        barrier.wait()
+
+    def allreduce_min(cy, level):
+        barrier.wait()
+        if cy.h.rank == 0:
+            m = torch.stack([c.s.min_tensor(level) for c in cyclers]).min()
+            for c in cyclers:
+                c.s.min_tensor(level).fill_(m)
+        barrier.wait()
+
+    for h in H:
+        lv, owned, keys = h.solver_args()
+        s = mgcfd.Solver.from_arrays(lv, mg.mesh_variant, n_owned=owned, order_keys=keys)
+        s.set_stream(tstream.cuda_stream)
+        solvers.append(s)
+        cyclers.append(PartitionedCycle(HipSolverAdapter(s, dev), h, None, exchange=exchange, allreduce_min=allreduce_min,
+                                        make_buffer=lambda n: torch.empty(max(n, 1), dtype=torch.float64, device=dev)))
+    errors = []
+
+    def run(cy):
+        try:
+            torch.cuda.set_device(0)
+            torch.cuda.set_stream(tstream)
+            for _ in range(cycles):
+                cy.cycle()
+        except Exception as e:                               # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(c,)) for c in cyclers]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for h, s in zip(H, solvers):
+        for l, P in enumerate(h.levels):
+            own = P.global_ids[:P.n_owned]
+            got = s.get(l, "variables")[:P.n_owned]
+            assert np.array_equal(got.view(np.int64), want[l][own].view(np.int64)), f"rank {h.rank} level {l}"
+        own0 = h.levels[0].global_ids[:h.levels[0].n_owned]
+        assert np.array_equal(s.get(0, "residuals")[:len(own0)].view(np.int64), want_res0[own0].view(np.int64))
+        s.close()
+
+
 def test_one_level_per_solver_equals_run_cycles(mesh3_dir):
     """BASELINE config 4 in miniature: the three levels of the case split over two solvers (two "ranks": levels 0
     and 2 on one, level 1 on the other), the restricted variables and the coarse residuals handed over as whole

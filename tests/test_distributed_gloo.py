@@ -156,6 +156,16 @@ def test_two_ranks_equal_the_duplicated_mesh(tmp_path, oracle):
 # ------------------------------------------------------------------------------------------
 # Partitioned level + halo exchange over gloo point-to-point (BASELINE config 5 in miniature)
 # ------------------------------------------------------------------------------------------
+def _libm_cbrt(x):
+    """cbrt through the C library the oracle itself calls (numpy's may differ in the last bit)."""
+    import ctypes
+    import ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    libm.cbrt.restype = ctypes.c_double
+    libm.cbrt.argtypes = [ctypes.c_double]
+    return np.array([libm.cbrt(float(v)) for v in np.asarray(x).ravel()]).reshape(np.shape(x))
+
+
 class OraclePartSolver:
     """CPU stand-in (oracle-backed) for a partitioned mgcfd.api.Solver: one level, ghosts last."""
 
@@ -185,7 +195,9 @@ class OraclePartSolver:
         vel = q[:, 1:4] / q[:, :1]
         sp2 = (vel[:, 0] * vel[:, 0] + vel[:, 1] * vel[:, 1]) + vel[:, 2] * vel[:, 2]
         p = (1.4 - 1.0) * (q[:, 4] - 0.5 * q[:, 0] * sp2)
-        self._min[0] = float((0.5 * (np.cbrt(self.vol) / (np.sqrt(sp2) + np.sqrt(1.4 * p / q[:, 0])))).min())
+        if not hasattr(self, "_cbrt_vol"):
+            self._cbrt_vol = _libm_cbrt(self.vol)
+        self._min[0] = float((0.5 * (self._cbrt_vol / (np.sqrt(sp2) + np.sqrt(1.4 * p / q[:, 0])))).min())
 
     def min_tensor(self, l):
         return self._min
@@ -370,3 +382,134 @@ def test_one_level_per_rank_equals_the_reference_binary(tmp_path, oracle):
     # the receiving side told its solver about every array it received
     assert set(np.load(tmp_path / "written_1.npy")) == {"1:variables", "2:residuals"}
     assert set(np.load(tmp_path / "written_0.npy")) == {"2:variables", "1:residuals"}
+
+
+# ------------------------------------------------------------------------------------------
+# A whole hierarchy partitioned over two ranks: multigrid transfers across the partition
+# ------------------------------------------------------------------------------------------
+class OracleHierarchyPartSolver:
+    """Oracle-backed stand-in for a solver created by mgcfd_create_partitioned_mg: per level the single-level
+    stand-in above, plus restrict (children averaged in GLOBAL-id order, as order_keys asks) and prolong."""
+
+    def __init__(self, oracle, hpart, ff_var):
+        self.O = oracle
+        self.lib = oracle.load()
+        self.h = hpart
+        self.lv = []
+        for P in hpart.levels:
+            q = np.tile(np.array(ff_var), (P.level["nel"], 1))
+            self.lv.append(OraclePartSolver(oracle, P.level, q))
+
+    # ---- per-level loops: delegate ----
+    def copy_old_variables(self, l): self.lv[l].copy_old_variables(0)
+    def step_factor_local(self, l): self.lv[l].step_factor_local(0)
+    def min_tensor(self, l): return self.lv[l].min_tensor(0)
+    def step_factor_apply(self, l): self.lv[l].step_factor_apply(0)
+    def compute_fluxes(self, l): self.lv[l].compute_fluxes(0)
+    def time_step(self, l, j): self.lv[l].time_step(0, j)
+    def residual(self, l): self.lv[l].residual(0)
+
+    def halo_plan(self, l, ids): return self.lv[l].halo_plan(0, ids)
+
+    def _field(self, l, name): return self.lv[l].v if name == "variables" else self.lv[l].res
+
+    def halo_pack(self, l, plan, name, ptr):
+        ids = self.lv[l].plans[plan]
+        if len(ids):
+            OraclePartSolver._view(ptr, len(ids) * 5)[:] = self._field(l, name)[ids].ravel()
+
+    def halo_unpack(self, l, plan, name, ptr):
+        ids = self.lv[l].plans[plan]
+        if len(ids):
+            self._field(l, name)[ids] = OraclePartSolver._view(ptr, len(ids) * 5).reshape(-1, 5)
+
+    def restrict(self, fine):
+        F, Cc = self.h.levels[fine], self.h.levels[fine + 1]
+        m = F.level["mg_map"]
+        qf, qc = self.lv[fine].v, self.lv[fine + 1].v
+        order = np.argsort(F.global_ids, kind="stable")                  # children summed by global id
+        acc = np.zeros_like(qc)
+        cnt = np.zeros(len(qc), dtype=np.int64)
+        for i in order:
+            acc[m[i]] += qf[i]
+            cnt[m[i]] += 1
+        has = cnt > 0
+        qc[has] = acc[has] * (1.0 / cnt[has])[:, None]
+
+    def prolong(self, fine):
+        O, lib = self.O, self.lib
+        F, Cc = self.lv[fine], self.lv[fine + 1]
+        m = np.ascontiguousarray(self.h.levels[fine].level["mg_map"], dtype=np.int64)
+        n_owned = self.h.levels[fine].n_owned
+        keep = F.v[n_owned:].copy()
+        lib.ora_prolong_residuals_interpolate_proper(O.ptr(F.edges), F.ni, O.ptr(Cc.res), O.ptr(F.res), O.ptr(F.v),
+                                                      F.nel, O.ptr(m), O.ptr(Cc.coords), O.ptr(F.coords))
+        F.v[n_owned:] = keep                                             # ghosts: whatever, the exchange overwrites them
+
+
+def _hier_worker(rank, world, port, cycles, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    import mgcfd
+    from mgcfd import meshgen
+    from mgcfd.distributed import PartitionedCycle
+    from mgcfd.partition import partition_hierarchy, rcb_partition
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mg = meshgen.make_multigrid((8, 4), "m6wing", seed=4, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    levels = mgcfd.generated_to_levels(mg)
+    H = partition_hierarchy(levels, rcb_partition(np.asarray(levels[0]["coords"]), world))[rank]
+    solver = OracleHierarchyPartSolver(oracle_py, H, oracle_py.farfield().var)
+    cyc = PartitionedCycle(solver, H, dist, make_buffer=lambda n: torch.zeros(max(n, 1), dtype=torch.float64))
+    for _ in range(cycles):
+        cyc.cycle()
+    for l, P in enumerate(H.levels):
+        np.save(os.path.join(out_dir, f"h_vars_{rank}_{l}.npy"), solver.lv[l].v[:P.n_owned])
+        np.save(os.path.join(out_dir, f"h_ids_{rank}_{l}.npy"), P.global_ids[:P.n_owned])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_partitioned_hierarchy_over_gloo_equals_whole_mesh(tmp_path, oracle):
+    """Two levels split over two ranks, ghost values moved by real gloo point-to-point messages after every time_step,
+    restrict and prolong: after two V-cycles every level's owned nodes equal the single-process oracle run bit for bit."""
+    import mgcfd
+    from mgcfd import meshgen
+    world, cycles = 2, 2
+    mp.spawn(_hier_worker, args=(world, _free_port(), cycles, str(tmp_path)), nprocs=world, join=True)
+    mg = meshgen.make_multigrid((8, 4), "m6wing", seed=4, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    levels = mgcfd.generated_to_levels(mg)
+    # single process, the oracle's own driver on the whole hierarchy
+    lib = oracle.load()
+    n = len(levels)
+    lv = (oracle.OraLevel * n)()
+    keep = []
+    for l, L in enumerate(levels):
+        vol = np.ascontiguousarray(L["volumes"], dtype=np.float64)
+        coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+        edges = np.ascontiguousarray(L["edges"]).copy()
+        state = [np.zeros((L["nel"], 5)) for _ in range(4)] + [np.zeros(L["nel"])]
+        keep.append((vol, coords, edges, state))
+        lv[l].nel, lv[l].n_edges = L["nel"], len(edges)
+        lv[l].n_internal, lv[l].n_boundary, lv[l].n_wall = L["n_internal"], L["n_boundary"], L["n_wall"]
+        lv[l].internal_start, lv[l].boundary_start, lv[l].wall_start = 0, L["n_internal"], L["n_internal"] + L["n_boundary"]
+        lv[l].volumes, lv[l].coords, lv[l].edges = oracle.ptr(vol), oracle.ptr(coords), oracle.ptr(edges)
+        lv[l].variables, lv[l].old_variables, lv[l].residuals, lv[l].fluxes = (oracle.ptr(a) for a in state[:4])
+        lv[l].step_factors = oracle.ptr(state[4])
+        if L.get("mg_map") is not None and l + 1 < n:
+            m = np.ascontiguousarray(L["mg_map"], dtype=np.int64)
+            keep.append(m)
+            lv[l].mg_map, lv[l].mgc = oracle.ptr(m), len(m)
+    rms = np.zeros(cycles)
+    assert lib.ora_solve(lv, n, mg.mesh_variant, cycles, 0, oracle.ptr(rms), None) == 0
+    want = [k[3][0] for k in keep if isinstance(k, tuple)]
+    for l in range(n):
+        seen = 0
+        for r in range(world):
+            ids = np.load(tmp_path / f"h_ids_{r}_{l}.npy")
+            got = np.load(tmp_path / f"h_vars_{r}_{l}.npy")
+            assert np.array_equal(got.view(np.int64), want[l][ids].view(np.int64)), (l, r)
+            seen += len(ids)
+        assert seen == levels[l]["nel"]

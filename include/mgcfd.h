@@ -51,7 +51,8 @@ enum { MGCFD_LOOP_FLUX = 0, MGCFD_LOOP_UPDATE, MGCFD_LOOP_COMPUTE_STEP, MGCFD_LO
 /* Per-level arrays a caller can read back / overwrite (reference: the arrays main() owns,
  * src/euler3d_cpu_double.cpp:138-162). */
 enum { MGCFD_ARR_VARIABLES = 0, MGCFD_ARR_OLD_VARIABLES, MGCFD_ARR_FLUXES, MGCFD_ARR_RESIDUALS,
-       MGCFD_ARR_STEP_FACTORS, MGCFD_ARR_VOLUMES };
+       MGCFD_ARR_STEP_FACTORS, MGCFD_ARR_VOLUMES,
+       MGCFD_ARR_STAGE /* the state the last mgcfd_sweep_stage wrote (halo messages between the stages of a split sweep) */ };
 
 /* Solver options (mgcfd_set_option) */
 enum {
@@ -276,6 +277,12 @@ int mgcfd_sweep_begin(mgcfd_solver *s, int level);
  * stage take the minimum over the (now global) partials — one small kernel and 5 us less on the way to the collective.
  * Same results as sweep_begin / sweep_end. */
 int mgcfd_step_factor_partials_devptr(mgcfd_solver *s, int level, void **devptr, int *count);
+/* The Runge-Kutta stages of such a sweep ONE AT A TIME, for a partitioned level: after mgcfd_sweep_begin[_partials] and
+ * the all-reduce, call mgcfd_sweep_stage(s, level, j, partials) for j = 0, 1, 2 — each a single fused launch (fluxes +
+ * time_step; the first finishes compute_step_factor, the last writes the residual and ends the sweep) — and between
+ * them move the ghosts' new values with mgcfd_halo_pack / _unpack on MGCFD_ARR_STAGE (the state that stage wrote; the
+ * ghosts hold no rows, so a stage leaves them at the sweep's start state until the message arrives). */
+int mgcfd_sweep_stage(mgcfd_solver *s, int level, int j, int partials);
 int mgcfd_sweep_begin_partials(mgcfd_solver *s, int level);
 int mgcfd_sweep_end_partials(mgcfd_solver *s, int level);
 int mgcfd_sweep_flux0(mgcfd_solver *s, int level);

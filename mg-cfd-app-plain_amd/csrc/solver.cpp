@@ -85,6 +85,8 @@ struct DeviceLevel {
     bool fluxes_zero = true;             // fluxes[] is logically zero (the flux launch need not read it)
     bool fluxes_stale = false;           // ... but its memory has not been zeroed (lazy zero after a fused time_step)
     bool sweep_flux0_done = false;       // mgcfd_sweep_flux0 ran since mgcfd_sweep_begin
+    int stage_next = 0;                  // mgcfd_sweep_stage: the stage expected next (0 = a sweep may start)
+    double *stage_out = nullptr;         // ... and the buffer the last one wrote (MGCFD_ARR_STAGE)
     int64_t n_owned = 0;                 // < nel on a partitioned level: original ids >= n_owned are ghosts
     std::vector<std::pair<int32_t *, int64_t>> halo_plans;   // device id lists of the halo messages
     bool has_transfer = false;           // plan to the next-coarser level present
@@ -862,7 +864,7 @@ static void smooth_once(mgcfd_solver *s, int level)
             apply_pending = s->op_step_factor(level, true, false);
         }
         // single level: the next sweep starts from this sweep's result, let the last stage look ahead
-        const bool look_ahead = s->L.size() == 1;
+        const bool look_ahead = s->L.size() == 1 && lv.n_owned == lv.info.nel;   // (a partitioned level's ghosts are stale)
         double *const start = lv.q, *const b1 = lv.q_alt, *const b2 = lv.old_variables;
         mgcfd_solver::Timed group(s, level, MGCFD_LOOP_FLUX, true, s->opt_timing == 2 ? MGCFD_RK : 1);
         s->op_fused_stage(level, 0, start, b1, apply_pending ? 1 : 0, false, start);
@@ -975,7 +977,7 @@ static int sweep_end_impl(mgcfd_solver *s, int level, bool scalar)
         DeviceLevel &lv = s->level(level);
         const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
         const int apply = global_dt ? (scalar ? 2 : 1) : 0;
-        const bool look_ahead = s->L.size() == 1;
+        const bool look_ahead = s->L.size() == 1 && lv.n_owned == lv.info.nel;
         double *const start = lv.q;
         double *const b1 = lv.q_alt;
         double *const b2 = lv.old_variables;
@@ -1004,6 +1006,36 @@ static int sweep_end_impl(mgcfd_solver *s, int level, bool scalar)
     });
 }
 
+int mgcfd_sweep_stage(mgcfd_solver *s, int level, int j, int partials)
+{
+    OP({
+        DeviceLevel &lv = s->level(level);
+        if (j != lv.stage_next) throw std::invalid_argument("mgcfd_sweep_stage: stages must run in order 0, 1, 2 after mgcfd_sweep_begin");
+        const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
+        double *const start = lv.q;
+        double *const b1 = lv.q_alt;
+        double *const b2 = lv.old_variables;
+        if (j == 0) {
+            if (!lv.fluxes_zero) throw std::invalid_argument("mgcfd_sweep_stage needs zero fluxes (as after time_step)");
+            s->settle_fluxes(lv);
+            s->op_fused_stage(level, 0, start, b1, global_dt ? (partials ? 1 : 2) : 0, false, start);
+            lv.stage_out = b1;
+            lv.stage_next = 1;
+        } else if (j == 1) {
+            s->op_fused_stage(level, 1, b1, b2, 0, false, start);
+            lv.stage_out = b2;
+            lv.stage_next = 2;
+        } else {
+            // (no look-ahead: on a partitioned level the ghosts of the new state are stale until the exchange)
+            s->op_fused_stage(level, 2, b2, b1, 0, true, start, false);
+            lv.rot = (lv.rot + 1) % 3;             // variables = b1, q_alt = b2, old_variables = start
+            lv.apply_rot();
+            lv.stage_out = lv.q;                   // == b1
+            lv.stage_next = 0;
+            lv.min_ahead = false;
+        }
+    });
+}
 int mgcfd_sweep_begin(mgcfd_solver *s, int level) { return sweep_begin_impl(s, level, true); }
 int mgcfd_sweep_end(mgcfd_solver *s, int level) { return sweep_end_impl(s, level, true); }
 int mgcfd_sweep_begin_partials(mgcfd_solver *s, int level) { return sweep_begin_impl(s, level, false); }
@@ -1160,6 +1192,9 @@ static double *array_ptr(DeviceLevel &lv, int which, int *ncols)
         case MGCFD_ARR_RESIDUALS: return lv.residuals;
         case MGCFD_ARR_STEP_FACTORS: *ncols = 1; return lv.step_factors;
         case MGCFD_ARR_VOLUMES: *ncols = 1; return lv.volumes;
+        case MGCFD_ARR_STAGE:
+            if (!lv.stage_out) throw std::invalid_argument("MGCFD_ARR_STAGE: no mgcfd_sweep_stage has run on this level");
+            return lv.stage_out;
         default: throw std::invalid_argument("unknown array id");
     }
 }

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("MGCFD_LIB") or os.path.join(CSRC_DIR, "libmgcfd_hip.s
 NVAR = 5
 RK = 3
 LOOPS = ("flux", "update", "compute_step", "time_step", "restrict", "prolong", "indirect_rw")
-ARR = {"variables": 0, "old_variables": 1, "fluxes": 2, "residuals": 3, "step_factors": 4, "volumes": 5}
+ARR = {"variables": 0, "old_variables": 1, "fluxes": 2, "residuals": 3, "step_factors": 4, "volumes": 5, "stage": 6}
 OPT = {"exact": 0, "timing": 1, "indirect_rw": 2, "check_invalid": 3, "flux_variant": 4, "fuse_update": 5, "graph": 6}
 ERR_NAMES = {0: "OK", 1: "ERR_ARG", 2: "ERR_IO", 3: "ERR_HIP", 4: "ERR_NAN", 5: "ERR_NEG_DENSITY",
              6: "ERR_NEG_ENERGY", 7: "ERR_VALIDATION"}
@@ -103,6 +103,7 @@ _SIGNATURES = [
     ("mgcfd_step_factor_local", C.c_int, [_vp, C.c_int]),
     ("mgcfd_step_factor_min_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_step_factor_partials_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]),
+    ("mgcfd_sweep_stage", C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     ("mgcfd_sweep_begin_partials", C.c_int, [_vp, C.c_int]),
     ("mgcfd_sweep_end_partials", C.c_int, [_vp, C.c_int]),
     ("mgcfd_step_factor_apply", C.c_int, [_vp, C.c_int]),
@@ -428,6 +429,7 @@ class Solver:
         self._c(self.lib.mgcfd_step_factor_partials_devptr(self.handle, l, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def sweep_stage(self, l, j, partials=True): self._c(self.lib.mgcfd_sweep_stage(self.handle, l, j, 1 if partials else 0))
     def sweep_begin_partials(self, l): self._c(self.lib.mgcfd_sweep_begin_partials(self.handle, l))
     def sweep_end_partials(self, l): self._c(self.lib.mgcfd_sweep_end_partials(self.handle, l))
 

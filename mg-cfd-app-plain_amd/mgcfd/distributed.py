@@ -146,8 +146,9 @@ class PartitionedSweep:
     copier to run several parts on one GPU."""
 
     def __init__(self, solver, part, dist=None, make_buffer=None, exchange=None, allreduce_min=None,
-                 global_time_step=True):
+                 global_time_step=True, fused=False):
         self.s = solver
+        self.fused = fused and hasattr(solver, "sweep_stage")     # one fused launch per RK stage (mgcfd_sweep_stage)
         self.allreduce_min_fn = allreduce_min
         self.part = part
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
@@ -184,6 +185,10 @@ class PartitionedSweep:
         """The per-level body of the reference's cycle loop (src/euler3d_cpu_double.cpp:383-508) on a
         partitioned level; ghosts must be current on entry (call exchange() after setting the state)."""
         s = self.s
+        if self.fused:
+            _fused_partitioned_sweep(s, 0, self.global_time_step, self.allreduce_min_fn, self.dist,
+                                     lambda: self.exchange("stage"), self)
+            return
         s.copy_old_variables(0)
         if self.global_time_step:
             s.step_factor_local(0)
@@ -248,6 +253,22 @@ class LevelPerRankCycle:
                     s.smooth(l, 1)
 
 
+def _fused_partitioned_sweep(s, level, global_time_step, allreduce_min_fn, dist, exchange_stage, owner):
+    """A sweep of a partitioned level with one fused launch per Runge-Kutta stage: the first half of
+    compute_step_factor reduced to the rank's scalar minimum (the ranks' levels differ in size, so their per-workgroup
+    minima cannot be all-reduced element-wise), the all-reduce(MIN) of that scalar, then stage / halo message three
+    times (the message carries the state the stage just wrote, MGCFD_ARR_STAGE)."""
+    s.sweep_begin(level)
+    if global_time_step:
+        if allreduce_min_fn:
+            allreduce_min_fn(owner, level)
+        elif dist:
+            dist.all_reduce(s.min_tensor(level), op=dist.ReduceOp.MIN)
+    for j in range(RK):
+        s.sweep_stage(level, j, False)
+        exchange_stage()
+
+
 class PartitionedCycle:
     """Multigrid V-cycles on a hierarchy partitioned over ranks (mgcfd.partition.partition_hierarchy): every level is
     split, each rank sweeps its owned nodes, and ghost values move wherever the next operation reads them —
@@ -256,8 +277,9 @@ class PartitionedCycle:
     _unpack around torch.distributed.batch_isend_irecv, or the injected `exchange`).  One all-reduce(MIN) of the time
     step per sweep as in PartitionedSweep."""
 
-    def __init__(self, solver, hpart, dist=None, make_buffer=None, exchange=None, allreduce_min=None):
+    def __init__(self, solver, hpart, dist=None, make_buffer=None, exchange=None, allreduce_min=None, fused=False):
         self.s, self.h = solver, hpart
+        self.fused = fused and hasattr(solver, "sweep_stage")
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.exchange_fn = exchange
         self.allreduce_min_fn = allreduce_min
@@ -289,6 +311,10 @@ class PartitionedCycle:
 
     def sweep(self, level):
         s = self.s
+        if self.fused:
+            _fused_partitioned_sweep(s, level, True, self.allreduce_min_fn, self.dist,
+                                     lambda: self.exchange(level, "stage"), self)
+            return
         s.copy_old_variables(level)
         s.step_factor_local(level)
         if self.allreduce_min_fn:

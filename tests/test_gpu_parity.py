@@ -646,8 +646,9 @@ def test_ragged_tiles_overflow_the_lds_halo(oracle, exact):
     s.close()
 
 
-@pytest.mark.parametrize("variant,n_parts,partitioner", [(0, 3, "slab"), (2, 3, "slab"), (0, 4, "rcb")])
-def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts, partitioner):
+@pytest.mark.parametrize("variant,n_parts,partitioner,fused", [(0, 3, "slab", False), (2, 3, "slab", False), (0, 4, "rcb", False),
+                                                               (0, 3, "slab", True), (2, 4, "rcb", True)])
+def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts, partitioner, fused):
     """BASELINE config 5 in miniature: one level split into 3 parts with ghost nodes, every RK stage
     followed by a halo exchange (packed / unpacked on the GPU), global-min time step over all parts.
     The three parts run as three solvers on this one GPU, threads standing in for ranks and an
@@ -687,12 +688,13 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts
             buf.copy_(sweepers[peer].buf_send[sw.part.rank])
         barrier.wait()                                   # nobody repacks before all copies are enqueued
 
-    def allreduce_min(sw):
+    def allreduce_min(sw, level=0, partials=False):
         barrier.wait()
         if sw.part.rank == 0:
-            m = torch.stack([x.s.min_tensor(0) for x in sweepers]).min()
+            get = (lambda x: x.s.partial_min_tensor(0)) if partials else (lambda x: x.s.min_tensor(0))
+            m = torch.stack([get(x) for x in sweepers]).min(dim=0).values
             for x in sweepers:
-                x.s.min_tensor(0).fill_(m)
+                get(x).copy_(m)
         barrier.wait()
 
     for P in parts:
@@ -702,7 +704,7 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts
         s.set(0, "variables", q0[P.global_ids])          # ghosts start current
         solvers.append(s)
         sweepers.append(PartitionedSweep(HipSolverAdapter(s, dev), P, None, exchange=exchange, allreduce_min=allreduce_min,
-                                         make_buffer=lambda n: torch.empty(n, dtype=torch.float64, device=dev)))
+                                         make_buffer=lambda n: torch.empty(n, dtype=torch.float64, device=dev), fused=fused))
     errors = []
 
     def run(sw):
@@ -733,8 +735,8 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts
     assert abs(np.sqrt(sumsq / L["nel"]) - want_rms) <= 1e-12 * want_rms
 
 
-@pytest.mark.parametrize("sizes,n_parts", [((12, 6, 3), 3), ((14, 7), 4)])
-def test_partitioned_hierarchy_vcycles_equal_whole_mesh(sizes, n_parts):
+@pytest.mark.parametrize("sizes,n_parts,fused", [((12, 6, 3), 3, False), ((14, 7), 4, False), ((12, 6, 3), 3, True)])
+def test_partitioned_hierarchy_vcycles_equal_whole_mesh(sizes, n_parts, fused):
     """Every level of a hierarchy split over "ranks" (threads, one solver each, in-process copies for send/recv):
     flux ghosts, the children a rank's coarse nodes need for mgcfd_restrict and the parents mgcfd_prolong reads are
     ghosts that the cycle keeps current by halo exchanges; children are averaged in global-id order.  Three V-cycles
@@ -767,12 +769,13 @@ def test_partitioned_hierarchy_vcycles_equal_whole_mesh(sizes, n_parts):
             buf.copy_(cyclers[peer].buf_send[level][cy.h.rank])
         barrier.wait()
 
-    def allreduce_min(cy, level):
+    def allreduce_min(cy, level, partials=False):
         barrier.wait()
         if cy.h.rank == 0:
-            m = torch.stack([c.s.min_tensor(level) for c in cyclers]).min()
+            get = (lambda c: c.s.partial_min_tensor(level)) if partials else (lambda c: c.s.min_tensor(level))
+            m = torch.stack([get(c) for c in cyclers]).min(dim=0).values
             for c in cyclers:
-                c.s.min_tensor(level).fill_(m)
+                get(c).copy_(m)
         barrier.wait()
 
     for h in H:
@@ -781,7 +784,7 @@ def test_partitioned_hierarchy_vcycles_equal_whole_mesh(sizes, n_parts):
         s.set_stream(tstream.cuda_stream)
         solvers.append(s)
         cyclers.append(PartitionedCycle(HipSolverAdapter(s, dev), h, None, exchange=exchange, allreduce_min=allreduce_min,
-                                        make_buffer=lambda n: torch.empty(max(n, 1), dtype=torch.float64, device=dev)))
+                                        make_buffer=lambda n: torch.empty(max(n, 1), dtype=torch.float64, device=dev), fused=fused))
     errors = []
 
     def run(cy):

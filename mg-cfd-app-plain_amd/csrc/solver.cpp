@@ -866,8 +866,15 @@ static void smooth_once(mgcfd_solver *s, int level)
         // single level: the next sweep starts from this sweep's result, let the last stage look ahead
         const bool look_ahead = s->L.size() == 1 && lv.n_owned == lv.info.nel;   // (a partitioned level's ghosts are stale)
         double *const start = lv.q, *const b1 = lv.q_alt, *const b2 = lv.old_variables;
+        // Every workgroup of the first stage takes the minimum over ALL per-workgroup partial minima: fine for a
+        // thousand tiles (11 MB of L2 reads at the M6 size), quadratic beyond — large levels reduce them once.
+        int apply = apply_pending ? 1 : 0;
+        if (apply_pending && lv.plan.n_tiles > 2048) {
+            exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
+            apply = 2;
+        }
         mgcfd_solver::Timed group(s, level, MGCFD_LOOP_FLUX, true, s->opt_timing == 2 ? MGCFD_RK : 1);
-        s->op_fused_stage(level, 0, start, b1, apply_pending ? 1 : 0, false, start);
+        s->op_fused_stage(level, 0, start, b1, apply, false, start);
         s->op_fused_stage(level, 1, b1, b2, 0, false, start);
         const bool sumsq = lv.want_sumsq && lv.n_owned == lv.info.nel;
         s->op_fused_stage(level, 2, b2, b1, 0, true, start, look_ahead, sumsq);   // + :508

@@ -101,7 +101,8 @@ class ShardedSweep:
             # fused kernels: everything before the collective, the collective, everything after.  Where the solver
             # offers them, the per-workgroup PARTIAL minima (a few KB) are all-reduced instead of the scalar: no
             # reduction kernel in front of the collective, the first stage takes the minimum over the global partials.
-            partials = self.reduce_partials and hasattr(s, "partial_min_tensor")
+            # (up to ~2,000 tiles: every workgroup of the first stage reduces the whole array, which is quadratic)
+            partials = self.reduce_partials and hasattr(s, "partial_min_tensor") and s.partial_min_tensor(level).numel() <= 2048
             (s.sweep_begin_partials if partials else s.sweep_begin)(level)
             if self.global_time_step and self.dist:
                 # The first stage's fluxes do not depend on the time step: run them while the all-reduce

@@ -885,10 +885,15 @@ static void smooth_once(mgcfd_solver *s, int level)
         return;
     }
     const bool apply_pending = s->op_step_factor(level, true);     // :383 + :388-395
+    int apply0 = apply_pending ? 1 : 0;
+    if (apply_pending && lv.plan.n_tiles > 2048) {                 // large level: reduce the partial minima once (see above)
+        exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
+        apply0 = 2;
+    }
     for (int j = 0; j < MGCFD_RK; j++) {                           // :397-506
         s->op_flux(level, 7);
         // the indirect_rw probe reads fluxes[] right after, so zero for real when it is on
-        s->op_time_step(level, j, (apply_pending && j == 0) ? 1 : 0, j == MGCFD_RK - 1, !s->opt_indirect_rw);   // + :508 on the last stage
+        s->op_time_step(level, j, j == 0 ? apply0 : 0, j == MGCFD_RK - 1, !s->opt_indirect_rw);   // + :508 on the last stage
         if (s->opt_indirect_rw) { s->op_indirect_rw(level); s->op_zero_fluxes(level); }
     }
 }

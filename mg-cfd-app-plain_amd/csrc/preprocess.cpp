@@ -146,6 +146,51 @@ std::vector<int32_t> cluster_order(const Adjacency &g, int64_t nel)
     return order;
 }
 
+// Recursive coordinate bisection into boxes of kTile nodes (all but the last hold exactly kTile): split the node
+// set at a multiple of kTile along its longest axis.  No fragments, whatever the degree distribution — the fallback
+// for meshes (tetrahedral, ~15 neighbours per node) on which the greedy balls leave ragged remainders between them.
+void rcb_split(const double *coords, int32_t *ids, int64_t n)
+{
+    if (n <= kTile) return;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = 0; i < n; i++)
+        for (int c = 0; c < 3; c++) {
+            const double x = coords[3 * static_cast<size_t>(ids[i]) + c];
+            lo[c] = std::min(lo[c], x); hi[c] = std::max(hi[c], x);
+        }
+    int ax = 0;
+    for (int c = 1; c < 3; c++) if (hi[c] - lo[c] > hi[ax] - lo[ax]) ax = c;
+    const int64_t tiles = (n + kTile - 1) / kTile, left = (tiles / 2) * kTile;
+    std::nth_element(ids, ids + left, ids + n, [&](int32_t x, int32_t y) {
+        const double cx = coords[3 * static_cast<size_t>(x) + ax], cy = coords[3 * static_cast<size_t>(y) + ax];
+        return cx != cy ? cx < cy : x < y;
+    });
+    rcb_split(coords, ids, left);
+    rcb_split(coords, ids + left, n - left);
+}
+
+// What an ordering costs the tile kernels: {halo nodes that do not fit a tile's LDS (read from HBM per use), all halo nodes}.
+std::pair<int64_t, int64_t> halo_cost(const Adjacency &g, const std::vector<int32_t> &order, int64_t nel)
+{
+    std::vector<int32_t> tile_of(static_cast<size_t>(nel)), stamp(static_cast<size_t>(nel), -1);
+    for (int64_t n = 0; n < nel; n++) tile_of[static_cast<size_t>(order[static_cast<size_t>(n)])] = static_cast<int32_t>(n / kTile);
+    int64_t excess = 0, total = 0;
+    for (int64_t s = 0; s < nel; s += kTile) {
+        const int32_t t = static_cast<int32_t>(s / kTile);
+        int64_t count = 0;
+        for (int64_t n = s; n < std::min(nel, s + kTile); n++) {
+            const int32_t v = order[static_cast<size_t>(n)];
+            for (int32_t k = g.ptr[static_cast<size_t>(v)]; k < g.ptr[static_cast<size_t>(v) + 1]; k++) {
+                const int32_t u = g.idx[static_cast<size_t>(k)];
+                if (tile_of[static_cast<size_t>(u)] != t && stamp[static_cast<size_t>(u)] != t) { stamp[static_cast<size_t>(u)] = t; count++; }
+            }
+        }
+        total += count;
+        excess += std::max<int64_t>(0, count - kHaloStride);
+    }
+    return {excess, total};
+}
+
 inline double inv_distance(const double *p, const double *q)
 {
     const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
@@ -231,7 +276,18 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
 
     // ---- node order ----
     std::vector<int32_t> order;
-    if (opt.ordering == 2) order = cluster_order(g, nel);
+    if (opt.ordering == 2) {
+        order = cluster_order(g, nel);
+        // greedy balls have the smallest halos on hexahedral-like meshes; where they overflow the LDS tile
+        // (high-degree meshes) try coordinate boxes and keep whichever leaves fewer halo nodes outside
+        const std::pair<int64_t, int64_t> greedy = halo_cost(g, order, nel);
+        if (greedy.first > 0 && L.coords) {
+            std::vector<int32_t> boxes(static_cast<size_t>(nel));
+            std::iota(boxes.begin(), boxes.end(), 0);
+            rcb_split(L.coords, boxes.data(), nel);
+            if (halo_cost(g, boxes, nel) < greedy) order.swap(boxes);
+        }
+    }
     else if (opt.ordering == 1) order = cuthill_mckee(g, nel);
     else { order.resize(static_cast<size_t>(nel)); std::iota(order.begin(), order.end(), 0); }
     std::vector<int32_t> bnd_count(static_cast<size_t>(nel), 0);
@@ -345,9 +401,43 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                 if (id < base || id >= base + kTile) halo.push_back(id);
             }
             std::sort(halo.begin(), halo.end());
+            const int32_t n_refs = static_cast<int32_t>(halo.size());
             halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
             const int32_t n_halo = static_cast<int32_t>(halo.size());
             const int32_t staged = std::min<int32_t>(n_halo, halo_cap);
+            if (n_halo > staged) {
+                // more halo nodes than the LDS tile holds: stage the most referenced ones, leave the least
+                // referenced to the overflow table (each use of those is a gather from HBM); both parts ascending
+                std::vector<std::pair<int32_t, int32_t>> by_refs;                // (-references, id)
+                by_refs.reserve(static_cast<size_t>(n_halo));
+                {
+                    std::vector<int32_t> all;
+                    all.reserve(static_cast<size_t>(n_refs));
+                    for (int64_t e = e0; e < e1; e++) {
+                        const int32_t code = P.nbr[static_cast<size_t>(e)];
+                        if (code < 0) continue;
+                        const int32_t id = code & kIdMask;
+                        if (id < base || id >= base + kTile) all.push_back(id);
+                    }
+                    std::sort(all.begin(), all.end());
+                    for (size_t i = 0; i < all.size();) {
+                        size_t j = i;
+                        while (j < all.size() && all[j] == all[i]) j++;
+                        by_refs.emplace_back(-static_cast<int32_t>(j - i), all[i]);
+                        i = j;
+                    }
+                }
+                std::sort(by_refs.begin(), by_refs.end());
+                for (int32_t k = 0; k < n_halo; k++) halo[static_cast<size_t>(k)] = by_refs[static_cast<size_t>(k)].second;
+                std::sort(halo.begin(), halo.begin() + staged);
+                std::sort(halo.begin() + staged, halo.end());
+            }
+            // position of a halo id in `halo` (staged part first, then the overflow part; each ascending)
+            auto halo_pos = [&](int32_t id) -> int32_t {
+                auto it = std::lower_bound(halo.begin(), halo.begin() + staged, id);
+                if (it != halo.begin() + staged && *it == id) return static_cast<int32_t>(it - halo.begin());
+                return static_cast<int32_t>(std::lower_bound(halo.begin() + staged, halo.end(), id) - halo.begin());
+            };
             if (n_halo - staged > ovf_cap) throw std::runtime_error("tile halo exceeds what 15-bit slots can address");
             halo_total += n_halo;
             P.halo_max = std::max<int32_t>(P.halo_max, n_halo);
@@ -362,8 +452,8 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                     uint32_t slot;
                     if (id >= base && id < base + kTile) slot = static_cast<uint32_t>(id - base);
                     else {
-                        // ascending halo: the first `staged` ids live in LDS, the rest in the overflow table
-                        const int32_t pos = static_cast<int32_t>(std::lower_bound(halo.begin(), halo.end(), id) - halo.begin());
+                        // the first `staged` halo ids live in LDS, the rest in the overflow table
+                        const int32_t pos = halo_pos(id);
                         slot = static_cast<uint32_t>(kTile + pos);        // pos >= staged  =>  slot >= kTileCap
                         if (pos >= staged) P.halo_overflow_refs++;
                     }
@@ -387,8 +477,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             if (P.edge_once) {
                 auto slot_of = [&](int32_t id) -> uint16_t {
                     if (id >= base && id < base + kTile) return static_cast<uint16_t>(id - base);
-                    const int32_t pos = static_cast<int32_t>(std::lower_bound(halo.begin(), halo.end(), id) - halo.begin());
-                    return static_cast<uint16_t>(kTile + pos);            // >= kTileCap: overflow table, as in nbr16
+                    return static_cast<uint16_t>(kTile + halo_pos(id));   // >= kTileCap: overflow table, as in nbr16
                 };
                 const size_t chunk0 = static_cast<size_t>(P.te_chunk_ptr[static_cast<size_t>(t)]);
                 const size_t n_chunks = (static_cast<size_t>(n_te) + kEdgeChunk - 1) / kEdgeChunk;

@@ -171,6 +171,68 @@ def make_random_graph_level(nel: int, *, degree: int = 6, seed: int = 0, boundar
                      nbr_idx=nb[order].copy(), nbr_w=ww[order].copy())
 
 
+_TET_EDGES = ((0, 1, 2, 3), (0, 2, 1, 3), (0, 3, 1, 2), (1, 2, 0, 3), (1, 3, 0, 2), (2, 3, 0, 1))   # (i, j, the other two)
+
+
+def make_tet_level(nel: int, *, seed: int = 0, wall_below: float = 0.9) -> LevelMesh:
+    """A genuinely unstructured level: the Delaunay tetrahedralisation of ``nel`` random points in the unit
+    cube with its MEDIAN-DUAL finite-volume metrics (the kind of mesh the reference's datasets hold: node
+    degrees from 5 to 50+, about 7.7 edges per node, no ordering locality).  Per internal edge the area vector
+    is the sum, over the tetrahedra around it, of the dual quadrilateral (edge midpoint, face centroid, cell
+    centroid, face centroid); node volume = a quarter of every incident tetrahedron; a hull node gets one
+    boundary face that closes its dual cell exactly (solid wall where that face looks down, -z, far field
+    elsewhere), so a uniform state is preserved to rounding."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    xyz = rng.random((nel, 3))
+    tri = Delaunay(xyz)
+    tets = tri.simplices.astype(np.int64)
+    p = xyz[tets]                                               # [T, 4, 3]
+    cen = p.mean(axis=1)
+    vol6 = np.abs(np.einsum("ij,ij->i", np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), p[:, 3] - p[:, 0]))
+    volumes = np.bincount(tets.ravel(), weights=np.repeat(vol6 / 24.0, 4), minlength=nel)
+    ea, eb, es = [], [], []
+    for i, j, k, l in _TET_EDGES:
+        mid = 0.5 * (p[:, i] + p[:, j])
+        fk = (p[:, i] + p[:, j] + p[:, k]) / 3.0
+        fl = (p[:, i] + p[:, j] + p[:, l]) / 3.0
+        s = 0.5 * np.cross(cen - mid, fl - fk)
+        s *= np.sign(np.einsum("ij,ij->i", s, p[:, j] - p[:, i]))[:, None]     # from i towards j
+        a, b = tets[:, i], tets[:, j]
+        swap = a > b
+        ea.append(np.where(swap, b, a)); eb.append(np.where(swap, a, b)); es.append(np.where(swap[:, None], -s, s))
+    ea, eb, es = np.concatenate(ea), np.concatenate(eb), np.concatenate(es)
+    key = ea * nel + eb
+    uniq, inv = np.unique(key, return_inverse=True)
+    w = np.stack([np.bincount(inv, weights=es[:, c], minlength=len(uniq)) for c in range(3)], axis=1)
+    lo, hi = uniq // nel, uniq % nel                            # w points from lo to hi
+    # what is missing from each hull node's closed surface is its boundary face
+    out = np.zeros((nel, 3))
+    for c in range(3):
+        out[:, c] = np.bincount(lo, weights=w[:, c], minlength=nel) - np.bincount(hi, weights=w[:, c], minlength=nel)
+    hull = np.unique(tri.convex_hull).astype(np.int64)
+    bw = -out[hull]
+    bcode = np.where(-bw[:, 2] > wall_below * np.linalg.norm(bw, axis=1), -1, -2).astype(np.int64)
+    src = np.concatenate([lo, hi, hull])
+    nb = np.concatenate([hi, lo, bcode])
+    ww = np.concatenate([w, -w, bw])
+    order = np.lexsort((rng.random(len(src)), src))
+    counts = np.bincount(src, minlength=nel)
+    ptr = np.zeros(nel + 1, dtype=np.int64)
+    np.cumsum(counts, out=ptr[1:])
+    return LevelMesh(nel=nel, volumes=volumes, coords=xyz, nbr_ptr=ptr, nbr_idx=nb[order].copy(), nbr_w=ww[order].copy())
+
+
+def make_tet_multigrid(sizes: Sequence[int], mesh_name: str = "m6wing", *, seed: int = 0) -> MultigridMesh:
+    """Hierarchy of independent Delaunay levels (``sizes`` = node counts), nearest-coarse-node maps."""
+    mg = MultigridMesh(mesh_name=mesh_name)
+    for l, n in enumerate(sizes):
+        mg.levels.append(make_tet_level(n, seed=seed + 101 * l))
+    for l in range(len(sizes) - 1):
+        mg.levels[l].mg_map = nearest_map(mg.levels[l], mg.levels[l + 1])
+    return mg
+
+
 def nearest_map(fine: LevelMesh, coarse: LevelMesh) -> np.ndarray:
     from scipy.spatial import cKDTree
     _, idx = cKDTree(coarse.coords).query(fine.coords, k=1)

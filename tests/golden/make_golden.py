@@ -39,6 +39,8 @@ CASES = {
     "fvcorr_1lvl": ((8,), "fvcorr", dict(seed=7, cavity_radius=0.01, volume_noise=0.02), 20, 1),
     # run with the reference built with -DLEGACY_ORDERING (only the binary's outputs; undamped, so the order matters)
     "fvcorr_1lvl_legacy_ordering": ((8,), "fvcorr", dict(seed=8, cavity_radius=0.01, volume_noise=0.02), 30, 1),
+    # unstructured: Delaunay tetrahedra with median-dual metrics (sizes = node counts), degrees 4..30, wall + far-field hull faces
+    "tet_2lvl": ((420, 90), "rotor37", dict(seed=4, tet=True), 4, 1),
 }
 
 
@@ -71,7 +73,8 @@ def kernel_vectors(ref, case_dir, info, mesh_variant):
         out[f"L{l}_volumes"] = vol
         if mesh_variant != 0:
             ref.ref_adjust_ewt(O.ptr(coords), n_edges, O.ptr(edges))
-            ref.ref_dampen_ewt(n_edges, O.ptr(edges), 5e-8)
+            # damping per mesh (src/euler3d_cpu_double.cpp:337-352): m6wing 5e-8, la_cascade 1e-7, rotor37 2e-7
+            ref.ref_dampen_ewt(n_edges, O.ptr(edges), {2: 5e-8, 3: 1e-7, 4: 2e-7}[mesh_variant])
         out[f"L{l}_edges"] = edges.copy()
         levels.append((nel, sizes, vol, edges, coords))
     for l, (nel, sizes, vol, edges, coords) in enumerate(levels):
@@ -138,10 +141,13 @@ def main():
     ref = O.load_reference()
     env = dict(os.environ, OMP_NUM_THREADS="1")
     for name, (sizes, mesh_name, kw, cycles, dup) in CASES.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:      # python make_golden.py [case ...]
+            continue
         d = os.path.join(HERE, name)
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(os.path.join(d, "input"))
-        mg = meshgen.make_multigrid(sizes, mesh_name, **kw)
+        kw = dict(kw)
+        mg = (meshgen.make_tet_multigrid if kw.pop("tet", False) else meshgen.make_multigrid)(sizes, mesh_name, **kw)
         meshgen.write_input(mg, os.path.join(d, "input"))
         out_dir = os.path.join(d, "_out")
         os.makedirs(out_dir)

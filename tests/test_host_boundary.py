@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ["m6_2lvl", "m6_3lvl", "fvcorr_1lvl"]
+CASES = ["m6_2lvl", "m6_3lvl", "fvcorr_1lvl", "tet_2lvl"]
 
 
 @pytest.fixture(scope="module")
@@ -48,7 +48,7 @@ def test_reader_matches_reference(mgcfd_mod, case):
     d = os.path.join(GOLDEN, case)
     g = np.load(os.path.join(d, "kernels.npz"))
     mesh = mgcfd_mod.Mesh("input.dat", os.path.join(d, "input"))
-    assert mesh.variant == (0 if case.startswith("fvcorr") else 2)
+    assert mesh.variant == (0 if case.startswith("fvcorr") else 4 if case.startswith("tet") else 2)      # tet_2lvl is a rotor37 input
     for l in range(mesh.num_levels):
         L = mesh.level(l)
         sizes = g[f"L{l}_sizes"].tolist()

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Sweep and flux-kernel rates on an UNSTRUCTURED level (Delaunay tetrahedra, median-dual metrics,
+meshgen.make_tet_level): the same measurements bench.py takes on the lattice workload, to show how the tile
+kernels behave with 7.7 edges per node, degrees up to ~55 and halos larger than a tile holds.
+    python tools/tet_mesh_bench.py [--nodes 120000] [--steps 300]"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd"))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nodes", type=int, default=120000)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--variants", default="-1,1,2")
+    args = ap.parse_args()
+    import numpy as np, torch, mgcfd
+    from mgcfd import meshgen
+    from bench import perturbed_state
+    t0 = time.time()
+    mg = meshgen.MultigridMesh(mesh_name="m6wing")
+    mg.levels.append(meshgen.make_tet_level(args.nodes, seed=0))
+    levels = mgcfd.generated_to_levels(mg)
+    print(f"mesh built in {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
+    out = []
+    for variant in [int(v) for v in args.variants.split(",")]:
+        s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+        s.set_stream(stream.cuda_stream)
+        s.set_option("flux_variant", variant)
+        nel, E = s.nel(0), s.num_internal_edges(0)
+        s.set(0, "variables", perturbed_state(nel, s.far_field()[:5]))
+        for _ in range(50):
+            s.smooth(0, 1)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(args.steps):
+            s.smooth(0, 1)
+        torch.cuda.synchronize()
+        sweep = (time.perf_counter() - t) / args.steps
+        flux = s.bench_flux(0, 50)
+        rc, _ = s.check_for_invalid_variables(0)
+        out.append({"variant": variant, "nodes": nel, "edges": E, "edge_once": bool(s.has_edge_once(0)),
+                    "sweep_us": round(sweep * 1e6, 2), "sweep_gedges_s": round(3 * E / sweep / 1e9, 2),
+                    "flux_us": round(flux * 1e6, 2), "flux_gedges_s": round(E / flux / 1e9, 2),
+                    "flux_roofline_frac": round((40 * E + 80 * nel) / flux / 8e12, 4), "state_valid": rc == 0})
+        s.close()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

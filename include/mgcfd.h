@@ -159,6 +159,12 @@ void mgcfd_destroy(mgcfd_solver *s);
 int mgcfd_set_option(mgcfd_solver *s, int option, int value);
 /* *yes = 1 when level `level` can run the edge-once flux variant (MGCFD_OPT_FLUX_VARIANT bit 1). */
 int mgcfd_level_has_edge_once(const mgcfd_solver *s, int level, int *yes);
+/* What the tiling of level `level` looks like (the figures MGCFD_VERBOSE=1 prints at creation):
+ * out[0] tiles of 256 nodes, out[1] halo nodes of all tiles together, out[2] the largest halo, out[3] halo nodes a
+ * tile can stage in LDS, out[4] incidence-row entries that refer to a halo node beyond that (each a gather from
+ * HBM), out[5] incidence-row entries of internal edges (two per edge), out[6] padding entries among them,
+ * out[7] 1 when the nodes were ordered by coordinate boxes instead of greedy clusters. */
+int mgcfd_level_tiling(const mgcfd_solver *s, int level, int64_t out[8]);
 int mgcfd_get_option(const mgcfd_solver *s, int option, int *value);
 /* Run all subsequent work of this solver on an existing HIP stream (hipStream_t as void*), e.g.
  * the cuda_stream of a torch.cuda.Stream() made current with torch.cuda.set_stream(): collectives

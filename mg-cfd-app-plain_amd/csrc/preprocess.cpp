@@ -285,7 +285,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             std::vector<int32_t> boxes(static_cast<size_t>(nel));
             std::iota(boxes.begin(), boxes.end(), 0);
             rcb_split(L.coords, boxes.data(), nel);
-            if (halo_cost(g, boxes, nel) < greedy) order.swap(boxes);
+            if (halo_cost(g, boxes, nel) < greedy) { order.swap(boxes); P.ordered_by_boxes = true; }
         }
     }
     else if (opt.ordering == 1) order = cuthill_mckee(g, nel);
@@ -508,6 +508,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             P.tile_ovf_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(P.tile_ovf.size());
         }
         P.halo_mean = P.n_tiles ? double(halo_total) / double(P.n_tiles) : 0.0;
+        P.halo_total = halo_total;
         P.te_mean = P.n_tiles ? double(te_total) / double(P.n_tiles) : 0.0;
         if (!P.edge_once) {
             P.te_slots.clear(); P.te_w.clear(); P.gat16.clear();
@@ -537,6 +538,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     int64_t int_slots = 0;
     for (int32_t s = 0; s < P.n_slices; s++) int_slots += static_cast<int64_t>(P.rows_int[static_cast<size_t>(s)]) * kSlice;
     P.pad_fraction = useful > 0 ? double(int_slots - useful) / double(useful) : 0.0;
+    P.pad_entries = int_slots - useful;
 }
 
 void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge> &fine_edges,

@@ -68,7 +68,8 @@ struct LevelPlan {
     std::vector<int32_t> tile_ovf_ptr;    // [n_tiles+1]
     std::vector<int32_t> tile_ovf;        // global new ids of halo nodes that did not fit the LDS tile
     std::vector<uint16_t> nbr16;          // [rows*64] 16-bit tile-local codes (see kT16*)
-    double halo_mean = 0.0; int32_t halo_max = 0; int64_t halo_overflow_refs = 0;
+    double halo_mean = 0.0; int32_t halo_max = 0; int64_t halo_overflow_refs = 0, halo_total = 0;
+    bool ordered_by_boxes = false;        // node order from rcb_split (coordinate boxes) instead of cluster_order
     std::vector<EdgeW> w;              // [rows*64]
     //   internal, this node = a:  (x,y,z) = -0.5*e   k = -|e|*smoothing*0.5   (flux_kernel.elemfunc.c:130-140)
     //   internal, this node = b:  (x,y,z) = +0.5*e   k = same
@@ -91,6 +92,7 @@ struct LevelPlan {
                                           //   node is its b end; -1 = padding / boundary rows
     int64_t n_internal_entries = 0;    // = 2 * internal edges
     double pad_fraction = 0.0;         // padding / useful entries in the internal rows
+    int64_t pad_entries = 0;           // padding entries in the internal rows
 
     // ---- restriction to the next-coarser level: coarse-centred CSR of children ----
     std::vector<int32_t> child_ptr;    // [nel_coarse+1]

@@ -742,6 +742,21 @@ int mgcfd_level_has_edge_once(const mgcfd_solver *s, int level, int *yes)
     *yes = s->L[static_cast<size_t>(level)].dp.edge_once;
     return MGCFD_OK;
 }
+int mgcfd_level_tiling(const mgcfd_solver *s, int level, int64_t out[8])
+{
+    REQUIRE(s); REQUIRE(out);
+    if (level < 0 || level >= static_cast<int>(s->L.size())) { g_last_error = "level out of range"; return MGCFD_ERR_ARG; }
+    const LevelPlan &P = s->L[static_cast<size_t>(level)].plan;
+    out[0] = P.n_tiles;
+    out[1] = P.halo_total;
+    out[2] = P.halo_max;
+    out[3] = kTileCap - kTile;
+    out[4] = P.halo_overflow_refs;
+    out[5] = P.n_internal_entries;
+    out[6] = P.pad_entries;
+    out[7] = P.ordered_by_boxes ? 1 : 0;
+    return MGCFD_OK;
+}
 int mgcfd_get_option(const mgcfd_solver *s, int option, int *value)
 {
     REQUIRE(s); REQUIRE(value);

@@ -67,6 +67,7 @@ _SIGNATURES = [
     ("mgcfd_destroy", None, [_vp]),
     ("mgcfd_set_option", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mgcfd_level_has_edge_once", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    ("mgcfd_level_tiling", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
     ("mgcfd_get_option", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_set_stream", C.c_int, [_vp, _vp]),
     ("mgcfd_synchronize", C.c_int, [_vp]),
@@ -284,6 +285,13 @@ class Solver:
 
     def array_written(self, l: int, name: str):
         self._c(self.lib.mgcfd_array_written(self.handle, l, ARR[name]))
+
+    def tiling(self, l: int) -> dict:
+        """How level ``l`` was cut into LDS tiles (mgcfd_level_tiling)."""
+        out = (C.c_int64 * 8)()
+        self._c(self.lib.mgcfd_level_tiling(self.handle, l, out))
+        keys = ("tiles", "halo_nodes", "halo_max", "halo_capacity", "overflow_refs", "row_entries", "padding_entries", "coordinate_boxes")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def has_edge_once(self, l: int) -> bool:
         v = C.c_int()

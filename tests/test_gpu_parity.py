@@ -374,6 +374,28 @@ def test_unstructured_tetrahedral_median_dual_mesh(oracle, name, sizes, cycles):
         s.close()
 
 
+def test_tiling_report_and_coordinate_box_fallback():
+    """mgcfd_level_tiling: a lattice level keeps the greedy clusters (no halo node left outside the LDS tile); on a
+    tetrahedral level those overflow, coordinate boxes are chosen instead, and few row entries are left to gather
+    from HBM."""
+    import mgcfd
+    from mgcfd import meshgen
+    mg = meshgen.make_multigrid((20,), "m6wing", seed=1, jitter=0.2)
+    s = mgcfd.Solver.from_arrays(mgcfd.generated_to_levels(mg), mg.mesh_variant)
+    t = s.tiling(0)
+    assert t["tiles"] == (8000 + 255) // 256 and t["overflow_refs"] == 0 and t["coordinate_boxes"] == 0
+    assert t["halo_max"] <= t["halo_capacity"] == 304
+    assert t["row_entries"] == 2 * s.num_internal_edges(0)
+    s.close()
+    mg = meshgen.make_tet_multigrid((30000,), "m6wing", seed=1)
+    s = mgcfd.Solver.from_arrays(mgcfd.generated_to_levels(mg), mg.mesh_variant)
+    t = s.tiling(0)
+    assert t["coordinate_boxes"] == 1 and t["halo_max"] > t["halo_capacity"]
+    assert t["row_entries"] == 2 * s.num_internal_edges(0)
+    assert t["overflow_refs"] < 0.02 * t["row_entries"]
+    s.close()
+
+
 @pytest.mark.parametrize("fuse", [1, 0])
 def test_old_variables_hold_the_sweep_start_state(mesh3_dir, fvcorr_dir, fuse):
     """The fused sweeps never copy variables to old_variables (the three state buffers change roles instead) and may

@@ -374,6 +374,50 @@ def test_unstructured_tetrahedral_median_dual_mesh(oracle, name, sizes, cycles):
         s.close()
 
 
+def _hand_level(nel, internal, faces, seed=0, scale=1e-3):
+    """A level dict from explicit lists: internal = [(a, b)], faces = [(code, node)] with code -1 (solid wall) / -2 (far field)."""
+    from mgcfd.meshgen import EDGE_DTYPE
+    rng = np.random.default_rng(seed)
+    faces = sorted(faces, key=lambda f: -f[0])                   # class order: internal | -1 | -2
+    edges = np.zeros(len(internal) + len(faces), dtype=EDGE_DTYPE)
+    for k, (a, b) in enumerate(internal):
+        edges[k] = (a, b, *rng.normal(size=3) * scale)
+    for k, (code, node) in enumerate(faces):
+        edges[len(internal) + k] = (code, node, *rng.normal(size=3) * scale)
+    return {"nel": nel, "volumes": rng.uniform(1e-6, 2e-6, nel), "coords": rng.random((nel, 3)), "edges": edges,
+            "n_internal": len(internal), "n_boundary": sum(1 for c, _ in faces if c == -1),
+            "n_wall": sum(1 for c, _ in faces if c == -2), "mg_map": None}
+
+
+@pytest.mark.parametrize("name,nel,internal,faces", [
+    ("one node, one far-field face", 1, [], [(-2, 0)]),
+    ("one node, nothing attached", 1, [], []),
+    ("three isolated nodes, wall faces only", 3, [], [(-1, 0), (-1, 2), (-1, 2)]),
+    ("two nodes, one edge, no faces", 2, [(0, 1)], []),
+    ("isolated nodes between connected ones", 6, [(0, 5), (2, 5)], [(-2, 3), (-1, 5), (-2, 5)]),
+    ("a hub: one node on 300 edges (more rows than a tile has nodes)", 301, [(0, k) for k in range(1, 301)], [(-2, 0)]),
+])
+def test_degenerate_levels(oracle, name, nel, internal, faces):
+    """Empty and degenerate inputs: levels without internal edges, without faces, with isolated nodes, with a node of
+    degree 300 — a few iterations against the oracle, bit for bit, fused and kernel-by-kernel."""
+    import mgcfd
+    levels = [_hand_level(nel, internal, faces, seed=len(name), scale=1e-3 if nel < 100 else 1e-6)]   # (the hub: small weights, or the undamped state goes negative)
+    want, want_rms = _oracle_solve_arrays(oracle, levels, 0, 3)          # fvcorr: undamped, local time step, no coords needed
+    for fuse in (1, 0):
+        s = mgcfd.Solver.from_arrays(levels, 0)
+        s.set_option("fuse_update", fuse)
+        rms = s.run_cycles(3)
+        _assert_close(s.get(0, "variables"), want[0], True, f"{name} fuse={fuse}")
+        assert np.allclose(rms, want_rms, rtol=1e-12, atol=1e-300)
+        s.close()
+    # the same with the global time step (m6wing: needs coordinates; damping 5e-8)
+    want, want_rms = _oracle_solve_arrays(oracle, levels, 2, 2)
+    s = mgcfd.Solver.from_arrays(levels, 2)
+    s.run_cycles(2)
+    _assert_close(s.get(0, "variables"), want[0], True, f"{name} m6wing")
+    s.close()
+
+
 def test_tiling_report_and_coordinate_box_fallback():
     """mgcfd_level_tiling: a lattice level keeps the greedy clusters (no halo node left outside the LDS tile); on a
     tetrahedral level those overflow, coordinate boxes are chosen instead, and few row entries are left to gather

@@ -221,8 +221,14 @@ int mgcfd_prolong(mgcfd_solver *s, int fine_level);
 int mgcfd_smooth(mgcfd_solver *s, int level, int sweeps);
 /* Runs `cycles` (multigrid) cycles from the solver's current state.  rms_out (may be NULL)
  * receives, per cycle, the level-0 RMS the reference prints.  Synchronises before returning.
- * On an invalid state returns MGCFD_ERR_NAN / NEG_* like the reference's exit(). */
+ * On an invalid state returns MGCFD_ERR_NAN / NEG_* like the reference's exit().
+ * The check runs inside every time_step launch; the earliest failing launch and, within it, the smallest original
+ * cell id are what is reported (the reference stops at exactly that cell).  The cycles of the current batch (up to
+ * 4096) still run to the end; rms_out entries from the failing cycle on are NaN. */
 int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out);
+/* Where the last MGCFD_ERR_NAN / NEG_DENSITY / NEG_ENERGY was found: *cell = original cell id (the reference's
+ * "Cell %ld"), *cycle = 0-based cycle of the mgcfd_run_cycles call (-1: not known — graph replay, or found by another call). */
+int mgcfd_invalid_state_location(const mgcfd_solver *s, int64_t *cell, int *cycle);
 
 /* ---------------------------------------------------------------------------------
  * State access (synchronous; original numbering)

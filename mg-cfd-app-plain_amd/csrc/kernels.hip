@@ -171,6 +171,15 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// check_for_invalid_variables (validation.cpp:107-138) runs after every time_step and stops at the first bad cell
+// in original order.  Here a bad cell leaves (launch sequence number, original id, code) in one word and the
+// smallest wins: the earliest checked launch since the host last looked, then the smallest original id.
+// `check` = that sequence number (>= 1, < 2^23; 0 switches the check off).
+__device__ __forceinline__ unsigned long long err_key(int check, int32_t original_id, int code)
+{
+    return (static_cast<unsigned long long>(check) << 40) | (static_cast<unsigned long long>(uint32_t(original_id)) << 8) | unsigned(code);
+}
+
 // XCD-aware block order: hardware deals consecutive workgroups round-robin over the 8 XCDs
 // (each with a private L2).  Give every XCD one CONTIGUOUS range of tiles instead, so that a
 // tile's halo — owned by neighbouring tiles — is usually already in the same L2.  Pure speed:
@@ -427,7 +436,7 @@ __device__ __forceinline__ void finish_node(int64_t i, int64_t nel, int64_t stri
             if (!finite) code = 1;
             else if (rho < 0.0) code = 2;
             else if (en < 0.0) code = 3;
-            if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
+            if (code) atomicMin(fs.err, err_key(fs.check, fs.old_of_new[i], code));
         }
         // look-ahead: the next sweep's compute_step_factor starts from the state just produced
         if (fs.next_partial_min) {
@@ -566,7 +575,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             if (!finite) code = 1;
             else if (o0 < 0.0) code = 2;
             else if (o4 < 0.0) code = 3;
-            if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
+            if (code) atomicMin(fs.err, err_key(fs.check, fs.old_of_new[i], code));
         }
     } else {
         o0 = q[i]; o1 = q[stride + i]; o2 = q[2 * stride + i]; o3 = q[3 * stride + i]; o4 = q[4 * stride + i];
@@ -727,7 +736,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             if (!finite) code = 1;
             else if (rho < 0.0) code = 2;
             else if (en < 0.0) code = 3;
-            if (code) atomicMin(fs.err, (static_cast<unsigned long long>(fs.old_of_new[i]) << 8) | unsigned(code));
+            if (code) atomicMin(fs.err, err_key(fs.check, fs.old_of_new[i], code));
         }
         // look-ahead: the next sweep's compute_step_factor starts from the state just produced
         if (ROLE == 3) {
@@ -1084,10 +1093,7 @@ k_time_step(int64_t nel, int64_t stride, double rk_div, double *__restrict__ ste
         else if (rho < 0.0) code = 2;
         else if (en < 0.0) code = 3;
         if (code) {
-            // The reference stops at the first bad cell in original order; keep the smallest
-            // original id and its code packed as (id << 8) | code.
-            const unsigned long long key = (static_cast<unsigned long long>(old_of_new[i]) << 8) | unsigned(code);
-            atomicMin(err, key);
+            atomicMin(err, err_key(check, old_of_new[i], code));
         }
     }
 }
@@ -1105,7 +1111,7 @@ k_check_invalid(int64_t nel, int64_t stride, const double *__restrict__ q, const
     if (!finite) code = 1;
     else if (v0 < 0.0) code = 2;
     else if (v4 < 0.0) code = 3;
-    if (code) atomicMin(err, (static_cast<unsigned long long>(old_of_new[i]) << 8) | unsigned(code));
+    if (code) atomicMin(err, err_key(1, old_of_new[i], code));
 }
 
 // residual (validation.cpp:77-89), flat over the 5 padded fields

@@ -293,16 +293,23 @@ int main(int argc, char **argv)
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = mgcfd_run_cycles(solver, conf.num_cycles, rms.data());
     const double total_compute_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for (int i = 0; i < conf.num_cycles; i++) {
+    const bool invalid = rc == MGCFD_ERR_NAN || rc == MGCFD_ERR_NEG_DENSITY || rc == MGCFD_ERR_NEG_ENERGY;
+    int64_t bad_cell = -1;
+    int bad_cycle = -1;
+    if (invalid) mgcfd_invalid_state_location(solver, &bad_cell, &bad_cycle);
+    // (the reference prints a cycle's line when the cycle starts and exits inside the failing time_step)
+    const int printed = invalid && bad_cycle >= 0 ? bad_cycle + 1 : conf.num_cycles;
+    for (int i = 0; i < printed; i++) {
         std::printf(levels <= 1 ? "\nCycle %d / %d" : "\nMG cycle %d / %d", i + 1, conf.num_cycles);
-        std::printf(" (RMS = %.3e)", rms[static_cast<size_t>(i)]);
+        if (!(invalid && i == bad_cycle)) std::printf(" (RMS = %.3e)", rms[static_cast<size_t>(i)]);
     }
     std::printf("\n");
-    if (rc == MGCFD_ERR_NAN || rc == MGCFD_ERR_NEG_DENSITY || rc == MGCFD_ERR_NEG_ENERGY) {
-        // check_for_invalid_variables' messages (src/Kernels/validation.cpp:112-134)
+    if (invalid) {
+        // check_for_invalid_variables' messages (src/Kernels/validation.cpp:112-134); the cell's values at that
+        // moment are not kept on the device
         std::printf(rc == MGCFD_ERR_NAN ? "\nERROR: NaN detected!" :
                     rc == MGCFD_ERR_NEG_DENSITY ? "\nERROR: Negative density detected!" : "\nERROR: Negative density.energy detected!");
-        std::printf("\n");
+        std::printf("\nCell %ld\n", static_cast<long>(bad_cell));
         return EXIT_FAILURE;
     }
     if (rc != MGCFD_OK) return fail("running the cycles");

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -111,6 +112,11 @@ struct mgcfd_solver {
     double ff17[17] = {0};
     unsigned long long *err = nullptr;       // device: packed (cell << 8 | code), ~0 = clean
     int opt_exact = 1, opt_timing = 0, opt_indirect_rw = 0, opt_check = 1, opt_variant = -1, opt_fuse = 1, opt_graph = 0;
+    // check_for_invalid_variables: every checked launch carries its sequence number since the host last read the
+    // error word, so the EARLIEST failing time_step wins, as in the reference (kernels.hip: err_key)
+    int check_seq = 0;
+    int64_t invalid_cell = -1; int invalid_cycle = -1;                     // where the last reported invalid state was found
+    int next_check() { if (!opt_check) return 0; if (check_seq < (1 << 22)) check_seq++; return check_seq; }
     int timing_stride = 8;                  // OPT_TIMING == 2: bracket the flux launches of every Nth sweep
     int64_t sweep_counter = 0;
     bool in_timed_group = false;
@@ -279,7 +285,7 @@ struct mgcfd_solver {
         fs.vin_div = double(MGCFD_RK + 1);
         fs.old_of_new = lv.dp.old_of_new;
         fs.err = err;
-        fs.check = opt_check;
+        fs.check = next_check();
         Timed t(this, l, MGCFD_LOOP_FLUX, true);
         if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs);
         else fast::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs);
@@ -319,8 +325,9 @@ struct mgcfd_solver {
         const double *pm = apply_min == 1 ? lv.partial_min : (apply_min == 2 ? lv.min_dt : nullptr);
         const int n_pm = apply_min == 2 ? 1 : static_cast<int>((lv.info.nel + 255) / 256);
         double *res = with_residual ? lv.residuals : nullptr;
-        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, old, out, lv.dp.old_of_new, err, opt_check, pm, n_pm, lv.volumes, res, lazy_zero ? 0 : 1);
-        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, old, out, lv.dp.old_of_new, err, opt_check, pm, n_pm, lv.volumes, res, lazy_zero ? 0 : 1);
+        const int check = next_check();
+        if (opt_exact) exact::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, old, out, lv.dp.old_of_new, err, check, pm, n_pm, lv.volumes, res, lazy_zero ? 0 : 1);
+        else fast::launch_time_step(stream, lv.info.nel, lv.dp.stride, j, lv.step_factors, lv.fluxes, old, out, lv.dp.old_of_new, err, check, pm, n_pm, lv.volumes, res, lazy_zero ? 0 : 1);
         lv.fluxes_stale = lazy_zero;
         lv.fluxes_zero = true;
         lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
@@ -368,13 +375,18 @@ struct mgcfd_solver {
         F.min_ahead = ahead;
         F.iters[MGCFD_LOOP_PROLONG] += F.info.n_internal + F.info.nel;  // mg_loops.cpp:728,842
     }
-    int read_error(int64_t *bad_cell)
+    // Synchronises.  seq (may be null): the sequence number of the checked launch that found it.
+    int read_error(int64_t *bad_cell, int *seq = nullptr)
     {
         unsigned long long h = 0;
         HIP_CHECK(hipMemcpyAsync(&h, err, sizeof(h), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
+        check_seq = 0;                              // (nothing is in flight: later launches count from 1 again)
         if (h == ~0ULL) return MGCFD_OK;
-        if (bad_cell) *bad_cell = static_cast<int64_t>(h >> 8);
+        invalid_cell = static_cast<int64_t>((h >> 8) & 0xFFFFFFFFULL);
+        invalid_cycle = -1;
+        if (bad_cell) *bad_cell = invalid_cell;
+        if (seq) *seq = static_cast<int>(h >> 40);
         HIP_CHECK(hipMemsetAsync(err, 0xFF, sizeof(unsigned long long), stream));
         switch (h & 0xFF) {
             case 1: return MGCFD_ERR_NAN;
@@ -840,6 +852,13 @@ int mgcfd_calc_rms(mgcfd_solver *s, int level, double *rms)
         *rms = std::sqrt(sum / double(lv.info.nel));
     });
 }
+int mgcfd_invalid_state_location(const mgcfd_solver *s, int64_t *cell, int *cycle)
+{
+    REQUIRE(s);
+    if (cell) *cell = s->invalid_cell;
+    if (cycle) *cycle = s->invalid_cycle;
+    return MGCFD_OK;
+}
 int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_cell)
 {
     REQUIRE(s);
@@ -1115,7 +1134,7 @@ static void cycle_once(mgcfd_solver *s, bool capturing)
 int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
 {
     REQUIRE(s);
-    int code = MGCFD_OK;
+    int code = MGCFD_OK, failed_cycle = -1, seq_before = 0, seq_per_cycle = 0;
     int rc = guarded([&] {
         s->use_device();
         if (!s->rms_ring) {
@@ -1125,6 +1144,7 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
         const size_t nl = s->L.size();
         std::vector<double> sums;
         sums.reserve(static_cast<size_t>(cycles > 0 ? cycles : 0));
+        seq_before = s->check_seq;                  // checked launches of earlier calls nobody has read back yet
         for (int done = 0; done < cycles;) {
             const int chunk = std::min(cycles - done, mgcfd_solver::kRmsRing);
             HIP_CHECK(hipMemsetAsync(s->rms_count, 0, sizeof(int), s->stream));
@@ -1190,21 +1210,43 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
                     }
                 }
             } else {
-                for (int c = 0; c < chunk; c++) cycle_once(s, false);
+                for (int c = 0; c < chunk; c++) {
+                    cycle_once(s, false);
+                    if (c == 0) seq_per_cycle = s->check_seq - seq_before;
+                }
             }
             const size_t at = sums.size();
             sums.resize(at + static_cast<size_t>(chunk));
             HIP_CHECK(hipMemcpyAsync(sums.data() + at, s->rms_ring, sizeof(double) * chunk, hipMemcpyDeviceToHost, s->stream));
-            HIP_CHECK(hipStreamSynchronize(s->stream));
+            int seq = 0;
+            code = s->read_error(nullptr, &seq);                           // synchronises
+            if (code != MGCFD_OK) {
+                // the reference exits inside the failing time_step: stop here, and say in which cycle it was when
+                // the launches were numbered one by one (a replayed graph repeats its numbers)
+                if (seq_per_cycle > 0 && seq > seq_before)
+                    failed_cycle = done + std::min(chunk - 1, (seq - 1 - seq_before) / seq_per_cycle);
+                done += chunk;
+                break;
+            }
             done += chunk;
+            seq_before = 0;
         }
-        code = s->read_error(nullptr);                                     // synchronises
-        if (rms_out)
-            for (int c = 0; c < cycles; c++) rms_out[c] = std::sqrt(sums[static_cast<size_t>(c)] / double(s->L[0].info.nel));
+        if (rms_out) {
+            const double nan = std::numeric_limits<double>::quiet_NaN();
+            for (int c = 0; c < cycles; c++)
+                rms_out[c] = (c < static_cast<int>(sums.size()) && (failed_cycle < 0 || c < failed_cycle))
+                                 ? std::sqrt(sums[static_cast<size_t>(c)] / double(s->L[0].info.nel)) : nan;
+        }
         HIP_CHECK(hipGetLastError());
     });
     if (rc != MGCFD_OK) return rc;
-    if (code != MGCFD_OK) g_last_error = "check_for_invalid_variables: invalid state during the cycles";
+    if (code != MGCFD_OK) {
+        s->invalid_cycle = failed_cycle;
+        g_last_error = std::string("check_for_invalid_variables: ") +
+                       (code == MGCFD_ERR_NAN ? "NaN/Inf" : code == MGCFD_ERR_NEG_DENSITY ? "negative density" : "negative density*energy") +
+                       " at cell " + std::to_string(s->invalid_cell) +
+                       (failed_cycle >= 0 ? " in cycle " + std::to_string(failed_cycle + 1) : std::string(" during the cycles"));
+    }
     return code;
 }
 

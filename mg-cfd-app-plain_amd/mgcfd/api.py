@@ -68,6 +68,7 @@ _SIGNATURES = [
     ("mgcfd_set_option", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mgcfd_level_has_edge_once", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_level_tiling", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
+    ("mgcfd_invalid_state_location", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     ("mgcfd_get_option", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_set_stream", C.c_int, [_vp, _vp]),
     ("mgcfd_synchronize", C.c_int, [_vp]),
@@ -285,6 +286,12 @@ class Solver:
 
     def array_written(self, l: int, name: str):
         self._c(self.lib.mgcfd_array_written(self.handle, l, ARR[name]))
+
+    def invalid_state_location(self):
+        """(original cell id, 0-based cycle or -1) of the last invalid state a run reported."""
+        cell, cycle = C.c_int64(-1), C.c_int(-1)
+        self._c(self.lib.mgcfd_invalid_state_location(self.handle, C.byref(cell), C.byref(cycle)))
+        return cell.value, cycle.value
 
     def tiling(self, l: int) -> dict:
         """How level ``l`` was cut into LDS tiles (mgcfd_level_tiling)."""

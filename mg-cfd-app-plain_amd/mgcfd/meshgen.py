@@ -233,6 +233,25 @@ def make_tet_multigrid(sizes: Sequence[int], mesh_name: str = "m6wing", *, seed:
     return mg
 
 
+def make_hub_level(spokes: int, *, scale: float = 1e-4, seed: int = 0) -> LevelMesh:
+    """One node joined to ``spokes`` others (a row far longer than a tile is wide), one far-field face on the hub,
+    random weights of size ``scale``: non-physical on purpose — with ``mesh_name = fvcorr`` (undamped) and weights
+    above ~1e-4 the state goes negative after a few iterations, which is what the error-path tests need."""
+    rng = np.random.default_rng(seed)
+    nel = spokes + 1
+    w = rng.normal(size=(spokes, 3)) * scale
+    bw = rng.normal(size=(1, 3)) * scale
+    src = np.concatenate([np.zeros(spokes, dtype=np.int64), np.arange(1, nel, dtype=np.int64), [0]])
+    nb = np.concatenate([np.arange(1, nel, dtype=np.int64), np.zeros(spokes, dtype=np.int64), [-2]])
+    ww = np.concatenate([w, -w, bw])
+    order = np.lexsort((np.arange(len(src)), src))
+    counts = np.bincount(src, minlength=nel)
+    ptr = np.zeros(nel + 1, dtype=np.int64)
+    np.cumsum(counts, out=ptr[1:])
+    return LevelMesh(nel=nel, volumes=rng.uniform(1e-6, 2e-6, nel), coords=rng.random((nel, 3)), nbr_ptr=ptr,
+                     nbr_idx=nb[order].copy(), nbr_w=ww[order].copy())
+
+
 def nearest_map(fine: LevelMesh, coarse: LevelMesh) -> np.ndarray:
     from scipy.spatial import cKDTree
     _, idx = cKDTree(coarse.coords).query(fine.coords, k=1)

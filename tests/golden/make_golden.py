@@ -41,6 +41,10 @@ CASES = {
     "fvcorr_1lvl_legacy_ordering": ((8,), "fvcorr", dict(seed=8, cavity_radius=0.01, volume_noise=0.02), 30, 1),
     # unstructured: Delaunay tetrahedra with median-dual metrics (sizes = node counts), degrees 4..30, wall + far-field hull faces
     "tet_2lvl": ((420, 90), "rotor37", dict(seed=4, tet=True), 4, 1),
+    # runs that the reference ABORTS (check_for_invalid_variables, validation.cpp:107-138): a 300-spoke hub with
+    # non-physical weights, undamped; only the binary's stdout (cycle lines, ERROR line, first "Cell" line) and exit code
+    "fvcorr_hub_nan": ((300,), "fvcorr", dict(seed=5, hub=1.2e-4), 40, 1),                   # NaN in cycle 7
+    "fvcorr_hub_negative_energy": ((300,), "fvcorr", dict(seed=5, hub=1e-4), 40, 1),         # density*energy < 0 in cycle 32
 }
 
 
@@ -147,14 +151,28 @@ def main():
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(os.path.join(d, "input"))
         kw = dict(kw)
-        mg = (meshgen.make_tet_multigrid if kw.pop("tet", False) else meshgen.make_multigrid)(sizes, mesh_name, **kw)
+        hub = kw.pop("hub", None)
+        if hub is not None:
+            mg = meshgen.MultigridMesh(mesh_name=mesh_name)
+            mg.levels.append(meshgen.make_hub_level(sizes[0], scale=hub, **kw))
+        else:
+            mg = (meshgen.make_tet_multigrid if kw.pop("tet", False) else meshgen.make_multigrid)(sizes, mesh_name, **kw)
         meshgen.write_input(mg, os.path.join(d, "input"))
         out_dir = os.path.join(d, "_out")
         os.makedirs(out_dir)
         legacy = name.endswith("legacy_ordering")
         cmd = [O.REF_BIN_LEGACY if legacy else O.REF_BIN, "-i", "input.dat", "-d", os.path.join(d, "input"), "-o", out_dir + "/", "-g", str(cycles),
                "-m", str(dup), "--output-variables"]
-        r = subprocess.run(cmd, capture_output=True, text=True, env=env, check=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, check=hub is None)
+        if hub is not None:
+            assert r.returncode != 0, "this case is meant to be aborted by check_for_invalid_variables"
+            with open(os.path.join(d, "stdout.txt"), "w") as f:
+                f.write("\n".join(l for l in r.stdout.splitlines() if "cycle" in l.lower() or "ERROR" in l or l.startswith("Cell")) + "\n")
+            with open(os.path.join(d, "case.txt"), "w") as f:
+                f.write(f"cycles = {cycles}\nduplicate = {dup}\nmesh_name = {mesh_name}\nreturncode = {r.returncode}\n")
+            shutil.rmtree(out_dir)
+            print(f"{name}: aborted by the reference with exit code {r.returncode}")
+            continue
         shutil.copy(os.path.join(out_dir, f"variables.size={dup}x.cycles={cycles}.level=0"), os.path.join(d, "variables.level0.txt"))
         shutil.copy(os.path.join(out_dir, "LoopNumIters.csv"), os.path.join(d, "LoopNumIters.csv"))
         with open(os.path.join(d, "stdout.txt"), "w") as f:

@@ -418,6 +418,50 @@ def test_degenerate_levels(oracle, name, nel, internal, faces):
     s.close()
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_run_that_blows_up_reports_the_references_first_bad_cell(oracle, fuse):
+    """check_for_invalid_variables (validation.cpp:107-138) runs after every time_step and exits at the first bad
+    cell in original order.  An undamped hub with large weights goes negative after a few iterations: the library
+    must return the same error class, name the same cell and the same cycle, and leave NaN in rms_out afterwards."""
+    import mgcfd
+    levels = [_hand_level(301, [(0, k) for k in range(1, 301)], [(-2, 0)], seed=5, scale=1.2e-4)]       # goes negative in cycle 7
+    cycles = 12
+    # the oracle stops inside the failing time_step and leaves the state as it was then
+    lib = oracle.load()
+    first_bad = None
+    for c in range(1, cycles + 1):
+        try:
+            _oracle_solve_arrays(oracle, levels, 0, c)
+        except AssertionError:
+            first_bad = c - 1
+            break
+    assert first_bad is not None and first_bad >= 1, "the case must fail, and not in the very first cycle"
+    n = len(levels)
+    lv = (oracle.OraLevel * n)()
+    L = levels[0]
+    vol, coords, edges = (np.ascontiguousarray(L[k]).copy() for k in ("volumes", "coords", "edges"))
+    state = [np.zeros((L["nel"], 5)) for _ in range(4)] + [np.zeros(L["nel"])]
+    lv[0].nel, lv[0].n_edges, lv[0].n_internal, lv[0].n_boundary, lv[0].n_wall = L["nel"], len(edges), L["n_internal"], L["n_boundary"], L["n_wall"]
+    lv[0].internal_start, lv[0].boundary_start, lv[0].wall_start = 0, L["n_internal"], L["n_internal"] + L["n_boundary"]
+    lv[0].volumes, lv[0].coords, lv[0].edges = oracle.ptr(vol), oracle.ptr(coords), oracle.ptr(edges)
+    lv[0].variables, lv[0].old_variables, lv[0].residuals, lv[0].fluxes = (oracle.ptr(a) for a in state[:4])
+    lv[0].step_factors = oracle.ptr(state[4])
+    rms = np.zeros(cycles)
+    want_code = lib.ora_solve(lv, 1, 0, cycles, 0, oracle.ptr(rms), None)
+    assert want_code in (1, 2, 3)
+    bad = C.c_int64(-1)
+    assert lib.ora_check_for_invalid_variables(oracle.ptr(state[0]), L["nel"], C.byref(bad)) == want_code
+    s = mgcfd.Solver.from_arrays(levels, 0)
+    s.set_option("fuse_update", fuse)
+    out = np.zeros(cycles)
+    rc = s.lib.mgcfd_run_cycles(s.handle, cycles, out.ctypes.data_as(C.c_void_p))
+    assert rc == {1: 4, 2: 5, 3: 6}[want_code]                  # MGCFD_ERR_NAN / NEG_DENSITY / NEG_ENERGY
+    assert s.invalid_state_location() == (bad.value, first_bad)
+    assert np.isfinite(out[:first_bad]).all() and np.isnan(out[first_bad:]).all()
+    assert f"at cell {bad.value} in cycle {first_bad + 1}" in s.lib.mgcfd_last_error().decode()
+    s.close()
+
+
 def test_tiling_report_and_coordinate_box_fallback():
     """mgcfd_level_tiling: a lattice level keeps the greedy clusters (no halo node left outside the LDS tile); on a
     tetrahedral level those overflow, coordinate boxes are chosen instead, and few row entries are left to gather
@@ -538,6 +582,24 @@ def test_driver_reproduces_reference_binary(case, mode, tmp_path):
     assert list(t.keys())[:18] == list(want.keys())[:18] and "Total" in t
     if mode == "timers":
         assert float(t["flux0"]) > 0 and float(t["time_step0"]) > 0 and float(t["compute_step0"]) > 0
+
+
+@pytest.mark.parametrize("case", ["fvcorr_hub_nan", "fvcorr_hub_negative_energy"])
+@pytest.mark.parametrize("extra", [[], ["--no-timers"]])
+def test_driver_aborts_like_the_reference_binary(case, extra, tmp_path):
+    """Runs the reference aborted in check_for_invalid_variables (golden stdout of the real binary): same cycle
+    lines (the failing cycle's without an RMS), same ERROR line, same first bad cell, non-zero exit code."""
+    d, cycles, _ = _case(case)
+    want = [l.rstrip("\n") for l in open(os.path.join(d, "stdout.txt"))]
+    exe = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
+    r = subprocess.run([exe, "-i", "input.dat", "-d", os.path.join(d, "input"), "-o", str(tmp_path) + "/", "-g", str(cycles)] + extra,
+                       capture_output=True, text=True)
+    assert r.returncode == 1
+    got = [l for l in r.stdout.splitlines() if l.startswith("Cycle") or l.startswith("ERROR") or l.startswith("Cell")]
+    k = next(i for i, l in enumerate(want) if l.startswith("ERROR"))
+    assert got[:k + 1] == want[:k + 1]                                 # cycle lines with their RMS values, ERROR line
+    assert len(got) == k + 2 and want[k + 1].startswith(got[k + 1] + ":")   # "Cell 0" (the reference adds the cell's values)
+    assert "Total runtime" not in r.stdout
 
 
 def test_driver_legacy_ordering_reproduces_reference_built_with_that_flag(tmp_path):

@@ -31,7 +31,7 @@ struct Config {                       // the reference's `config` (src/Base/conf
     bool output_variables = false, output_old_variables = false, output_step_factors = false,
          output_edge_fluxes = false, output_fluxes = false, output_volumes = false;
     // extensions (not in the reference)
-    bool timers = true;               // --no-timers: fused, graph-replayed fast path; Times.csv holds only Total
+    bool timers = true;               // --no-timers: fused fast path (one launch per Runge-Kutta stage); Times.csv holds only Total
     bool fast_math = false;           // --fast: allow FMA contraction (MGCFD_OPT_EXACT = 0)
     bool indirect_rw = true;          // the reference runs the probe every RK stage; --no-indirect-rw skips it
     bool legacy_ordering = false;     // --legacy-ordering: the reference's -DLEGACY_ORDERING edge sort (a compile-time flag there)
@@ -111,7 +111,7 @@ void print_help()
         "  --output-step-factors            Write step factors to file\n\n"
         "GPU ARGUMENTS (extensions)\n"
         "  --device=INT                     GPU to run on (default 0)\n"
-        "  --no-timers                      Fused, graph-replayed kernels; no per-loop times\n"
+        "  --no-timers                      One fused launch per Runge-Kutta stage; no per-loop times\n"
         "  --no-indirect-rw                 Skip the indirect_rw bandwidth probe each RK stage\n"
         "  --fast                           Allow FMA contraction (results within 1e-12 relative)\n"
         "  --legacy-ordering                Sort edges by (a,b,x,y,z) like the reference built with -DLEGACY_ORDERING\n");

@@ -163,8 +163,11 @@ int mgcfd_level_has_edge_once(const mgcfd_solver *s, int level, int *yes);
  * out[0] tiles of 256 nodes, out[1] halo nodes of all tiles together, out[2] the largest halo, out[3] halo nodes a
  * tile can stage in LDS, out[4] incidence-row entries that refer to a halo node beyond that (each a gather from
  * HBM), out[5] incidence-row entries of internal edges (two per edge), out[6] padding entries among them,
- * out[7] 1 when the nodes were ordered by coordinate boxes instead of greedy clusters. */
-int mgcfd_level_tiling(const mgcfd_solver *s, int level, int64_t out[8]);
+ * out[7] 1 when the nodes were ordered by coordinate boxes instead of greedy clusters, out[8] internal-edge entries
+ * handed to the workgroups' lists instead of the per-node loops (long rows: entries beyond a tile's row limit, and
+ * every entry from a node's first out[4]-kind entry on — so with out[8] > 0 none of out[4] is gathered inside a loop),
+ * out[9] rows the per-node loops walk, summed over the 64-node slices. */
+int mgcfd_level_tiling(const mgcfd_solver *s, int level, int64_t out[10]);
 int mgcfd_get_option(const mgcfd_solver *s, int option, int *value);
 /* Run all subsequent work of this solver on an existing HIP stream (hipStream_t as void*), e.g.
  * the cuda_stream of a torch.cuda.Stream() made current with torch.cuda.set_stream(): collectives

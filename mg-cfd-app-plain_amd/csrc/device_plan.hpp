@@ -46,6 +46,15 @@ struct FusedStep {
     double *next_legacy_sf = nullptr;         // mesh_name = fvcorr: next sweep's step factors 0.5/(sqrt(vol)*(|v|+c)) (cfd_loops.cpp:37-61) go here
 };
 
+// Long rows (preprocess.hpp: LevelPlan::tail_*): device arrays of the entries the per-node loop leaves to the workgroup.
+struct TailPlan {
+    const int32_t *rows_main = nullptr;   // [n_slices] internal rows the per-node loop walks
+    const int32_t *tile_ptr = nullptr;    // [n_tiles+1]
+    const double2 *rec = nullptr;         // [total][3]: fx fy | fz k | (owner slot | code << 16) -
+    const int32_t *begin = nullptr, *count = nullptr;   // [stride] a node's entries
+    double2 *flux = nullptr;              // scratch [total][3]: the entry's five flux terms (48-byte records)
+};
+
 // Device pointers of one level's gather plan.
 struct DevicePlan {
     int64_t nel = 0;
@@ -65,6 +74,8 @@ struct DevicePlan {
     int32_t *te_chunk_ptr = nullptr, *te_count = nullptr;
     uint16_t *te_slots = nullptr, *gat16 = nullptr;
     double *te_w = nullptr;
+    int has_tail = 0;                   // long rows: some tile leaves entries to its workgroup (k_flux_tile<..., TAIL>)
+    TailPlan tail;
     // two-phase ("fission") design point: per-edge arrays, edge-flux scratch [5][n_edges_pad], rows' edge references
     int64_t n_edges = 0, n_edges_pad = 0;
     int32_t *fe_ab = nullptr, *row_edge = nullptr;

@@ -492,7 +492,9 @@ __device__ __forceinline__ void boundary_rows(const NodeQ &me, const FluxC &fm, 
 
 // ROLE (fused stages only): 0 = may finish compute_step_factor (first stage), 2 = may write the residual, its
 // squares and the look-ahead (last stage), 1 = neither: the paths a stage cannot take are compiled out.
-template <int MINW, bool LOADK, bool FUSE, bool ACC, int ROLE>
+// TAIL: the level has long rows (TailPlan): the per-node loop stops at the tile's row limit and the workgroup
+// evaluates the remaining entries together (see below).
+template <int MINW, bool LOADK, bool FUSE, bool ACC, int ROLE, bool TAIL>
 __global__ void __launch_bounds__(kBlock, MINW)
 k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at wave launch (Makefile:
             // -amdgpu-kernarg-preload-count): what the first loads of the prologue need comes first
@@ -501,7 +503,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
             const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
             const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
-            double *__restrict__ fluxes, int classes, FusedStep fs)
+            double *__restrict__ fluxes, int classes, FusedStep fs, TailPlan tp)
 {
     __shared__ double2 tile[kTileCap * kLdsRecD2];
 
@@ -531,7 +533,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     const int32_t hid = hrow[tid];                                     // -1: no halo node for this thread
     const int32_t hid2 = (ROLE != 5 && tid < kHaloStride - kBlock) ? hrow[kBlock + tid] : -1;   // halo larger than the workgroup (rare)
     const int32_t row0 = slice_row0[slice];
-    const int32_t n_int = (classes & 1) ? rows_int[slice] : 0;
+    const int32_t n_int = (classes & 1) ? (TAIL ? tp.rows_main : rows_int)[slice] : 0;
     const int32_t n_bnd = rows_bnd[slice];
     const bool has_halo = hid >= 0;
     const int64_t hnode = has_halo ? int64_t(hid) : i;
@@ -624,6 +626,8 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     // The row pair's work (rows e0, e1 -> a0..a4, strictly in row order = the reference's summation order).
     // ELL padding carries zero weights, so on a sum that started at +0.0 its +-0.0 contribution changes no
     // bit (x + y = -0.0 only if both are); a sum read from memory (ACC) may be -0.0 and skips padding.
+    // With long rows (TAIL) an entry the plan moved to the workgroup's list is blanked in nbr16 only (its weights stay,
+    // other kernels read them), so there too a padding code skips the add.
     // Halo nodes beyond the LDS tile (ragged clusters) are read from HBM.
 #define MGCFD_ROW_PAIR()                                                                                     \
     do {                                                                                                     \
@@ -631,7 +635,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             const bool v0 = s0 != kT16Pad, v1 = s1 != kT16Pad;                                               \
             const bool o0 = v0 && s0 >= uint32_t(kTileCap), o1 = v1 && s1 >= uint32_t(kTileCap);             \
             NodeQ n0, n1;                                                                                    \
-            if (__builtin_expect(__any(o0 || o1), 0)) {                                                      \
+            if (!TAIL && __builtin_expect(__any(o0 || o1), 0)) {      /* (long rows: such entries are on the list) */ \
                 n0 = o0 ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s0) - kTileCap])                \
                         : lds_load_record(tile, v0 ? s0 : uint32_t(tid));                                    \
                 n1 = o1 ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s1) - kTileCap])                \
@@ -643,7 +647,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             Flux5 f0, f1;                                                                                    \
             f0 = edge_flux<LOADK>(me, fm_pre, n0, e0);                                                       \
             f1 = edge_flux<LOADK>(me, fm_pre, n1, e1);                                                       \
-            if (ACC) {                                                                                       \
+            if (ACC || TAIL) {                                                                               \
                 a0 = v0 ? a0 + f0.d : a0;   a1 = v0 ? a1 + f0.mx : a1;   a2 = v0 ? a2 + f0.my : a2;          \
                 a3 = v0 ? a3 + f0.mz : a3;  a4 = v0 ? a4 + f0.en : a4;                                       \
                 a0 = v1 ? a0 + f1.d : a0;   a1 = v1 ? a1 + f1.mx : a1;   a2 = v1 ? a2 + f1.my : a2;          \
@@ -673,6 +677,60 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         if (r < n_int) MGCFD_ROW_PAIR();
     }
 #undef MGCFD_ROW_PAIR
+
+    if (TAIL && (classes & 1)) {
+        // Long rows.  The entries beyond the tile's row limit, one per thread whatever node they belong to: the same
+        // edge_flux from the same operands (the owner's record is read back from LDS), results to a global scratch;
+        // then every owner adds its own entries in row order — the accumulation order is untouched, only the
+        // evaluation is spread over the workgroup instead of waiting for the highest-degree lanes.
+        const int32_t tb = tp.tile_ptr[t], te = tp.tile_ptr[t + 1];        // (uniform)
+        if (te > tb) {
+            // (requested before the evaluation rounds, used after them)
+            const int32_t nb = tp.begin[i], nc = tp.count[i];
+            int32_t e = tb + tid;
+            double2 r0 = make_double2(0.0, 0.0), r1 = r0, r2 = r0;
+            if (e < te) { r0 = tp.rec[3 * int64_t(e)]; r1 = tp.rec[3 * int64_t(e) + 1]; r2 = tp.rec[3 * int64_t(e) + 2]; }
+            while (e < te) {
+                const double2 c0 = r0, c1 = r1, c2 = r2;
+                const int32_t en = e + kBlock;
+                if (en < te) { r0 = tp.rec[3 * int64_t(en)]; r1 = tp.rec[3 * int64_t(en) + 1]; r2 = tp.rec[3 * int64_t(en) + 2]; }   // next round's entry
+                const uint32_t word = static_cast<uint32_t>(__double_as_longlong(c2.x));
+                const uint32_t own = word & 0xFFFFu;
+                if (own != kT16Pad) {
+                    EdgeRow er;
+                    er.code = word >> 16;
+                    er.fx = c0.x; er.fy = c0.y; er.fz = c1.x; er.k = LOADK ? c1.y : 0.0;
+                    const uint32_t s = er.code & kT16SlotMask;
+                    const NodeQ mo = lds_load_record(tile, own);
+                    const NodeQ ot = s >= uint32_t(kTileCap) ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s) - kTileCap])
+                                                             : lds_load_record(tile, s);
+                    const Flux5 f = edge_flux<LOADK>(mo, flux_contribution(mo), ot, er);
+                    double2 *out = tp.flux + 3 * int64_t(e);
+                    out[0] = make_double2(f.d, f.mx); out[1] = make_double2(f.my, f.mz); out[2] = make_double2(f.en, 0.0);
+                }
+                e = en;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's scratch stores have left
+            __syncthreads();
+            // (a tile's scratch range is whole 128-byte lines that only this workgroup touches, and it reads them
+            //  only now: no stale copy can sit in this CU's L1)
+            // ordered adds, the records fetched three entries ahead of the sums that consume them
+            const double2 *in = tp.flux + 3 * int64_t(nb);
+            int32_t k = 0;
+            for (; k + 3 <= nc; k += 3) {
+                const double2 u0 = in[0], u1 = in[1], u2 = in[2], v0 = in[3], v1 = in[4], v2 = in[5], w0 = in[6], w1 = in[7], w2 = in[8];
+                in += 9;
+                a0 += u0.x; a1 += u0.y; a2 += u1.x; a3 += u1.y; a4 += u2.x;
+                a0 += v0.x; a1 += v0.y; a2 += v1.x; a3 += v1.y; a4 += v2.x;
+                a0 += w0.x; a1 += w0.y; a2 += w1.x; a3 += w1.y; a4 += w2.x;
+            }
+            for (; k < nc; k++) {
+                const double2 u0 = in[0], u1 = in[1], u2 = in[2];
+                in += 3;
+                a0 += u0.x; a1 += u0.y; a2 += u1.x; a3 += u1.y; a4 += u2.x;
+            }
+        }
+    }
 
     if ((classes & 6) && n_bnd > 0) {
         // The reference runs ALL solid-wall faces, then ALL far-field faces; the plan lists a
@@ -1457,10 +1515,14 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     FusedStep fs{};
     if (fused) fs = *fused;
     // 3 tiles of 52.5 KiB LDS fit a CU => at least 3 waves per SIMD wanted
-#define MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, ROLE)                                                            \
-    hipLaunchKernelGGL((k_flux_tile<3, LOADK, FUSE, ACC, ROLE>), grid, block, 0, st, q, p.tile_halo,           \
+#define MGCFD_TILE_LAUNCH_T(LOADK, FUSE, ACC, ROLE, TAIL)                                                      \
+    hipLaunchKernelGGL((k_flux_tile<3, LOADK, FUSE, ACC, ROLE, TAIL>), grid, block, 0, st, q, p.tile_halo,     \
                        uint32_t(p.n_tiles), p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.rows_bnd,  \
-                       p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs)
+                       p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs, p.tail)
+    // levels with long rows (tetrahedral meshes, hubs) run the instantiation that hands them to the workgroup
+    const bool tail = p.has_tail && (classes & 1);
+#define MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, ROLE)                                                            \
+    do { if (tail) MGCFD_TILE_LAUNCH_T(LOADK, FUSE, ACC, ROLE, true); else MGCFD_TILE_LAUNCH_T(LOADK, FUSE, ACC, ROLE, false); } while (0)
     // fused stages: the role decides which optional paths exist in the launched kernel
     const int role = !fused ? 1 : (fs.vin_flux ? 5 : fs.partial_min ? 0 : (fs.next_partial_min ? 3 : (fs.next_legacy_sf ? 4 : (fs.residuals ? 2 : 1))));
 #define MGCFD_TILE_LAUNCH(LOADK, FUSE, ACC)                                                                    \
@@ -1513,6 +1575,7 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     }
 #undef MGCFD_TILE_LAUNCH
 #undef MGCFD_TILE_LAUNCH_R
+#undef MGCFD_TILE_LAUNCH_T
 }
 
 void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, double *fluxes)

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <deque>
 #include <queue>
@@ -534,6 +536,82 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             if (entry_edge[e] >= 0)
                 P.row_edge[e] = static_cast<int32_t>(static_cast<uint32_t>(entry_edge[e]) | ((P.nbr[e] & kRoleB) ? 0x80000000u : 0u));
     }
+    // ---- long rows: per tile, the row limit that minimises the estimated time of its workgroup ----
+    // Units: one pair of rows of the per-node loop = 1.  The four waves walk their slices side by side, so the loop
+    // costs the longest slice; the workgroup's list costs a fixed part (barrier, scratch round trip), a part per round
+    // of 256 entries and a part per entry of the longest per-node run of ordered adds.
+    P.rows_main = P.rows_int;
+    P.tail_tile_ptr.assign(static_cast<size_t>(P.n_tiles) + 1, 0);
+    P.tail_begin.assign(static_cast<size_t>(nel), 0);
+    P.tail_count.assign(static_cast<size_t>(nel), 0);
+    P.tail_rec.clear();
+    P.has_tail = false;
+    auto push_tail = [&](const EdgeW &w, uint32_t owner, uint32_t code) {
+        const uint64_t word = uint64_t(owner) | (uint64_t(code) << 16);
+        double as_double;
+        std::memcpy(&as_double, &word, sizeof(as_double));
+        const double rec[6] = {w.x, w.y, w.z, w.k, as_double, 0.0};
+        P.tail_rec.insert(P.tail_rec.end(), rec, rec + 6);
+    };
+    // fitted on a tetrahedral level (tools/tet_mesh_bench.py): a round of the list costs about two row pairs of the
+    // loop (single entries, the owner's record and flux terms fetched again, a trip through the scratch)
+    const double c_fixed = 2.5, c_round = 2.0, c_add = 0.1;
+    if (opt.long_rows) {
+        for (int32_t t = 0; t < P.n_tiles; t++) {
+            const int32_t base = t * kTile, s0 = t * (kTile / kSlice);
+            const int32_t n_here = static_cast<int32_t>(std::min<int64_t>(kTile, nel - base));
+            int32_t deg[kTile], max_deg = 0;
+            for (int32_t k = 0; k < n_here; k++) { deg[k] = rows_of(order[static_cast<size_t>(base + k)]); max_deg = std::max(max_deg, deg[k]); }
+            auto cost = [&](int32_t T) {
+                int64_t tail = 0;
+                for (int32_t k = 0; k < n_here; k++) tail += std::max(0, deg[k] - T);
+                int32_t longest = 0;
+                for (int32_t q = 0; q < kTile / kSlice; q++) longest = std::max(longest, std::min(T, P.rows_int[static_cast<size_t>(s0 + q)]));
+                return double((longest + 1) / 2) +
+                       (tail > 0 ? c_fixed + c_round * double((tail + kTile - 1) / kTile) + c_add * double(max_deg - T) : 0.0);
+            };
+            int32_t best_T = max_deg;
+            double best = cost(max_deg);
+            for (int32_t T = 2; T < max_deg; T += 2) {
+                const double c = cost(T);
+                if (c < best - 0.5) { best = c; best_T = T; }          // (only for a clear gain)
+            }
+            P.tail_tile_ptr[static_cast<size_t>(t)] = static_cast<int32_t>(P.tail_rec.size() / 6);
+            // A node's own cut: the tile's row limit, or the first entry whose neighbour did not fit the LDS tile —
+            // in the per-node loop such an entry is a gather from HBM that the whole wave waits for; in the
+            // workgroup's list it is one of many loads in flight.  Everything from the cut on goes to the list
+            // (the order of the node's sum is kept: loop rows first, then its list entries in row order).
+            int32_t cut[kTile];
+            bool any = false;
+            for (int32_t k = 0; k < n_here; k++) {
+                cut[k] = std::min(best_T, deg[k]);
+                for (int32_t r = 0; r < cut[k]; r++)
+                    if ((P.nbr16[static_cast<size_t>(entry_index(base + k, r))] & kT16SlotMask) >= uint32_t(kTileCap)) { cut[k] = r; break; }
+                any = any || cut[k] < deg[k];
+            }
+            if (any) {
+                P.has_tail = true;
+                for (int32_t q = 0; q < kTile / kSlice; q++) P.rows_main[static_cast<size_t>(s0 + q)] = 0;
+                for (int32_t k = 0; k < n_here; k++) {
+                    int32_t &rm = P.rows_main[static_cast<size_t>(s0 + k / kSlice)];
+                    rm = std::max(rm, cut[k]);
+                    P.tail_begin[static_cast<size_t>(base + k)] = static_cast<int32_t>(P.tail_rec.size() / 6);
+                    P.tail_count[static_cast<size_t>(base + k)] = deg[k] - cut[k];
+                    for (int32_t r = cut[k]; r < deg[k]; r++) {
+                        const int64_t e = entry_index(base + k, r);
+                        push_tail(P.w[static_cast<size_t>(e)], static_cast<uint32_t>(k), P.nbr16[static_cast<size_t>(e)]);
+                        P.nbr16[static_cast<size_t>(e)] = static_cast<uint16_t>(kT16Pad);      // (the weights stay: indirect_rw reads them)
+                    }
+                }
+                while ((P.tail_rec.size() / 6) % 8)                     // whole 128-byte lines of the scratch per tile (8 x 48 B = 3 lines)
+                    push_tail(EdgeW{0.0, 0.0, 0.0, 0.0}, kT16Pad, kT16Pad);
+            }
+        }
+    }
+    P.tail_tile_ptr[static_cast<size_t>(P.n_tiles)] = static_cast<int32_t>(P.tail_rec.size() / 6);
+    P.tail_total = static_cast<int64_t>(P.tail_rec.size() / 6);
+    if (!P.has_tail) { P.tail_begin.clear(); P.tail_count.clear(); }
+
     P.n_internal_entries = useful;
     int64_t int_slots = 0;
     for (int32_t s = 0; s < P.n_slices; s++) int_slots += static_cast<int64_t>(P.rows_int[static_cast<size_t>(s)]) * kSlice;

@@ -85,6 +85,18 @@ struct LevelPlan {
     std::vector<double> te_w;             // [chunk][4][256] a-side weights: -0.5*e (x,y,z) and k = -|e|*smoothing*0.5
     std::vector<uint16_t> gat16;          // [rows*64] internal rows: position p of the entry's edge in its tile's list
                                           //   | kT16RoleB when this node is the edge's b end (it gets -F); kT16Pad
+    // ---- long rows: a node's internal entries beyond its tile's row limit.  The per-node loop stops at the limit;
+    //      the whole workgroup then evaluates the remaining entries one per thread, leaves the five results in a
+    //      global scratch, and every owner adds its own in row order — the summation order is unchanged, but the
+    //      workgroup no longer waits for its highest-degree wave (tetrahedral meshes, hubs) ----
+    bool has_tail = false;
+    std::vector<int32_t> rows_main;       // [n_slices] internal rows the per-node loop walks (<= rows_int)
+    std::vector<int32_t> tail_tile_ptr;   // [n_tiles+1] a tile's range in the tail arrays (multiples of 16 entries)
+    std::vector<double> tail_rec;         // [tail_total][6]: the entry's weights fx, fy, fz, k (as w), then one word
+                                          //   holding (tile-local slot of the owning node) | (neighbour code as nbr16) << 16
+                                          //   — owner kT16Pad = padding —, then padding to 48 bytes (three 16-byte loads)
+    std::vector<int32_t> tail_begin, tail_count;   // [nel] a node's entries: contiguous, in row order
+    int64_t tail_total = 0;
     // ---- two-phase ("fission") design point: edge fluxes to memory, then a node-centred sum ----
     std::vector<int32_t> fe_ab;           // [2][n_internal] end points (new ids) of every internal edge, original order
     std::vector<double> fe_w;             // [4][n_internal] a-side weights -0.5*e (x,y,z) and k
@@ -120,6 +132,7 @@ struct PlanOptions {
     int ordering = 2;
     bool degree_sort = true;           // inside each tile, sort nodes by degree (less ELL padding per slice)
     int64_t n_owned = -1;              // -1: every node is owned
+    bool long_rows = true;             // cut rows at a per-tile limit and evaluate the rest workgroup-wide (LevelPlan::tail_*)
 };
 
 // `edges` are the level's final edge weights (after adjust/dampen).  coarse_new_of_old is

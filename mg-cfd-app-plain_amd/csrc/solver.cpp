@@ -411,7 +411,10 @@ mgcfd_solver::~mgcfd_solver()
                         lv.cbrt_vol, lv.min_dt, lv.partial_min, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.child4, lv.dp.pro_w, lv.dp.pro_p, lv.dp.pro_tile_n, lv.dp.pro_tile_ids, lv.dp.pro_s16, lv.dp.pro_own16,
                         lv.dp.pro_parent, lv.dp.pro_wsum, lv.dp.te_chunk_ptr, lv.dp.te_count, lv.dp.te_slots, lv.dp.te_w,
-                        lv.dp.gat16, lv.dp.fe_ab, lv.dp.fe_w, lv.dp.row_edge, lv.dp.edge_flux};
+                        lv.dp.gat16, lv.dp.fe_ab, lv.dp.fe_w, lv.dp.row_edge, lv.dp.edge_flux,
+                        const_cast<int32_t *>(lv.dp.tail.rows_main), const_cast<int32_t *>(lv.dp.tail.tile_ptr),
+                        const_cast<double2 *>(lv.dp.tail.rec), const_cast<int32_t *>(lv.dp.tail.begin),
+                        const_cast<int32_t *>(lv.dp.tail.count), lv.dp.tail.flux};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         for (auto &hp : lv.halo_plans) if (hp.first) (void)hipFree(hp.first);
     }
@@ -468,12 +471,20 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
             lv.n_owned = n_owned[l];
             popt.n_owned = n_owned[l];
         }
+        popt.long_rows = !std::getenv("MGCFD_NO_LONG_ROWS");      // (diagnostic: per-node rows only, overflow entries gathered in the loop)
         build_level_plan(d, lv.edges, popt, lv.plan);
         if (std::getenv("MGCFD_VERBOSE"))
             std::fprintf(stderr, "[mgcfd] level %d: %ld nodes, %d tiles, halo mean %.0f max %d (cap %d), overflow refs %ld, ELL padding %.1f%%, tile edges mean %.0f max %d (edge-once %s)\n",
                          l, (long)d.nel, lv.plan.n_tiles, lv.plan.halo_mean, lv.plan.halo_max, kTileCap - kTile,
                          (long)lv.plan.halo_overflow_refs, 100.0 * lv.plan.pad_fraction, lv.plan.te_mean, lv.plan.te_max,
                          lv.plan.edge_once ? "yes" : "no");
+        if (std::getenv("MGCFD_VERBOSE") && lv.plan.has_tail) {
+            int64_t rows_full = 0, rows_cut = 0;
+            for (size_t q = 0; q < lv.plan.rows_int.size(); q++) { rows_full += lv.plan.rows_int[q]; rows_cut += lv.plan.rows_main[q]; }
+            std::fprintf(stderr, "[mgcfd] level %d: long rows: %ld entries left to the workgroups (%.1f per tile), per-node loop %.1f -> %.1f rows per slice\n",
+                         l, (long)lv.plan.tail_total, double(lv.plan.tail_total) / lv.plan.n_tiles,
+                         double(rows_full) / double(lv.plan.rows_int.size()), double(rows_cut) / double(lv.plan.rows_int.size()));
+        }
     }
     for (int l = 0; l + 1 < nlevels; l++) {
         const mgcfd_level_desc &d = levels[l];
@@ -561,6 +572,17 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.plan.fe_ab.clear(); lv.plan.fe_ab.shrink_to_fit();
         lv.plan.fe_w.clear(); lv.plan.fe_w.shrink_to_fit();
         lv.plan.row_edge.clear(); lv.plan.row_edge.shrink_to_fit();
+        lv.dp.has_tail = P.has_tail ? 1 : 0;
+        if (lv.dp.has_tail) {
+            lv.dp.tail.rows_main = dev_upload(P.rows_main);
+            lv.dp.tail.tile_ptr = dev_upload(P.tail_tile_ptr);
+            lv.dp.tail.rec = reinterpret_cast<const double2 *>(dev_upload(P.tail_rec));
+            lv.plan.tail_begin.resize(static_cast<size_t>(lv.dp.stride), 0);         // (threads past nel read these too)
+            lv.plan.tail_count.resize(static_cast<size_t>(lv.dp.stride), 0);
+            lv.dp.tail.begin = dev_upload(P.tail_begin);
+            lv.dp.tail.count = dev_upload(P.tail_count);
+            lv.dp.tail.flux = reinterpret_cast<double2 *>(dev_alloc<double>(static_cast<size_t>(6 * P.tail_total)));
+        }
         lv.dp.vin_ok = (P.halo_overflow_refs == 0 && P.halo_max <= kTile) ? 1 : 0;
         lv.dp.edge_once = (P.edge_once && !std::getenv("MGCFD_NO_EDGE_ONCE")) ? 1 : 0;
         if (lv.dp.edge_once) {
@@ -754,7 +776,7 @@ int mgcfd_level_has_edge_once(const mgcfd_solver *s, int level, int *yes)
     *yes = s->L[static_cast<size_t>(level)].dp.edge_once;
     return MGCFD_OK;
 }
-int mgcfd_level_tiling(const mgcfd_solver *s, int level, int64_t out[8])
+int mgcfd_level_tiling(const mgcfd_solver *s, int level, int64_t out[10])
 {
     REQUIRE(s); REQUIRE(out);
     if (level < 0 || level >= static_cast<int>(s->L.size())) { g_last_error = "level out of range"; return MGCFD_ERR_ARG; }
@@ -767,6 +789,9 @@ int mgcfd_level_tiling(const mgcfd_solver *s, int level, int64_t out[8])
     out[5] = P.n_internal_entries;
     out[6] = P.pad_entries;
     out[7] = P.ordered_by_boxes ? 1 : 0;
+    out[8] = P.has_tail ? P.tail_total : 0;
+    out[9] = 0;
+    for (int32_t r : P.rows_main) out[9] += r;
     return MGCFD_OK;
 }
 int mgcfd_get_option(const mgcfd_solver *s, int option, int *value)

@@ -295,9 +295,10 @@ class Solver:
 
     def tiling(self, l: int) -> dict:
         """How level ``l`` was cut into LDS tiles (mgcfd_level_tiling)."""
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 10)()
         self._c(self.lib.mgcfd_level_tiling(self.handle, l, out))
-        keys = ("tiles", "halo_nodes", "halo_max", "halo_capacity", "overflow_refs", "row_entries", "padding_entries", "coordinate_boxes")
+        keys = ("tiles", "halo_nodes", "halo_max", "halo_capacity", "overflow_refs", "row_entries", "padding_entries", "coordinate_boxes",
+                "list_entries", "loop_rows")
         return dict(zip(keys, (int(v) for v in out)))
 
     def has_edge_once(self, l: int) -> bool:

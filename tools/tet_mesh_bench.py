@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=120000)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--variants", default="-1,1,2")
+    ap.add_argument("--vcycle", default="", help="comma-separated node counts of a hierarchy: also time a multigrid cycle on it")
     args = ap.parse_args()
     import numpy as np, torch, mgcfd
     from mgcfd import meshgen
@@ -46,6 +47,21 @@ def main():
                     "sweep_us": round(sweep * 1e6, 2), "sweep_gedges_s": round(3 * E / sweep / 1e9, 2),
                     "flux_us": round(flux * 1e6, 2), "flux_gedges_s": round(E / flux / 1e9, 2),
                     "flux_roofline_frac": round((40 * E + 80 * nel) / flux / 8e12, 4), "state_valid": rc == 0})
+        s.close()
+    if args.vcycle:
+        sizes = [int(v) for v in args.vcycle.split(",")]
+        mgh = meshgen.make_tet_multigrid(sizes, "m6wing", seed=0)
+        s = mgcfd.Solver.from_arrays(mgcfd.generated_to_levels(mgh), mgh.mesh_variant)
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+        s.set_stream(stream.cuda_stream)
+        s.run_cycles(5)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        s.run_cycles(50)
+        torch.cuda.synchronize()
+        out.append({"vcycle_levels": sizes, "ms_per_cycle": round((time.perf_counter() - t) / 50 * 1e3, 4),
+                    "tiling": [s.tiling(l) for l in range(len(sizes))]})
         s.close()
     print(json.dumps(out, indent=1))
 

@@ -800,9 +800,11 @@ def test_ragged_tiles_overflow_the_lds_halo(oracle, exact):
     s.close()
 
 
-@pytest.mark.parametrize("variant,n_parts,partitioner,fused", [(0, 3, "slab", False), (2, 3, "slab", False), (0, 4, "rcb", False),
-                                                               (0, 3, "slab", True), (2, 4, "rcb", True)])
-def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts, partitioner, fused):
+@pytest.mark.parametrize("variant,n_parts,partitioner,fused,mesh", [
+    (0, 3, "slab", False, "lattice"), (2, 3, "slab", False, "lattice"), (0, 4, "rcb", False, "lattice"),
+    (0, 3, "slab", True, "lattice"), (2, 4, "rcb", True, "lattice"),
+    (-1, 3, "rcb", True, "tet"), (-1, 4, "slab", False, "tet")])      # tetrahedra: long rows and unstaged neighbours in every part
+def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts, partitioner, fused, mesh):
     """BASELINE config 5 in miniature: one level split into 3 parts with ghost nodes, every RK stage
     followed by a halo exchange (packed / unpacked on the GPU), global-min time step over all parts.
     The three parts run as three solvers on this one GPU, threads standing in for ranks and an
@@ -814,7 +816,10 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts
     from mgcfd.distributed import HipSolverAdapter, PartitionedSweep
     from mgcfd.partition import partition_level, rcb_partition, slab_partition
     dev = torch.device("cuda", 0)
-    mg = meshgen.make_multigrid((14,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    if mesh == "tet":
+        mg = meshgen.make_tet_multigrid((5000,), "m6wing", seed=6)
+    else:
+        mg = meshgen.make_multigrid((14,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
     L = mgcfd.generated_to_levels(mg)[0]
     sweeps = 3
     split = slab_partition if partitioner == "slab" else rcb_partition
@@ -1017,13 +1022,17 @@ def test_one_level_per_solver_equals_run_cycles(mesh3_dir):
         s.close()
 
 
-def test_split_sweep_on_a_ragged_level_equals_smooth():
-    """The split sweep (mgcfd_sweep_begin / _flux0 / _end, both exchanged quantities) on a random graph whose tiles
-    overflow the LDS halo: the second stage cannot absorb the first stage's time_step there (role 5 needs every
-    staged node in LDS) and the separate time_step launch is used — same bits as mgcfd_smooth."""
+@pytest.mark.parametrize("kind", ["random graph", "tetrahedra", "hub"])
+def test_split_sweep_on_a_ragged_level_equals_smooth(kind):
+    """The split sweep (mgcfd_sweep_begin / _flux0 / _end, both exchanged quantities) on levels whose tiles overflow
+    the LDS halo (a random graph, Delaunay tetrahedra): the second stage cannot absorb the first stage's time_step
+    there (role 5 needs every staged node in LDS) and the separate time_step launch is used; and on a 600-spoke hub,
+    where it can, with the hub's long row on the workgroup's list — same bits as mgcfd_smooth every time."""
     import mgcfd
     from mgcfd import meshgen
-    lvl = meshgen.make_random_graph_level(3000, degree=6, seed=5)
+    lvl = {"random graph": lambda: meshgen.make_random_graph_level(3000, degree=6, seed=5),
+           "tetrahedra": lambda: meshgen.make_tet_level(4000, seed=5),
+           "hub": lambda: meshgen.make_hub_level(600, scale=1e-4, seed=5)}[kind]()
     mg = meshgen.MultigridMesh(mesh_name="m6wing", levels=[lvl])
     L = mgcfd.generated_to_levels(mg)[0]
     ref = mgcfd.Solver.from_arrays([L], mg.mesh_variant)

@@ -657,6 +657,15 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
                 a0 += f1.d; a1 += f1.mx; a2 += f1.my; a3 += f1.mz; a4 += f1.en;                              \
             }                                                                                                \
     } while (0)
+    // long rows: what the workgroup's list pass needs first is requested here and arrives while the rows are walked
+    int32_t tl_b = 0, tl_e = 0, tl_nb = 0, tl_nc = 0;
+    double2 tl_r0 = make_double2(0.0, 0.0), tl_r1 = tl_r0, tl_r2 = tl_r0;
+    if (TAIL && (classes & 1)) {
+        tl_b = tp.tile_ptr[t]; tl_e = tp.tile_ptr[t + 1];
+        tl_nb = tp.begin[i]; tl_nc = tp.count[i];
+        const int32_t e_first = tl_b + tid;
+        if (e_first < tl_e) { tl_r0 = tp.rec[3 * int64_t(e_first)]; tl_r1 = tp.rec[3 * int64_t(e_first) + 1]; tl_r2 = tp.rec[3 * int64_t(e_first) + 2]; }
+    }
     double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, sfv = 0.0;       // fused stages: the time_step operands
     {
         // every pair but the last, each prefetching the pair after it
@@ -678,58 +687,77 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     }
 #undef MGCFD_ROW_PAIR
 
-    if (TAIL && (classes & 1)) {
+    if (TAIL && (classes & 1) && tl_e > tl_b) {                            // (uniform)
         // Long rows.  The entries beyond the tile's row limit, one per thread whatever node they belong to: the same
-        // edge_flux from the same operands (the owner's record is read back from LDS), results to a global scratch;
-        // then every owner adds its own entries in row order — the accumulation order is untouched, only the
-        // evaluation is spread over the workgroup instead of waiting for the highest-degree lanes.
-        const int32_t tb = tp.tile_ptr[t], te = tp.tile_ptr[t + 1];        // (uniform)
-        if (te > tb) {
-            // (requested before the evaluation rounds, used after them)
-            const int32_t nb = tp.begin[i], nc = tp.count[i];
-            int32_t e = tb + tid;
-            double2 r0 = make_double2(0.0, 0.0), r1 = r0, r2 = r0;
-            if (e < te) { r0 = tp.rec[3 * int64_t(e)]; r1 = tp.rec[3 * int64_t(e) + 1]; r2 = tp.rec[3 * int64_t(e) + 2]; }
-            while (e < te) {
-                const double2 c0 = r0, c1 = r1, c2 = r2;
-                const int32_t en = e + kBlock;
-                if (en < te) { r0 = tp.rec[3 * int64_t(en)]; r1 = tp.rec[3 * int64_t(en) + 1]; r2 = tp.rec[3 * int64_t(en) + 2]; }   // next round's entry
-                const uint32_t word = static_cast<uint32_t>(__double_as_longlong(c2.x));
-                const uint32_t own = word & 0xFFFFu;
-                if (own != kT16Pad) {
-                    EdgeRow er;
-                    er.code = word >> 16;
-                    er.fx = c0.x; er.fy = c0.y; er.fz = c1.x; er.k = LOADK ? c1.y : 0.0;
-                    const uint32_t s = er.code & kT16SlotMask;
-                    const NodeQ mo = lds_load_record(tile, own);
-                    const NodeQ ot = s >= uint32_t(kTileCap) ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s) - kTileCap])
-                                                             : lds_load_record(tile, s);
-                    const Flux5 f = edge_flux<LOADK>(mo, flux_contribution(mo), ot, er);
+        // edge_flux from the same operands (the owner's record is read back from LDS); then every owner adds its own
+        // entries in row order — the accumulation order is untouched, only the evaluation is spread over the
+        // workgroup instead of waiting for the highest-degree lanes.  The results of the last round of 256 entries
+        // (usually the only one) are handed over through LDS, where the records are dead by then; earlier rounds
+        // go through a global scratch.
+        const int32_t last0 = tl_b + ((tl_e - tl_b - 1) / kBlock) * kBlock;   // first entry of the last round
+        int32_t e = tl_b + tid;
+        double2 r0 = tl_r0, r1 = tl_r1, r2 = tl_r2;
+        Flux5 fl;
+        fl.d = 0.0; fl.mx = 0.0; fl.my = 0.0; fl.mz = 0.0; fl.en = 0.0;
+        while (e < tl_e) {
+            const double2 c0 = r0, c1 = r1, c2 = r2;
+            const int32_t en = e + kBlock;
+            if (en < tl_e) { r0 = tp.rec[3 * int64_t(en)]; r1 = tp.rec[3 * int64_t(en) + 1]; r2 = tp.rec[3 * int64_t(en) + 2]; }   // next round's entry
+            const uint32_t word = static_cast<uint32_t>(__double_as_longlong(c2.x));
+            const uint32_t own = word & 0xFFFFu;
+            if (own != kT16Pad) {
+                EdgeRow er;
+                er.code = word >> 16;
+                er.fx = c0.x; er.fy = c0.y; er.fz = c1.x; er.k = LOADK ? c1.y : 0.0;
+                const uint32_t s = er.code & kT16SlotMask;
+                const NodeQ mo = lds_load_record(tile, own);
+                const NodeQ ot = s >= uint32_t(kTileCap) ? load_and_derive(q, stride, tile_ovf[ovf0 + int32_t(s) - kTileCap])
+                                                         : lds_load_record(tile, s);
+                const Flux5 f = edge_flux<LOADK>(mo, flux_contribution(mo), ot, er);
+                if (e >= last0) {
+                    fl = f;
+                } else {
                     double2 *out = tp.flux + 3 * int64_t(e);
                     out[0] = make_double2(f.d, f.mx); out[1] = make_double2(f.my, f.mz); out[2] = make_double2(f.en, 0.0);
                 }
-                e = en;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's scratch stores have left
-            __syncthreads();
-            // (a tile's scratch range is whole 128-byte lines that only this workgroup touches, and it reads them
-            //  only now: no stale copy can sit in this CU's L1)
-            // ordered adds, the records fetched three entries ahead of the sums that consume them
-            const double2 *in = tp.flux + 3 * int64_t(nb);
-            int32_t k = 0;
-            for (; k + 3 <= nc; k += 3) {
-                const double2 u0 = in[0], u1 = in[1], u2 = in[2], v0 = in[3], v1 = in[4], v2 = in[5], w0 = in[6], w1 = in[7], w2 = in[8];
-                in += 9;
-                a0 += u0.x; a1 += u0.y; a2 += u1.x; a3 += u1.y; a4 += u2.x;
-                a0 += v0.x; a1 += v0.y; a2 += v1.x; a3 += v1.y; a4 += v2.x;
-                a0 += w0.x; a1 += w0.y; a2 += w1.x; a3 += w1.y; a4 += w2.x;
-            }
-            for (; k < nc; k++) {
-                const double2 u0 = in[0], u1 = in[1], u2 = in[2];
-                in += 3;
-                a0 += u0.x; a1 += u0.y; a2 += u1.x; a3 += u1.y; a4 += u2.x;
-            }
+            e = en;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's scratch stores have left
+        __syncthreads();                                                  // ... and nobody reads a record any more
+        tile[3 * tid] = make_double2(fl.d, fl.mx); tile[3 * tid + 1] = make_double2(fl.my, fl.mz); tile[3 * tid + 2] = make_double2(fl.en, 0.0);
+        __syncthreads();
+        // (a tile's scratch range is whole 128-byte lines that only this workgroup touches, and it reads them
+        //  only now: no stale copy can sit in this CU's L1)
+        // ordered adds: first the node's entries of the earlier rounds (global), then those of the last round (LDS)
+        const int32_t n_glob = min(tl_nc, max(0, last0 - tl_nb));
+#define MGCFD_ADD_ENTRIES(in, count)                                                                              \
+        do {                                                                                                      \
+            int32_t k_ = 0;                                                                                       \
+            for (; k_ + 3 <= (count); k_ += 3) {           /* the records fetched three entries ahead of the sums */ \
+                const double2 u0 = in[0], u1 = in[1], u2 = in[2], v0 = in[3], v1 = in[4], v2 = in[5],              \
+                              w0 = in[6], w1 = in[7], w2 = in[8];                                                 \
+                in += 9;                                                                                          \
+                a0 += u0.x; a1 += u0.y; a2 += u1.x; a3 += u1.y; a4 += u2.x;                                       \
+                a0 += v0.x; a1 += v0.y; a2 += v1.x; a3 += v1.y; a4 += v2.x;                                       \
+                a0 += w0.x; a1 += w0.y; a2 += w1.x; a3 += w1.y; a4 += w2.x;                                       \
+            }                                                                                                     \
+            for (; k_ < (count); k_++) {                                                                          \
+                const double2 u0 = in[0], u1 = in[1], u2 = in[2];                                                 \
+                in += 3;                                                                                          \
+                a0 += u0.x; a1 += u0.y; a2 += u1.x; a3 += u1.y; a4 += u2.x;                                       \
+            }                                                                                                     \
+        } while (0)
+        if (n_glob > 0) {
+            const double2 *in = tp.flux + 3 * int64_t(tl_nb);
+            MGCFD_ADD_ENTRIES(in, n_glob);
+        }
+        {
+            const double2 *in = tile + 3 * (tl_nb + n_glob - last0);
+            const int32_t n_lds = tl_nc - n_glob;
+            MGCFD_ADD_ENTRIES(in, n_lds);
+        }
+#undef MGCFD_ADD_ENTRIES
     }
 
     if ((classes & 6) && n_bnd > 0) {

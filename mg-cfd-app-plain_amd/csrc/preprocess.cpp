@@ -553,9 +553,9 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         const double rec[6] = {w.x, w.y, w.z, w.k, as_double, 0.0};
         P.tail_rec.insert(P.tail_rec.end(), rec, rec + 6);
     };
-    // fitted on a tetrahedral level (tools/tet_mesh_bench.py): a round of the list costs about two row pairs of the
-    // loop (single entries, the owner's record and flux terms fetched again, a trip through the scratch)
-    const double c_fixed = 2.5, c_round = 2.0, c_add = 0.1;
+    // fitted on a tetrahedral level (tools/tet_mesh_bench.py; the optimum is flat): a round of the list costs more than
+    // a row pair of the loop (single entries, the owner's record and flux terms fetched again, the hand-over)
+    const double c_fixed = 1.5, c_round = 1.5, c_add = 0.1;
     if (opt.long_rows) {
         for (int32_t t = 0; t < P.n_tiles; t++) {
             const int32_t base = t * kTile, s0 = t * (kTile / kSlice);

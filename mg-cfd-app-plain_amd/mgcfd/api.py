@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -128,6 +129,15 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if not os.path.exists(p):
         raise FileNotFoundError(f"{p} not found: build it with `make -C {CSRC_DIR}` "
                                 f"(or __graft_entry__.build()); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64, and a second runtime
+    # brought up after the system one finds "no ROCm-capable device".  With torch loaded first this library binds to
+    # the same (already loaded) runtime, so do that here when torch is installed — a process that never imports
+    # torch (the C++ driver, a plain ctypes user) runs on the system runtime alone.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(p)
     for name, res, args in _SIGNATURES:
         fn = getattr(lib, name)

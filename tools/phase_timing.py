@@ -99,20 +99,21 @@ def compile_lib(src, host_dir=None):
     print("built", lib)
 
 def build_tile(src):
-    i = src.index("template <int MINW, bool LOADK, bool FUSE, bool ACC, int ROLE>\n__global__ void __launch_bounds__(kBlock, MINW)\nk_flux_tile")
+    i = src.index("template <int MINW, bool LOADK, bool FUSE, bool ACC, int ROLE, bool TAIL>\n__global__ void __launch_bounds__(kBlock, MINW)\nk_flux_tile")
     src = src[:i] + HEAD + src[i:]
     j = src.index("k_flux_tile", i)
     body = src[j:]
     body = rep(body, "    double min_dt = 0.0;\n", "    PH_BEGIN();\n    double min_dt = 0.0;\n")
     body = rep(body, "    // ---- phase 2: incidence rows two at a time", "    PH_MARK(0);\n    // ---- phase 2: incidence rows two at a time")
-    body = rep(body, "    if ((classes & 6) && n_bnd > 0) {\n", "    PH_MARK(1);\n    if ((classes & 6) && n_bnd > 0) {\n")
+    body = rep(body, "    if (TAIL && (classes & 1)) {\n", "    PH_MARK(1);\n    if (TAIL && (classes & 1)) {\n")
+    body = rep(body, "    if ((classes & 6) && n_bnd > 0) {\n", "    PH_MARK(2);\n    if ((classes & 6) && n_bnd > 0) {\n")
     # only k_flux_tile's own text (up to the edge-once kernel's banner)
     end = body.index("// flux_edge_once: the same three loops")
     tile_body, rest = body[:end], body[end:]
     tile_body = rep(tile_body, "            fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;\n        }\n        return;\n    }",
-                    "            fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;\n        }\n        PH_MARK(2);\n        return;\n    }")
+                    "            fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;\n        }\n        PH_MARK(3);\n        return;\n    }")
     k_end = tile_body.rindex("}\n\n")                       # the closing brace of k_flux_tile
-    tile_body = tile_body[:k_end] + "    PH_MARK(2);\n" + tile_body[k_end:]
+    tile_body = tile_body[:k_end] + "    PH_MARK(3);\n" + tile_body[k_end:]
     body = tile_body + rest
     src = src[:j] + body + TAIL
     compile_lib(src)
@@ -122,7 +123,13 @@ def run():
     os.environ["MGCFD_LIB"] = lib_path
     sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd")); sys.path.insert(0, ROOT)
     import bench, mgcfd
-    mg, levels = bench.build_workload(67)
+    if os.environ.get("PH_MESH") == "tet":                # an unstructured level instead (long rows, unstaged neighbours)
+        from mgcfd import meshgen
+        mg = meshgen.MultigridMesh(mesh_name="m6wing")
+        mg.levels.append(meshgen.make_tet_level(120000, seed=0))
+        levels = mgcfd.generated_to_levels(mg)
+    else:
+        mg, levels = bench.build_workload(67)
     s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
     s.set(0, "variables", bench.perturbed_state(s.nel(0), s.far_field()[:5]))
     s.set_option("flux_variant", int(sys.argv[2]) if len(sys.argv) > 2 else 2)
@@ -144,7 +151,7 @@ def run():
     buf = a.sum(0)
     names = ["stage+sync", "edge phase", "sync", "dump+sync", "gather", "boundary+store"]
     if os.environ.get("PH_TILE"):
-        names = ["stage+sync", "row loop", "boundary+store", "-", "-", "-"]
+        names = ["stage+sync", "row loop", "long-row list", "boundary+store", "-", "-"]
     elif os.environ.get("PH_FINE"):
         names = ["entry -> halo ids", "-> q arrived", "derive + LDS store", "sync", "-", "-"]
     print(f"kernel avg {t*1e6:.2f} us, {n} workgroups")

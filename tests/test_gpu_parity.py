@@ -1219,3 +1219,73 @@ def test_full_size_matches_oracle_on_one_sweep(big, oracle):
     s.smooth(0, 1)
     _assert_close(s.get(0, "variables"), v, True, "300K-node sweep")
     _assert_close(s.get(0, "step_factors"), sf, True, "300K-node step factors")
+
+
+# ------------------------------------------------------------------------------------------
+# An unstructured level of the same edge count (Delaunay tetrahedra, 120,000 nodes / 926,505 edges):
+# size-independent properties, and the oracle on one sweep
+# ------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big_tet():
+    import mgcfd
+    from mgcfd import meshgen
+    # fvcorr: the weights are used as they are (the m6wing / rotor37 adjust_ewt divides internal weights by the edge
+    # length, after which the dual cells no longer close); every hull face far field
+    mg = meshgen.MultigridMesh(mesh_name="fvcorr")
+    mg.levels.append(meshgen.make_tet_level(120000, seed=0, wall_below=2.0))
+    levels = mgcfd.generated_to_levels(mg)
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    yield mgcfd, s, levels, mg
+    s.close()
+
+
+def test_tetrahedral_level_preserves_the_free_stream_and_conserves(big_tet):
+    """Closed median-dual cells: the far-field state is a steady solution (fluxes vanish to rounding, sweeps leave it
+    where it is), and on a perturbed state the internal fluxes of all nodes cancel (every edge adds F and -F) — with
+    the long rows of this mesh on the workgroups' lists."""
+    mgcfd, s, levels, mg = big_tet
+    t = s.tiling(0)
+    assert t["list_entries"] > 0 and t["coordinate_boxes"] == 1
+    ff = s.far_field()[:5]
+    q = np.tile(ff, (s.nel(0), 1))
+    s.set(0, "variables", q)
+    s.zero_fluxes(0)
+    s.compute_flux_edge(0); s.compute_boundary_flux_edge(0); s.compute_wall_flux_edge(0)
+    f = s.get(0, "fluxes")
+    w = np.abs(levels[0]["edges"]["x"]).max()
+    assert np.abs(f).max() < 1e-12 * w * np.abs(ff).max() * 40             # ~40 faces per node, each O(w * |q|)
+    s.zero_fluxes(0)
+    s.smooth(0, 5)
+    assert np.abs(s.get(0, "variables") - q).max() < 1e-9                  # (step factors ~1e3: rounding residue, not drift)
+    from conftest import perturbed_state
+    s.set(0, "variables", perturbed_state(s.nel(0), ff, seed=4))
+    s.zero_fluxes(0)
+    s.compute_flux_edge(0)
+    f = s.get(0, "fluxes")
+    assert np.isfinite(f).all() and np.all(np.abs(f.sum(axis=0)) <= 1e-12 * np.abs(f).sum(axis=0))
+
+
+def test_tetrahedral_level_matches_oracle_on_one_sweep(big_tet, oracle):
+    """One sweep on the 120,000-node tetrahedral level against the oracle, bit for bit (the oracle needs ~0.3 s)."""
+    mgcfd, s, levels, mg = big_tet
+    from conftest import perturbed_state
+    q = perturbed_state(s.nel(0), s.far_field()[:5], seed=8)
+    lib = oracle.load()
+    L = levels[0]
+    edges = np.ascontiguousarray(L["edges"]).copy()                      # (fvcorr: no adjust_ewt / dampen_ewt)
+    ni, nb, nw = L["n_internal"], L["n_boundary"], L["n_wall"]
+    nel = L["nel"]
+    vol = np.ascontiguousarray(L["volumes"], dtype=np.float64)
+    var, old, flux, sf = q.copy(), q.copy(), np.zeros((nel, 5)), np.zeros(nel)
+    ff = oracle.farfield()
+    lib.ora_compute_step_factor_legacy(nel, oracle.ptr(var), oracle.ptr(vol), oracle.ptr(sf))
+    for j in range(3):
+        lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(var), oracle.ptr(flux))
+        lib.ora_compute_boundary_flux_edge(ni, nb, oracle.ptr(edges), oracle.ptr(var), oracle.ptr(flux))
+        lib.ora_compute_wall_flux_edge(ni + nb, nw, oracle.ptr(edges), oracle.ptr(var), oracle.ptr(flux), C.byref(ff))
+        lib.ora_time_step(j, nel, oracle.ptr(sf), oracle.ptr(flux), oracle.ptr(old), oracle.ptr(var))
+    s.set(0, "variables", q)
+    s.zero_fluxes(0)
+    s.smooth(0, 1)
+    assert np.array_equal(s.get(0, "variables").view(np.int64), var.view(np.int64))
+

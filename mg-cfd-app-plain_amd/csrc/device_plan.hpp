@@ -46,6 +46,16 @@ struct FusedStep {
     double *next_legacy_sf = nullptr;         // mesh_name = fvcorr: next sweep's step factors 0.5/(sqrt(vol)*(|v|+c)) (cfd_loops.cpp:37-61) go here
 };
 
+// "Add up these partial sums" as an argument: k_sum_partials does only that; k_restrict can take it along.
+struct SumTask {
+    const double *partial = nullptr;      // [n]
+    int n = 0;
+    double *out = nullptr;                // the total
+    double *ring = nullptr;               // nullptr, or: also append the total to the rms history
+    int *count = nullptr;
+    int cap = 0;
+};
+
 // Long rows (preprocess.hpp: LevelPlan::tail_*): device arrays of the entries the per-node loop leaves to the workgroup.
 struct TailPlan {
     const int32_t *rows_main = nullptr;   // [n_slices] internal rows the per-node loop walks

@@ -1231,26 +1231,31 @@ k_sumsq(int64_t nel, int64_t stride, const double *__restrict__ x, double *__res
     }
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_sum_partials(int n, const double *__restrict__ partial, double *__restrict__ out,
-               double *__restrict__ ring /* nullptr, or: also append the sum to the rms history */, int *__restrict__ count, int cap)
+// One workgroup adds up n partial sums (always in this order) and may append the total to the rms history.
+__device__ __forceinline__ void block_sum_partials(const SumTask &task)
 {
     __shared__ double s[kBlock / 64];
     double acc = 0.0;
-    for (int k = threadIdx.x; k < n; k += kBlock) acc += partial[k];
+    for (int k = threadIdx.x; k < task.n; k += kBlock) acc += task.partial[k];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < kBlock / 64; w++) t += s[w];
-        out[0] = t;
-        if (ring) {
-            const int c = *count;
-            if (c < cap) ring[c] = t;
-            *count = c + 1;
+        task.out[0] = t;
+        if (task.ring) {
+            const int c = *task.count;
+            if (c < task.cap) task.ring[c] = t;
+            *task.count = c + 1;
         }
     }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_sum_partials(SumTask task)
+{
+    block_sum_partials(task);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1293,7 +1298,9 @@ __global__ void __launch_bounds__(kBlock)
 k_restrict(int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine, const int32_t *__restrict__ child_ptr,
            const int32_t *__restrict__ child, const int4 *__restrict__ child4, const double *__restrict__ fine_q,
            double *__restrict__ coarse_q, const double *__restrict__ cbrt_vol,
-           double *__restrict__ partial_min /* nullptr, or: look ahead, see below */)
+           double *__restrict__ partial_min /* nullptr, or: look ahead, see below */,
+           SumTask rms /* .partial != nullptr: the last workgroup also adds up the fine level's per-tile sums of squares
+                          (calc_rms of the sweep just finished) — the launch that would do only that is saved */)
 {
     const int64_t c = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     double sf = __longlong_as_double(0x7FF0000000000000LL);          // +inf
@@ -1337,6 +1344,7 @@ k_restrict(int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine, const
         if (partial_min) sf = local_step_factor(n0, n1, n2, n3, n4, cbrt_vol[c]);
     }
     if (partial_min) block_min_to(sf, partial_min);
+    if (rms.partial && blockIdx.x == gridDim.x - 1) block_sum_partials(rms);      // (uniform per workgroup)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1634,8 +1642,7 @@ void launch_sumsq(hipStream_t st, int64_t nel, int64_t stride, const double *x, 
 {
     hipLaunchKernelGGL(k_sumsq, dim3(n_partial), dim3(kBlock), 0, st, nel, stride, x, partial,
                        n_owned < nel ? old_of_new : nullptr, n_owned);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, n_partial, partial, out, static_cast<double *>(nullptr),
-                       static_cast<int *>(nullptr), 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, SumTask{partial, n_partial, out, nullptr, nullptr, 0});
 }
 
 void launch_halo_pack(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const double *field, double *msg)
@@ -1645,18 +1652,18 @@ void launch_halo_unpack(hipStream_t st, int64_t n, int64_t stride, const int32_t
 { if (n > 0) hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, msg, field); }
 
 void launch_sum_partials_append(hipStream_t st, int n, const double *partial, double *out, double *ring, int *count, int cap)
-{ hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, n, partial, out, ring, count, cap); }
+{ hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, SumTask{partial, n, out, ring, count, cap}); }
 
 void launch_append_scalar(hipStream_t st, const double *src, double *ring, int *count, int cap)
 { hipLaunchKernelGGL(k_append_scalar, dim3(1), dim3(64), 0, st, src, ring, count, cap); }
 
 void launch_restrict(hipStream_t st, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,
                      const int32_t *child_ptr, const int32_t *child, const int32_t *child4, const double *fine_q,
-                     double *coarse_q, const double *cbrt_vol, double *partial_min)
+                     double *coarse_q, const double *cbrt_vol, double *partial_min, const SumTask &rms)
 {
     hipLaunchKernelGGL(k_restrict, dim3(grid_for(nel_coarse)), dim3(kBlock), 0, st, nel_coarse, stride_coarse,
                        stride_fine, child_ptr, child, reinterpret_cast<const int4 *>(child4), fine_q, coarse_q, cbrt_vol,
-                       partial_min);
+                       partial_min, rms);
 }
 
 void launch_prolong(hipStream_t st, const DevicePlan &p, int64_t stride_coarse, const double *coarse_residuals,

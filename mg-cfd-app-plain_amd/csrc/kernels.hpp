@@ -36,7 +36,7 @@
     void launch_restrict(hipStream_t, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,                \
                          const int32_t *child_ptr, const int32_t *child, const int32_t *child4, const double *fine_q, \
                          double *coarse_q,                                                                        \
-                         const double *cbrt_vol, double *partial_min);                                              \
+                         const double *cbrt_vol, double *partial_min, const SumTask &rms);                          \
     void launch_prolong(hipStream_t, const DevicePlan &, int64_t stride_coarse, const double *coarse_residuals,      \
                         const double *fine_residuals, double *fine_q, const double *cbrt_vol,                       \
                         double *partial_min);                                                                        \

@@ -344,7 +344,8 @@ struct mgcfd_solver {
         if (opt_exact) exact::launch_sumsq(stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
         else fast::launch_sumsq(stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
     }
-    void op_restrict(int fine)
+    // rms (may be null): per-tile sums of squares of the fine level that the launch adds up on the side (cycle_once)
+    void op_restrict(int fine, const SumTask *rms = nullptr)
     {
         DeviceLevel &F = level(fine);
         DeviceLevel &C = level(fine + 1);
@@ -357,8 +358,9 @@ struct mgcfd_solver {
         const bool ahead = mesh_variant != MGCFD_MESH_FVCORR && C.n_owned == C.info.nel;
         double *pm = ahead ? C.partial_min : nullptr;
         Timed t(this, fine + 1, MGCFD_LOOP_RESTRICT);
-        if (opt_exact) exact::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.dp.child4, F.q, C.q, C.cbrt_vol, pm);
-        else fast::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.dp.child4, F.q, C.q, C.cbrt_vol, pm);
+        const SumTask task = rms ? *rms : SumTask{};
+        if (opt_exact) exact::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.dp.child4, F.q, C.q, C.cbrt_vol, pm, task);
+        else fast::launch_restrict(stream, C.info.nel, C.dp.stride, F.dp.stride, F.dp.child_ptr, F.dp.child, F.dp.child4, F.q, C.q, C.cbrt_vol, pm, task);
         C.min_ahead = ahead;
         C.iters[MGCFD_LOOP_RESTRICT] += 2 * F.info.mgc + C.info.nel;   // mg_loops.cpp:61,117,172
     }
@@ -1133,14 +1135,21 @@ static void cycle_once(mgcfd_solver *s, bool capturing)
 {
     const int n = static_cast<int>(s->L.size());
     auto sweep = [&](int l) { if (capturing) smooth_once(s, l); else run_sweep(s, l); };
+    SumTask rms_task;
+    bool rms_pending = false;
     for (int l = 0; l < n; l++) {
         if (l == 0) { s->L[0].want_sumsq = true; s->L[0].have_sumsq = false; }
         sweep(l);                                                          // :383-508
         if (l == 0) {                                                      // :509-512
             DeviceLevel &l0 = s->L[0];
             l0.want_sumsq = false;
-            if (l0.have_sumsq) {
-                // the last stage left per-tile sums of squares: one small launch adds them up and appends
+            if (l0.have_sumsq && n > 1) {
+                // the last stage left per-tile sums of squares: the restriction that follows adds them up and appends
+                rms_task = SumTask{l0.tile_sumsq, static_cast<int>((l0.info.nel + 255) / 256), l0.sumsq, s->rms_ring, s->rms_count,
+                                   mgcfd_solver::kRmsRing};
+                rms_pending = true;
+            } else if (l0.have_sumsq) {
+                // ... single level: one small launch does
                 exact::launch_sum_partials_append(s->stream, static_cast<int>((l0.info.nel + 255) / 256), l0.tile_sumsq, l0.sumsq,
                                                   s->rms_ring, s->rms_count, mgcfd_solver::kRmsRing);
             } else {
@@ -1148,7 +1157,7 @@ static void cycle_once(mgcfd_solver *s, bool capturing)
                 exact::launch_append_scalar(s->stream, l0.sumsq, s->rms_ring, s->rms_count, mgcfd_solver::kRmsRing);
             }
         }
-        if (l + 1 < n) s->op_restrict(l);                                  // :527-559
+        if (l + 1 < n) { s->op_restrict(l, (l == 0 && rms_pending) ? &rms_task : nullptr); rms_pending = false; }   // :527-559
     }
     for (int l = n - 2; l >= 0; l--) {
         s->op_prolong(l);                                                  // :560-688

@@ -576,7 +576,11 @@ int ora_solve(ora_level *levels, int nlevels, int mesh_variant, int cycles,
 {
     ora_farfield ff;
     ora_far_field(&ff);                                             /* :321 */
-    int64_t *up_scratch = (int64_t *)malloc(sizeof(int64_t) * (size_t)levels[0].nel); /* :323 */
+    /* :323 sizes this by nel[0]; mg_restrict indexes it by COARSE node, so a hierarchy whose coarse level is the
+     * larger one overruns it there.  Sized by the largest level here: same results wherever the reference is defined. */
+    int64_t scratch_n = levels[0].nel;
+    for (int l = 1; l < nlevels; l++) if (levels[l].nel > scratch_n) scratch_n = levels[l].nel;
+    int64_t *up_scratch = (int64_t *)malloc(sizeof(int64_t) * (size_t)scratch_n);
     for (int l = 0; l < nlevels; l++) {
         ora_initialize_variables(levels[l].nel, levels[l].variables, &ff);
         ora_zero_fluxes(levels[l].nel, levels[l].fluxes);

@@ -462,6 +462,30 @@ def test_run_that_blows_up_reports_the_references_first_bad_cell(oracle, fuse):
     s.close()
 
 
+@pytest.mark.parametrize("seed", [0, 3, 7, 12, 19, 23, 40, 57, 88, 101, 127, 149])
+def test_randomised_hierarchies(oracle, seed):
+    """tools/fuzz_parity.py's generator (random kind — lattice, tetrahedra, hub, random graph —, sizes, mesh name,
+    options; 150 seeds ran clean when it was written): a dozen of them here, every level bit for bit.  Seed 40 is a
+    hierarchy whose COARSE level is the larger one."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity
+    import mgcfd
+    rng = np.random.default_rng(seed)
+    kind, name, mg, cycles = fuzz_parity.make_case(rng)
+    levels = mgcfd.generated_to_levels(mg)
+    want, want_rms = _oracle_solve_arrays(oracle, levels, mg.mesh_variant, cycles)
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    s.set_option("fuse_update", int(rng.integers(0, 2)))
+    s.set_option("flux_variant", int(rng.choice([-1, 0, 1, 2, 3])))
+    s.set_option("graph", int(rng.integers(0, 2)))
+    rms = s.run_cycles(cycles)
+    for l in range(len(levels)):
+        _assert_close(s.get(l, "variables"), want[l], True, f"seed {seed}: {kind} {name} level {l}")
+    assert np.allclose(rms, want_rms, rtol=1e-12, atol=1e-300)
+    s.close()
+
+
 def test_tiling_report_and_coordinate_box_fallback():
     """mgcfd_level_tiling: a lattice level keeps the greedy clusters (no halo node left outside the LDS tile); on a
     tetrahedral level those overflow, coordinate boxes are chosen instead, and few row entries are left to gather

@@ -827,7 +827,9 @@ def test_ragged_tiles_overflow_the_lds_halo(oracle, exact):
 @pytest.mark.parametrize("variant,n_parts,partitioner,fused,mesh", [
     (0, 3, "slab", False, "lattice"), (2, 3, "slab", False, "lattice"), (0, 4, "rcb", False, "lattice"),
     (0, 3, "slab", True, "lattice"), (2, 4, "rcb", True, "lattice"),
-    (-1, 3, "rcb", True, "tet"), (-1, 4, "slab", False, "tet")])      # tetrahedra: long rows and unstaged neighbours in every part
+    (-1, 3, "rcb", True, "tet"), (-1, 4, "slab", False, "tet"),       # tetrahedra: long rows and unstaged neighbours in every part
+    (-1, 3, "slab", True, "hub"), (-1, 2, "rcb", False, "hub"),       # a 700-spoke hub: owned by one part, a ghost in the others
+    (-1, 3, "rcb", True, "graph"), (-1, 3, "slab", False, "graph")])   # random graph: nearly every node of a part has ghosts
 def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts, partitioner, fused, mesh):
     """BASELINE config 5 in miniature: one level split into 3 parts with ghost nodes, every RK stage
     followed by a halo exchange (packed / unpacked on the GPU), global-min time step over all parts.
@@ -842,6 +844,10 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts
     dev = torch.device("cuda", 0)
     if mesh == "tet":
         mg = meshgen.make_tet_multigrid((5000,), "m6wing", seed=6)
+    elif mesh == "hub":
+        mg = meshgen.MultigridMesh(mesh_name="m6wing", levels=[meshgen.make_hub_level(700, scale=1e-4, seed=6)])
+    elif mesh == "graph":
+        mg = meshgen.MultigridMesh(mesh_name="m6wing", levels=[meshgen.make_random_graph_level(2500, degree=8, seed=6)])
     else:
         mg = meshgen.make_multigrid((14,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
     L = mgcfd.generated_to_levels(mg)[0]

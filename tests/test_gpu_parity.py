@@ -924,7 +924,8 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts
     assert abs(np.sqrt(sumsq / L["nel"]) - want_rms) <= 1e-12 * want_rms
 
 
-@pytest.mark.parametrize("sizes,n_parts,fused", [((12, 6, 3), 3, False), ((14, 7), 4, False), ((12, 6, 3), 3, True)])
+@pytest.mark.parametrize("sizes,n_parts,fused", [((12, 6, 3), 3, False), ((14, 7), 4, False), ((12, 6, 3), 3, True),
+                                                 ((3000, 700, 150), 3, True), ((2500, 500), 2, False)])   # node counts >= 100: tetrahedra
 def test_partitioned_hierarchy_vcycles_equal_whole_mesh(sizes, n_parts, fused):
     """Every level of a hierarchy split over "ranks" (threads, one solver each, in-process copies for send/recv):
     flux ghosts, the children a rank's coarse nodes need for mgcfd_restrict and the parents mgcfd_prolong reads are
@@ -938,7 +939,10 @@ def test_partitioned_hierarchy_vcycles_equal_whole_mesh(sizes, n_parts, fused):
     from mgcfd.partition import partition_hierarchy, rcb_partition
     dev = torch.device("cuda", 0)
     cycles = 3
-    mg = meshgen.make_multigrid(sizes, "m6wing", seed=4, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    if sizes[0] >= 100:
+        mg = meshgen.make_tet_multigrid(sizes, "m6wing", seed=4)
+    else:
+        mg = meshgen.make_multigrid(sizes, "m6wing", seed=4, jitter=0.2, area_noise=0.05, volume_noise=0.05)
     levels = mgcfd.generated_to_levels(mg)
     whole = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
     whole.run_cycles(cycles)

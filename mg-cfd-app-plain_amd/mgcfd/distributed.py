@@ -15,6 +15,7 @@ scalar views; the product passes a :class:`mgcfd.api.Solver`, the CPU tests a st
 from __future__ import annotations
 
 import math
+import os
 
 RK = 3
 
@@ -86,6 +87,8 @@ class ShardedSweep:
         self.fused = fused and hasattr(solver, "sweep_begin")   # one launch per RK stage (mgcfd_sweep_begin/_end)
         self.overlap_even_alone = False     # tests: take the sweep_flux0 path without a process group
         self.reduce_partials = True         # all-reduce the partial minima (see sweep)
+        # all-reduce a torch-owned copy instead of the library's memory (fallback, see sweep; MGCFD_ALLREDUCE_STAGED=1 forces it)
+        self._staged = os.environ.get("MGCFD_ALLREDUCE_STAGED") == "1"
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.global_time_step = global_time_step      # False for mesh_name = fvcorr (local time step)
 
@@ -108,9 +111,22 @@ class ShardedSweep:
                 # The first stage's fluxes do not depend on the time step: run them while the all-reduce
                 # (latency bound, tens of microseconds over xGMI) is in flight.
                 t = s.partial_min_tensor(level) if partials else s.min_tensor(level)
-                work = self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, async_op=True)
+                stage = None
+                if not self._staged:
+                    try:
+                        # in place on the library's own device memory (the tensor aliases it)
+                        work = self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, async_op=True)
+                    except RuntimeError:
+                        # a backend that refuses memory torch did not allocate: go through a torch-owned copy from
+                        # now on (two small device copies per sweep; same values)
+                        self._staged = True
+                if self._staged:
+                    stage = t.clone()
+                    work = self.dist.all_reduce(stage, op=self.dist.ReduceOp.MIN, async_op=True)
                 s.sweep_flux0(level)
                 work.wait()          # stream-level wait: later kernels are ordered after the collective
+                if stage is not None:
+                    t.copy_(stage)
             elif self.overlap_even_alone:
                 s.sweep_flux0(level)
             (s.sweep_end_partials if partials else s.sweep_end)(level)

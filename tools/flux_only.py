@@ -9,8 +9,15 @@ ap.add_argument("--lattice", type=int, default=67)
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--launches", type=int, default=20)
 ap.add_argument("--fast", action="store_true")
+ap.add_argument("--tet", type=int, default=0, help="node count of a Delaunay tetrahedral level to use instead of the lattice")
 a = ap.parse_args()
-mg, levels = bench.build_workload(a.lattice)
+if a.tet:
+    from mgcfd import meshgen
+    mg = meshgen.MultigridMesh(mesh_name="m6wing")
+    mg.levels.append(meshgen.make_tet_level(a.tet, seed=0))
+    levels = mgcfd.generated_to_levels(mg)
+else:
+    mg, levels = bench.build_workload(a.lattice)
 s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
 s.set(0, "variables", bench.perturbed_state(s.nel(0), s.far_field()[:5]))
 s.set_option("exact", 0 if a.fast else 1)

@@ -109,6 +109,34 @@ def test_reader_errors_are_reported_not_fatal(mgcfd_mod, tmp_path):
         mgcfd_mod.Mesh("t.dat", str(tmp_path))
 
 
+def test_reader_accepts_what_operator_extraction_accepts(mgcfd_mod, tmp_path):
+    """The reference parses the mesh, .coords and map files with operator>>: any whitespace separates tokens, numbers
+    may carry '+' and a capital exponent, lines may end in CR LF.  (Checked against the real binary when this test was
+    written: such files give its golden dump byte for byte — while an input.dat with CR LF line ends makes it exit
+    with 1, as it does this reader.)"""
+    import re
+    import shutil
+    src = os.path.join(GOLDEN, "m6_2lvl", "input")
+    want = mgcfd_mod.Mesh("input.dat", src)
+    for f in os.listdir(src):
+        t = open(os.path.join(src, f)).read()
+        if f != "input.dat":
+            t = re.sub(r"(?<![\w.+-])(\d+\.\d+e[+-]\d+)", r"+\1", t).replace("e", "E").replace(" ", "\t").replace("\n", "\r\n")
+        open(tmp_path / f, "w", newline="").write(t)
+    got = mgcfd_mod.Mesh("input.dat", str(tmp_path))
+    for l in range(2):
+        for k in ("edges", "volumes", "coords"):
+            assert np.array_equal(got.level(l)[k], want.level(l)[k]), (l, k)
+    assert np.array_equal(got.level(0)["mg_map"], want.level(0)["mg_map"])
+    got.close()
+    crlf = tmp_path / "crlf"
+    shutil.copytree(src, crlf)
+    (crlf / "input.dat").write_bytes(open(os.path.join(src, "input.dat"), "rb").read().replace(b"\n", b"\r\n"))
+    with pytest.raises(mgcfd_mod.MgcfdError):
+        mgcfd_mod.Mesh("input.dat", str(crlf))
+    want.close()
+
+
 def test_dump_format_and_validation_rule(mgcfd_mod, tmp_path):
     lib = mgcfd_mod.load_library()
     a = np.array([[1.4, 1.68, 0.0, -1e-300, 3.508], [np.pi, -np.e, 1e22, 5e-324, 2.0]])

@@ -968,7 +968,9 @@ static void run_sweep(mgcfd_solver *s, int level)
     DeviceLevel &lv = s->level(level);
     const int64_t n = s->sweep_counter++;
     const bool timed = s->opt_timing == 1 || (s->opt_timing == 2 && (n % s->timing_stride) == 0);
-    const bool graphable = s->opt_graph && s->opt_fuse && !s->opt_indirect_rw && !timed && lv.fluxes_zero && !lv.fluxes_stale;
+    // (only the fused launches are replayed: the unfused ones — the two-phase flux variant — leave host-side flags
+    //  behind, fluxes_stale, that a replay would not set)
+    const bool graphable = s->opt_graph && s->opt_fuse && !(s->variant_for(lv) & 4) && !s->opt_indirect_rw && !timed && lv.fluxes_zero && !lv.fluxes_stale;
     if (!graphable) {
         const int keep = s->opt_timing;
         if (!timed) s->opt_timing = 0;
@@ -1183,7 +1185,7 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
             const int chunk = std::min(cycles - done, mgcfd_solver::kRmsRing);
             HIP_CHECK(hipMemsetAsync(s->rms_count, 0, sizeof(int), s->stream));
             bool graphable = s->opt_graph && s->opt_fuse && !s->opt_indirect_rw && s->opt_timing == 0;
-            for (auto &lv : s->L) graphable = graphable && lv.fluxes_zero && !lv.fluxes_stale;
+            for (auto &lv : s->L) graphable = graphable && lv.fluxes_zero && !lv.fluxes_stale && !(s->variant_for(lv) & 4);
             graphable = graphable && nl <= 8;               // the graph key holds 8 levels' buffer rotations
             if (graphable) {
                 // the whole cycle — every sweep and transfer of every level — as ONE graph replay.

@@ -490,6 +490,19 @@ def test_randomised_hierarchies(oracle, seed):
     s.close()
 
 
+@pytest.mark.parametrize("seed", [2, 7, 12, 22, 157, 159, 222, 392, 640, 901])
+def test_randomised_operation_sequences(seed):
+    """tools/fuzz_ops.py: kernel-granular calls, sweeps (plain, split around the collective hooks), cycles, transfers,
+    array writes and option changes in random order, mirrored call by call on the oracle; every array of every level is
+    compared bit for bit after every call.  1,100 seeds ran clean when this was written; 157, 159, 222 and 392 are the
+    ones that found a graph replay of UNFUSED sweeps (two-phase flux variant) leaving `fluxes` readable as non-zero."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_ops
+    log = fuzz_ops.run_seed(seed, 60)
+    assert len(log) >= 2
+
+
 def test_tiling_report_and_coordinate_box_fallback():
     """mgcfd_level_tiling: a lattice level keeps the greedy clusters (no halo node left outside the LDS tile); on a
     tetrahedral level those overflow, coordinate boxes are chosen instead, and few row entries are left to gather

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Randomised OPERATION sequences (GPU box): the kernel-granular calls, whole sweeps (plain and split around the
+collective hooks) and multigrid transfers in random order on a random hierarchy, mirrored call by call on the oracle;
+after every call every array of every level is compared bit for bit.  Aims at the solver's state machine (buffer
+rotation, step-factor look-ahead, lazily zeroed fluxes, option changes between calls), not at the arithmetic.
+    python tools/fuzz_ops.py [--seeds 30] [--first 0] [--ops 40]"""
+import argparse, ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd")); sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+
+ARRAYS = ("variables", "old_variables", "fluxes", "residuals", "step_factors")
+
+
+class Mirror:
+    """The reference's arrays of one hierarchy, driven through the oracle's kernels."""
+
+    def __init__(self, oracle, levels, mesh_variant):
+        self.o, self.lib, self.mv = oracle, oracle.load(), mesh_variant
+        self.ff = oracle.farfield()
+        self.L = []
+        for lv in levels:
+            edges = np.ascontiguousarray(lv["edges"]).copy()
+            coords = np.ascontiguousarray(lv["coords"], dtype=np.float64)
+            if mesh_variant != 0:
+                self.lib.ora_adjust_ewt(oracle.ptr(coords), len(edges), oracle.ptr(edges))
+                self.lib.ora_dampen_ewt(len(edges), oracle.ptr(edges), {2: 5e-8, 3: 1e-7, 4: 2e-7}[mesh_variant])
+            nel = lv["nel"]
+            st = {k: np.zeros((nel, 5)) for k in ARRAYS[:4]}
+            st["step_factors"] = np.zeros(nel)
+            st["variables"][:] = np.array(self.ff.var)
+            self.L.append(dict(nel=nel, edges=edges, coords=coords, vol=np.ascontiguousarray(lv["volumes"], dtype=np.float64),
+                               ni=lv["n_internal"], nb=lv["n_boundary"], nw=lv["n_wall"],
+                               map=None if lv.get("mg_map") is None else np.ascontiguousarray(lv["mg_map"], dtype=np.int64), **st))
+
+    def p(self, a):
+        return self.o.ptr(a)
+
+    def flux(self, l, classes=7):
+        L = self.L[l]
+        if classes & 1: self.lib.ora_compute_flux_edge(0, L["ni"], self.p(L["edges"]), self.p(L["variables"]), self.p(L["fluxes"]))
+        if classes & 2: self.lib.ora_compute_boundary_flux_edge(L["ni"], L["nb"], self.p(L["edges"]), self.p(L["variables"]), self.p(L["fluxes"]))
+        if classes & 4: self.lib.ora_compute_wall_flux_edge(L["ni"] + L["nb"], L["nw"], self.p(L["edges"]), self.p(L["variables"]), self.p(L["fluxes"]), C.byref(self.ff))
+
+    def step_factor(self, l):
+        L = self.L[l]
+        fn = self.lib.ora_compute_step_factor_legacy if self.mv == 0 else self.lib.ora_compute_step_factor
+        fn(L["nel"], self.p(L["variables"]), self.p(L["vol"]), self.p(L["step_factors"]))
+
+    def time_step(self, l, j):
+        L = self.L[l]
+        self.lib.ora_time_step(j, L["nel"], self.p(L["step_factors"]), self.p(L["fluxes"]), self.p(L["old_variables"]), self.p(L["variables"]))
+
+    def copy_old(self, l):
+        self.L[l]["old_variables"][:] = self.L[l]["variables"]
+
+    def residual(self, l):
+        L = self.L[l]
+        self.lib.ora_residual(L["nel"], self.p(L["old_variables"]), self.p(L["variables"]), self.p(L["residuals"]))
+
+    def sweep(self, l):                                     # euler3d_cpu_double.cpp:383-508
+        self.copy_old(l); self.step_factor(l)
+        for j in range(3):
+            self.flux(l); self.time_step(l, j)
+        self.residual(l)
+
+    def restrict(self, l):
+        F, Cc = self.L[l], self.L[l + 1]
+        scratch = np.zeros(max(x["nel"] for x in self.L), dtype=np.int64)
+        self.lib.ora_mg_restrict(self.p(F["variables"]), self.p(Cc["variables"]), Cc["nel"], self.p(F["map"]), self.p(scratch), len(F["map"]))
+
+    def prolong(self, l):
+        F, Cc = self.L[l], self.L[l + 1]
+        self.lib.ora_prolong_residuals_interpolate_proper(self.p(F["edges"]), F["ni"], self.p(Cc["residuals"]), self.p(F["residuals"]),
+                                                          self.p(F["variables"]), F["nel"], self.p(F["map"]), self.p(Cc["coords"]), self.p(F["coords"]))
+
+    def cycle(self):                                        # :371-694
+        n = len(self.L)
+        for l in range(n):
+            self.sweep(l)
+            if l + 1 < n: self.restrict(l)
+        for l in range(n - 2, -1, -1):
+            self.prolong(l)
+            if l > 0: self.sweep(l)
+
+
+def run_seed(seed, n_ops, verbose=False):
+    import mgcfd
+    import oracle_py as oracle
+    import fuzz_parity
+    from conftest import perturbed_state
+    rng = np.random.default_rng(1000 + seed)
+    while True:
+        kind, name, mg, _ = fuzz_parity.make_case(rng)
+        if max(l.nel for l in mg.levels) <= 4000:
+            break
+    levels = mgcfd.generated_to_levels(mg)
+    m = Mirror(oracle, levels, mg.mesh_variant)
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    nl = len(levels)
+    log = [f"{kind} {name} {[l.nel for l in mg.levels]}"]
+
+    def compare(tag):
+        for l in range(nl):
+            for a in ARRAYS:
+                got, want = s.get(l, a), m.L[l][a]
+                if not np.array_equal(got.view(np.int64), np.ascontiguousarray(want).view(np.int64)):
+                    bad = np.argwhere(got.view(np.int64) != np.ascontiguousarray(want).view(np.int64))[0]
+                    raise AssertionError(f"seed {seed}: after {tag}: level {l} {a} differs first at {tuple(bad)} (got {got[tuple(bad)]!r}, want {want[tuple(bad)]!r})\n  " + "\n  ".join(log))
+
+    # a developed, non-uniform start
+    for l in range(nl):
+        q = perturbed_state(m.L[l]["nel"], np.array(m.ff.var), seed=seed * 7 + l)
+        s.set(l, "variables", q); m.L[l]["variables"][:] = q
+    compare("set")
+    for k in range(n_ops):
+        l = int(rng.integers(nl))
+        op = str(rng.choice(["sweep", "sweep", "cycle", "flux", "flux_parts", "time_step", "step_factor", "copy_old", "residual", "restrict",
+                             "prolong", "zero", "set", "option", "split_sweep", "sweeps3", "get_only"]))
+        if op == "sweep":
+            s.smooth(l, 1); m.sweep(l)
+        elif op == "sweeps3":
+            s.smooth(l, 3); [m.sweep(l) for _ in range(3)]
+        elif op == "cycle":
+            try:
+                s.run_cycles(1)
+            except mgcfd.MgcfdError as e:
+                # check_for_invalid_variables fired inside the cycle: the reference would have exited there; the
+                # mirror (which runs the cycle to its end) must have gone through an invalid state as well
+                if e.code not in (4, 5, 6):
+                    raise
+                m.cycle()
+                bad = C.c_int64(-1)
+                if all(m.lib.ora_check_for_invalid_variables(m.p(x["variables"]), x["nel"], C.byref(bad)) == 0 for x in m.L):
+                    raise AssertionError(f"seed {seed}: the library reported {e} but the oracle's state is valid\n  " + "\n  ".join(log))
+                log.append(f"{k}: cycle went invalid on both sides: stop")
+                break
+            m.cycle()
+        elif op == "flux":
+            s.compute_fluxes(l); m.flux(l)
+        elif op == "flux_parts":
+            order = rng.permutation(3)
+            for c in order:
+                [s.compute_flux_edge, s.compute_boundary_flux_edge, s.compute_wall_flux_edge][c](l); m.flux(l, 1 << int(c))
+        elif op == "time_step":
+            j = int(rng.integers(3)); s.time_step(l, j); m.time_step(l, j)
+        elif op == "step_factor":
+            s.compute_step_factor(l); m.step_factor(l)
+        elif op == "copy_old":
+            s.copy_old_variables(l); m.copy_old(l)
+        elif op == "residual":
+            s.residual(l); m.residual(l)
+        elif op == "restrict":
+            if l + 1 >= nl: continue
+            s.restrict(l); m.restrict(l)
+        elif op == "prolong":
+            if l + 1 >= nl: continue
+            s.prolong(l); m.prolong(l)
+        elif op == "zero":
+            s.zero_fluxes(l); m.L[l]["fluxes"][:] = 0.0
+        elif op == "set":
+            a = str(rng.choice(["variables", "fluxes", "old_variables", "residuals"]))
+            v = m.L[l][a] * (1.0 + 1e-3 * rng.uniform(-1, 1, m.L[l][a].shape)) if a != "fluxes" else rng.normal(size=(m.L[l]["nel"], 5)) * 1e-9
+            s.set(l, a, v); m.L[l][a][:] = v
+        elif op == "option":
+            name_, val = [("fuse_update", int(rng.integers(2))), ("graph", int(rng.integers(2))), ("flux_variant", int(rng.choice([-1, 0, 1, 2, 3, 4]))),
+                          ("check_invalid", int(rng.integers(2)))][int(rng.integers(4))]
+            s.set_option(name_, val); op = f"option {name_}={val}"
+        elif op == "split_sweep":
+            if not np.all(m.L[l]["fluxes"] == 0.0): continue        # (sweep_begin wants zero fluxes, as after time_step)
+            partials = bool(rng.integers(2)) and mg.mesh_variant != 0
+            (s.sweep_begin_partials if partials else s.sweep_begin)(l)
+            if rng.integers(2): s.sweep_flux0(l)
+            (s.sweep_end_partials if partials else s.sweep_end)(l)
+            m.sweep(l)
+        log.append(f"{k}: {op} level {l}")
+        if verbose: print(log[-1], flush=True)
+        # a state that went invalid ends the sequence (the reference would have exited)
+        if any(not np.isfinite(m.L[x]["variables"]).all() or (m.L[x]["variables"][:, 0] <= 0).any() or (m.L[x]["variables"][:, 4] <= 0).any() for x in range(nl)):
+            log.append("state invalid: stop")
+            break
+        compare(op)
+    s.close()
+    return log
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=30)
+    ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--ops", type=int, default=40)
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+    bad = 0
+    for seed in range(args.first, args.first + args.seeds):
+        try:
+            log = run_seed(seed, args.ops, args.verbose)
+            print(f"seed {seed}: {log[0]}: {len(log) - 1} ops ok", flush=True)
+        except AssertionError as e:
+            print(str(e), flush=True)
+            bad += 1
+    print("mismatching seeds:", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

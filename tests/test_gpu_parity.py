@@ -494,13 +494,37 @@ def test_randomised_hierarchies(oracle, seed):
 def test_randomised_operation_sequences(seed):
     """tools/fuzz_ops.py: kernel-granular calls, sweeps (plain, split around the collective hooks), cycles, transfers,
     array writes and option changes in random order, mirrored call by call on the oracle; every array of every level is
-    compared bit for bit after every call.  1,100 seeds ran clean when this was written; 157, 159, 222 and 392 are the
-    ones that found a graph replay of UNFUSED sweeps (two-phase flux variant) leaving `fluxes` readable as non-zero."""
+    compared bit for bit after every call.  1,600 seeds ran clean when this was written (an earlier version of the
+    generator found the bug test_graph_replay_never_covers_unfused_sweeps pins)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_ops
     log = fuzz_ops.run_seed(seed, 60)
     assert len(log) >= 2
+
+
+def test_graph_replay_never_covers_unfused_sweeps(mesh3_dir):
+    """MGCFD_OPT_GRAPH=1 with the two-phase flux variant (whose sweeps run unfused): a replayed sweep used to leave the
+    host-side "fluxes are stale" flag unset, so mgcfd_get_array(fluxes) returned the last stage's fluxes instead of
+    the zeros time_step leaves (cfd_loops.cpp:266-268).  Sweeps and cycles, several replays each."""
+    import mgcfd
+    want = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", mesh3_dir))
+    s = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", mesh3_dir))
+    s.set_option("graph", 1)
+    s.set_option("flux_variant", 4)
+    q = perturbed_state(s.nel(0), s.far_field()[:5], seed=3)
+    for x in (s, want):
+        x.set(0, "variables", q)
+    for k in range(4):
+        s.smooth(0, 1); want.smooth(0, 1)
+        assert not s.get(0, "fluxes").any(), f"sweep {k}"
+        assert np.array_equal(s.get(0, "variables").view(np.int64), want.get(0, "variables").view(np.int64))
+    for k in range(3):
+        s.run_cycles(1); want.run_cycles(1)
+        for l in range(s.num_levels):
+            assert not s.get(l, "fluxes").any(), f"cycle {k} level {l}"
+            assert np.array_equal(s.get(l, "variables").view(np.int64), want.get(l, "variables").view(np.int64))
+    s.close(); want.close()
 
 
 def test_tiling_report_and_coordinate_box_fallback():

@@ -62,7 +62,7 @@ class Mirror:
     def sweep(self, l):                                     # euler3d_cpu_double.cpp:383-508
         self.copy_old(l); self.step_factor(l)
         for j in range(3):
-            self.flux(l); self.time_step(l, j)
+            self.flux(l); self.time_step(l, j)              # (the indirect_rw probe + zero_fluxes that may follow change nothing)
         self.residual(l)
 
     def restrict(self, l):
@@ -99,6 +99,7 @@ def run_seed(seed, n_ops, verbose=False):
     m = Mirror(oracle, levels, mg.mesh_variant)
     s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
     nl = len(levels)
+    indirect = [0]
     log = [f"{kind} {name} {[l.nel for l in mg.levels]}"]
 
     def compare(tag):
@@ -117,7 +118,8 @@ def run_seed(seed, n_ops, verbose=False):
     for k in range(n_ops):
         l = int(rng.integers(nl))
         op = str(rng.choice(["sweep", "sweep", "cycle", "flux", "flux_parts", "time_step", "step_factor", "copy_old", "residual", "restrict",
-                             "prolong", "zero", "set", "option", "split_sweep", "sweeps3", "get_only"]))
+                             "prolong", "zero", "set", "option", "split_sweep", "sweeps3", "get_only", "indirect_rw", "rms", "step_factor_split",
+                             "cycles2", "check"]))
         if op == "sweep":
             s.smooth(l, 1); m.sweep(l)
         elif op == "sweeps3":
@@ -137,6 +139,32 @@ def run_seed(seed, n_ops, verbose=False):
                 log.append(f"{k}: cycle went invalid on both sides: stop")
                 break
             m.cycle()
+        elif op == "indirect_rw":
+            L = m.L[l]
+            s.indirect_rw(l); m.lib.ora_indirect_rw(0, L["ni"], m.p(L["edges"]), m.p(L["variables"]), m.p(L["fluxes"]))
+        elif op == "rms":
+            L = m.L[l]
+            got, want = s.calc_rms(l), m.lib.ora_calc_rms(L["nel"], m.p(L["residuals"]))
+            if not (abs(got - want) <= 1e-12 * abs(want) or got == want):
+                raise AssertionError(f"seed {seed}: calc_rms level {l}: {got!r} vs {want!r}\n  " + "\n  ".join(log))
+        elif op == "check":
+            L = m.L[l]
+            bad = C.c_int64(-1)
+            want = m.lib.ora_check_for_invalid_variables(m.p(L["variables"]), L["nel"], C.byref(bad))
+            got = s.check_for_invalid_variables(l)
+            if (got[0] != 0) != (want != 0) or (want != 0 and got[1] != bad.value):
+                raise AssertionError(f"seed {seed}: check_for_invalid_variables level {l}: {got} vs ({want}, {bad.value})\n  " + "\n  ".join(log))
+        elif op == "step_factor_split":
+            if mg.mesh_variant == 0: continue               # (the two halves exist for the global time step only)
+            s.step_factor_local(l); s.step_factor_apply(l); m.step_factor(l)
+        elif op == "cycles2":
+            try:
+                s.run_cycles(2)
+            except mgcfd.MgcfdError as e:
+                if e.code not in (4, 5, 6): raise
+                log.append(f"{k}: cycles went invalid: stop")
+                break
+            m.cycle(); m.cycle()
         elif op == "flux":
             s.compute_fluxes(l); m.flux(l)
         elif op == "flux_parts":
@@ -165,7 +193,8 @@ def run_seed(seed, n_ops, verbose=False):
             s.set(l, a, v); m.L[l][a][:] = v
         elif op == "option":
             name_, val = [("fuse_update", int(rng.integers(2))), ("graph", int(rng.integers(2))), ("flux_variant", int(rng.choice([-1, 0, 1, 2, 3, 4]))),
-                          ("check_invalid", int(rng.integers(2)))][int(rng.integers(4))]
+                          ("check_invalid", int(rng.integers(2))), ("indirect_rw", int(rng.integers(2))), ("timing", int(rng.integers(3)))][int(rng.integers(6))]
+            if name_ == "indirect_rw": indirect[0] = val
             s.set_option(name_, val); op = f"option {name_}={val}"
         elif op == "split_sweep":
             if not np.all(m.L[l]["fluxes"] == 0.0): continue        # (sweep_begin wants zero fluxes, as after time_step)

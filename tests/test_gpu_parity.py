@@ -891,14 +891,24 @@ def test_partitioned_level_with_halo_exchange_equals_whole_mesh(variant, n_parts
         mg = meshgen.MultigridMesh(mesh_name="m6wing", levels=[meshgen.make_random_graph_level(2500, degree=8, seed=6)])
     else:
         mg = meshgen.make_multigrid((14,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    _partitioned_level_check(mg, variant, n_parts, partitioner, fused)
+
+
+def _partitioned_level_check(mg, variant, n_parts, partitioner, fused, sweeps=3, seed=9):
+    """Level 0 of `mg` split into n_parts solvers on this GPU against the unpartitioned run (see the test above)."""
+    import threading
+    import torch
+    import mgcfd
+    from mgcfd.distributed import HipSolverAdapter, PartitionedSweep
+    from mgcfd.partition import partition_level, rcb_partition, slab_partition
+    dev = torch.device("cuda", 0)
     L = mgcfd.generated_to_levels(mg)[0]
-    sweeps = 3
     split = slab_partition if partitioner == "slab" else rcb_partition
     parts = partition_level(L, split(np.asarray(L["coords"]), n_parts))
-    assert sum(p.n_owned for p in parts) == L["nel"] and all(p.send and p.recv for p in parts)
+    assert sum(p.n_owned for p in parts) == L["nel"]
 
     whole = mgcfd.Solver.from_arrays([L], mg.mesh_variant)
-    q0 = perturbed_state(L["nel"], whole.far_field()[:5], seed=9)
+    q0 = perturbed_state(L["nel"], whole.far_field()[:5], seed=seed)
     whole.set(0, "variables", q0)
     whole.set_option("fuse_update", 0)
     whole.smooth(0, sweeps)

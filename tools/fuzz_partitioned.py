@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Randomised partitioned-level sweep (GPU box): a random level (lattice, tetrahedra, hub, random graph) split into
+2-5 parts by a random partitioner, every part a solver of its own on this GPU with ghost nodes and halo exchanges after
+every Runge-Kutta stage (tests/test_gpu_parity.py: _partitioned_level_check), against the unpartitioned run, bit for bit.
+    python tools/fuzz_partitioned.py [--seeds 40] [--first 0]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd")); sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=40)
+    ap.add_argument("--first", type=int, default=0)
+    args = ap.parse_args()
+    import numpy as np
+    from mgcfd import meshgen
+    import fuzz_parity
+    import test_gpu_parity as T
+    bad = 0
+    for seed in range(args.first, args.first + args.seeds):
+        rng = np.random.default_rng(5000 + seed)
+        while True:
+            kind, name, mg, _ = fuzz_parity.make_case(rng)
+            if name != "fvcorr" and 20 <= mg.levels[0].nel <= 5000:        # (global time step; the helper assumes it)
+                break
+        mg.levels = mg.levels[:1]
+        mg.levels[0].mg_map = None
+        n_parts = int(rng.integers(2, 6))
+        partitioner = str(rng.choice(["slab", "rcb"]))
+        fused = bool(rng.integers(2))
+        variant = int(rng.choice([-1, 0, 1, 2, 3]))
+        tag = f"seed {seed}: {kind} {name} {mg.levels[0].nel} nodes, {n_parts} parts ({partitioner}), fused={fused}, variant={variant}"
+        try:
+            T._partitioned_level_check(mg, variant, n_parts, partitioner, fused, sweeps=int(rng.integers(1, 4)), seed=seed)
+            print(tag + ": ok", flush=True)
+        except AssertionError as e:
+            print(tag + ": MISMATCH " + str(e)[:200], flush=True)
+            bad += 1
+    print("mismatches:", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -988,12 +988,21 @@ def test_partitioned_hierarchy_vcycles_equal_whole_mesh(sizes, n_parts, fused):
     from mgcfd import meshgen
     from mgcfd.distributed import HipSolverAdapter, PartitionedCycle
     from mgcfd.partition import partition_hierarchy, rcb_partition
-    dev = torch.device("cuda", 0)
-    cycles = 3
     if sizes[0] >= 100:
         mg = meshgen.make_tet_multigrid(sizes, "m6wing", seed=4)
     else:
         mg = meshgen.make_multigrid(sizes, "m6wing", seed=4, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    _partitioned_hierarchy_check(mg, n_parts, fused)
+
+
+def _partitioned_hierarchy_check(mg, n_parts, fused, cycles=3):
+    """The hierarchy `mg` split over n_parts solvers on this GPU against mgcfd_run_cycles on the whole (see the test above)."""
+    import threading
+    import torch
+    import mgcfd
+    from mgcfd.distributed import HipSolverAdapter, PartitionedCycle
+    from mgcfd.partition import partition_hierarchy, rcb_partition
+    dev = torch.device("cuda", 0)
     levels = mgcfd.generated_to_levels(mg)
     whole = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
     whole.run_cycles(cycles)

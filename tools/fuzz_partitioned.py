@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised partitioned-level sweep (GPU box): a random level (lattice, tetrahedra, hub, random graph) split into
+"""Randomised partitioned-level / partitioned-hierarchy sweep (GPU box): a random level (lattice, tetrahedra, hub, random graph) split into
 2-5 parts by a random partitioner, every part a solver of its own on this GPU with ghost nodes and halo exchanges after
 every Runge-Kutta stage (tests/test_gpu_parity.py: _partitioned_level_check), against the unpartitioned run, bit for bit.
     python tools/fuzz_partitioned.py [--seeds 40] [--first 0]"""
@@ -25,6 +25,11 @@ def main():
             kind, name, mg, _ = fuzz_parity.make_case(rng)
             if name != "fvcorr" and 20 <= mg.levels[0].nel <= 5000:        # (global time step; the helper assumes it)
                 break
+        # the whole hierarchy too (multigrid cycles over the partitions) where the generator made one with coarser levels smaller
+        hier = None
+        if len(mg.levels) > 1 and all(mg.levels[k + 1].nel < mg.levels[k].nel for k in range(len(mg.levels) - 1)) and mg.levels[-1].nel >= 8:
+            import copy
+            hier = copy.deepcopy(mg)
         mg.levels = mg.levels[:1]
         mg.levels[0].mg_map = None
         n_parts = int(rng.integers(2, 6))
@@ -33,8 +38,10 @@ def main():
         variant = int(rng.choice([-1, 0, 1, 2, 3]))
         tag = f"seed {seed}: {kind} {name} {mg.levels[0].nel} nodes, {n_parts} parts ({partitioner}), fused={fused}, variant={variant}"
         try:
+            if hier is not None:
+                T._partitioned_hierarchy_check(hier, n_parts, fused, cycles=int(rng.integers(1, 4)))
             T._partitioned_level_check(mg, variant, n_parts, partitioner, fused, sweeps=int(rng.integers(1, 4)), seed=seed)
-            print(tag + ": ok", flush=True)
+            print(tag + (f" + hierarchy {[l.nel for l in hier.levels]}" if hier is not None else "") + ": ok", flush=True)
         except AssertionError as e:
             print(tag + ": MISMATCH " + str(e)[:200], flush=True)
             bad += 1

@@ -669,6 +669,17 @@ def test_driver_aborts_like_the_reference_binary(case, extra, tmp_path):
     assert "Total runtime" not in r.stdout
 
 
+def test_driver_randomised_inputs_and_flags():
+    """tools/fuzz_driver.py: random hierarchies written in the reference's file formats, the drop-in binary with random
+    -g / -m / --no-timers / --no-indirect-rw / --legacy-ordering, against the oracle reading the same files (dump bit
+    for bit, RMS lines, LoopNumIters).  Six of its seeds."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_driver
+    assert fuzz_driver.run_seeds(0, 3) == 0
+    assert fuzz_driver.run_seeds(40, 3) == 0
+
+
 def test_driver_legacy_ordering_reproduces_reference_built_with_that_flag(tmp_path):
     """--legacy-ordering == the reference compiled with -DLEGACY_ORDERING (src/Base/io.cpp:183-193): byte-identical
     dump; and the Python binding's Mesh(legacy_ordering=True) hands back the sorted edges."""

@@ -10,62 +10,74 @@ sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join
 EXE = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seeds", type=int, default=40)
-    ap.add_argument("--first", type=int, default=0)
-    args = ap.parse_args()
+def _one(seed, np, meshgen, oracle, fuzz_parity, read_loop_iters):
+    bad = 0
+    rng = np.random.default_rng(9000 + seed)
+    while True:
+        kind, name, mg, _ = fuzz_parity.make_case(rng)
+        # the file format lists a level's coarser neighbour by index: keep hierarchies the reference itself accepts
+        if max(l.nel for l in mg.levels) <= 3000 and all(mg.levels[k + 1].nel <= mg.levels[k].nel for k in range(len(mg.levels) - 1)):
+            break
+    d = tempfile.mkdtemp(prefix="mgcfd_fuzz_")
+    try:
+        meshgen.write_input(mg, d)
+        cycles = int(rng.integers(1, 5))
+        dup = int(rng.choice([1, 1, 2, 3]))
+        legacy = bool(rng.integers(2)) and dup == 1
+        flags = [f for f, on in (("--no-timers", rng.integers(2)), ("--no-indirect-rw", rng.integers(2))) if on]
+        cmd = [EXE, "-i", "input.dat", "-d", d, "-o", d + "/", "-g", str(cycles), "-m", str(dup), "--output-variables"] + flags + (["--legacy-ordering"] if legacy else [])
+        tag = f"seed {seed}: {kind} {name} {[l.nel for l in mg.levels]} -g {cycles} -m {dup} {' '.join(flags)}{' --legacy-ordering' if legacy else ''}"
+        oc = oracle.OracleCase.from_input_dat(os.path.join(d, "input.dat"), dup, legacy_ordering=legacy)
+        rc, rms, iters = oc.solve(cycles, run_indirect_rw=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if rc != 0:
+            ok = r.returncode == 1 and "ERROR:" in r.stdout
+            print(tag + (": both abort: ok" if ok else f": MISMATCH (oracle aborts with {rc}, driver rc {r.returncode})"), flush=True)
+            bad += 0 if ok else 1
+            return bad
+        problems = []
+        if r.returncode != 0:
+            problems.append(f"driver rc {r.returncode}: {r.stdout[-200:]}")
+        else:
+            got = np.loadtxt(os.path.join(d, f"variables.size={dup}x.cycles={cycles}.level=0")).reshape(-1, 5)
+            want = oc.array(0, "variables").reshape(-1, 5)
+            if not np.array_equal(got.view(np.int64), np.ascontiguousarray(want).view(np.int64)):
+                problems.append("variables dump differs")
+            lines = [l for l in r.stdout.splitlines() if "RMS" in l]
+            if len(lines) != cycles or any(f"(RMS = {rms[c]:.3e})" not in lines[c] for c in range(cycles)):
+                problems.append("RMS lines differ")
+            got_it = read_loop_iters(os.path.join(d, "LoopNumIters.csv"), oc.nlevels)
+            for l in range(oc.nlevels):
+                want_it = {"flux": iters[l].flux, "update": 0, "compute_step": iters[l].compute_step, "time_step": iters[l].time_step,
+                           "restrict": iters[l].restrict_, "prolong": iters[l].prolong}
+                if {k: got_it[l][k] for k in want_it} != want_it:
+                    problems.append(f"LoopNumIters level {l}: {got_it[l]} vs {want_it}")
+        print(tag + (": ok" if not problems else ": MISMATCH " + "; ".join(problems)), flush=True)
+        bad += 1 if problems else 0
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return bad
+
+
+def run_seeds(first, count):
+    """Returns the number of mismatching seeds (prints one line per seed)."""
     import numpy as np
     from mgcfd import meshgen
     import oracle_py as oracle
     import fuzz_parity
     from test_oracle_golden import read_loop_iters
     bad = 0
-    for seed in range(args.first, args.first + args.seeds):
-        rng = np.random.default_rng(9000 + seed)
-        while True:
-            kind, name, mg, _ = fuzz_parity.make_case(rng)
-            # the file format lists a level's coarser neighbour by index: keep hierarchies the reference itself accepts
-            if max(l.nel for l in mg.levels) <= 3000 and all(mg.levels[k + 1].nel <= mg.levels[k].nel for k in range(len(mg.levels) - 1)):
-                break
-        d = tempfile.mkdtemp(prefix="mgcfd_fuzz_")
-        try:
-            meshgen.write_input(mg, d)
-            cycles = int(rng.integers(1, 5))
-            dup = int(rng.choice([1, 1, 2, 3]))
-            legacy = bool(rng.integers(2)) and dup == 1
-            flags = [f for f, on in (("--no-timers", rng.integers(2)), ("--no-indirect-rw", rng.integers(2))) if on]
-            cmd = [EXE, "-i", "input.dat", "-d", d, "-o", d + "/", "-g", str(cycles), "-m", str(dup), "--output-variables"] + flags + (["--legacy-ordering"] if legacy else [])
-            tag = f"seed {seed}: {kind} {name} {[l.nel for l in mg.levels]} -g {cycles} -m {dup} {' '.join(flags)}{' --legacy-ordering' if legacy else ''}"
-            oc = oracle.OracleCase.from_input_dat(os.path.join(d, "input.dat"), dup, legacy_ordering=legacy)
-            rc, rms, iters = oc.solve(cycles, run_indirect_rw=True)
-            r = subprocess.run(cmd, capture_output=True, text=True)
-            if rc != 0:
-                ok = r.returncode == 1 and "ERROR:" in r.stdout
-                print(tag + (": both abort: ok" if ok else f": MISMATCH (oracle aborts with {rc}, driver rc {r.returncode})"), flush=True)
-                bad += 0 if ok else 1
-                continue
-            problems = []
-            if r.returncode != 0:
-                problems.append(f"driver rc {r.returncode}: {r.stdout[-200:]}")
-            else:
-                got = np.loadtxt(os.path.join(d, f"variables.size={dup}x.cycles={cycles}.level=0")).reshape(-1, 5)
-                want = oc.array(0, "variables").reshape(-1, 5)
-                if not np.array_equal(got.view(np.int64), np.ascontiguousarray(want).view(np.int64)):
-                    problems.append("variables dump differs")
-                lines = [l for l in r.stdout.splitlines() if "RMS" in l]
-                if len(lines) != cycles or any(f"(RMS = {rms[c]:.3e})" not in lines[c] for c in range(cycles)):
-                    problems.append("RMS lines differ")
-                got_it = read_loop_iters(os.path.join(d, "LoopNumIters.csv"), oc.nlevels)
-                for l in range(oc.nlevels):
-                    want_it = {"flux": iters[l].flux, "update": 0, "compute_step": iters[l].compute_step, "time_step": iters[l].time_step,
-                               "restrict": iters[l].restrict_, "prolong": iters[l].prolong}
-                    if {k: got_it[l][k] for k in want_it} != want_it:
-                        problems.append(f"LoopNumIters level {l}: {got_it[l]} vs {want_it}")
-            print(tag + (": ok" if not problems else ": MISMATCH " + "; ".join(problems)), flush=True)
-            bad += 1 if problems else 0
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
+    for seed in range(first, first + count):
+        bad += _one(seed, np, meshgen, oracle, fuzz_parity, read_loop_iters)
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=40)
+    ap.add_argument("--first", type=int, default=0)
+    args = ap.parse_args()
+    bad = run_seeds(args.first, args.seeds)
     print("mismatches:", bad)
     sys.exit(1 if bad else 0)
 

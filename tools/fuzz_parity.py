@@ -46,6 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--fast", action="store_true", help="MGCFD_OPT_EXACT=0 (FMA contraction): compare by the reference's -v tolerance rule instead of bit for bit")
     args = ap.parse_args()
     import numpy as np
     import mgcfd
@@ -65,8 +66,16 @@ def main():
         s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
         for k, v in opts.items():
             s.set_option(k, v)
+        if args.fast:
+            s.set_option("exact", 0)
         rms = s.run_cycles(cycles)
-        ok = all(np.array_equal(s.get(l, "variables").view(np.int64), want[l].view(np.int64)) for l in range(len(levels)))
+        if args.fast:
+            # the reference's own -v tolerance rule (validation.cpp:140-199): -1 = no value out of tolerance
+            lib = oracle.load()
+            ok = all(lib.ora_identify_differences(oracle.ptr(np.ascontiguousarray(s.get(l, "variables"))), oracle.ptr(np.ascontiguousarray(want[l])),
+                                                  levels[l]["nel"], mg.mesh_variant) == -1 for l in range(len(levels)))
+        else:
+            ok = all(np.array_equal(s.get(l, "variables").view(np.int64), want[l].view(np.int64)) for l in range(len(levels)))
         ok = ok and np.allclose(rms, want_rms, rtol=1e-12, atol=1e-300)
         t = s.tiling(0)
         s.close()

@@ -123,13 +123,19 @@ class OracleCase:
         self.nlevels = 0
 
     @classmethod
-    def from_files(cls, level_paths, map_paths, mesh_variant: int, duplicate: int = 1, legacy_ordering: bool = False) -> "OracleCase":
+    def from_files(cls, level_paths, map_paths, mesh_variant: int, duplicate: int = 1, legacy_ordering: bool = False,
+                   coords_as_reference: bool = False) -> "OracleCase":
+        """coords_as_reference: read <mesh>.coords only when there is more than one level, exactly as the reference does
+        (src/Base/io.cpp:49-54,77-81) — a single-level m6wing / la_cascade / rotor37 input then has all-zero coordinates,
+        adjust_ewt divides by a zero distance and the run aborts with NaN, as the reference binary's does.  Default: also
+        read the file when it exists (what the library does), so such inputs can be used."""
         self = cls(mesh_variant)
         n = len(level_paths)
         self.nlevels = n
         self.levels = (OraLevel * n)()
         for l, p in enumerate(level_paths):
-            rc = self.lib.ora_read_grid(p.encode(), mesh_variant, 1 if (n > 1 or os.path.exists(p + ".coords")) else 0,
+            rc = self.lib.ora_read_grid(p.encode(), mesh_variant,
+                                        1 if (n > 1 or (not coords_as_reference and os.path.exists(p + ".coords"))) else 0,
                                         C.byref(self.levels[l]))
             if rc:
                 raise RuntimeError(f"ora_read_grid({p}) failed rc={rc}")
@@ -152,12 +158,13 @@ class OracleCase:
         return self
 
     @classmethod
-    def from_input_dat(cls, dat_path: str, duplicate: int = 1, legacy_ordering: bool = False) -> "OracleCase":
+    def from_input_dat(cls, dat_path: str, duplicate: int = 1, legacy_ordering: bool = False,
+                       coords_as_reference: bool = False) -> "OracleCase":
         info = parse_input_dat(dat_path)
         d = os.path.dirname(dat_path)
         return cls.from_files([os.path.join(d, p) for p in info["levels"]],
                               [os.path.join(d, p) for p in info["mg_mapping"]],
-                              info["mesh_variant"], duplicate, legacy_ordering)
+                              info["mesh_variant"], duplicate, legacy_ordering, coords_as_reference)
 
     # -- array views (owned by the C side) --
     def edges(self, l):

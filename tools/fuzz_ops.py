@@ -59,10 +59,11 @@ class Mirror:
         L = self.L[l]
         self.lib.ora_residual(L["nel"], self.p(L["old_variables"]), self.p(L["variables"]), self.p(L["residuals"]))
 
-    def sweep(self, l):                                     # euler3d_cpu_double.cpp:383-508
+    def sweep(self, l, after_stage=None):                   # euler3d_cpu_double.cpp:383-508
         self.copy_old(l); self.step_factor(l)
         for j in range(3):
             self.flux(l); self.time_step(l, j)              # (the indirect_rw probe + zero_fluxes that may follow change nothing)
+            if after_stage: after_stage(j)
         self.residual(l)
 
     def restrict(self, l):
@@ -119,7 +120,7 @@ def run_seed(seed, n_ops, verbose=False):
         l = int(rng.integers(nl))
         op = str(rng.choice(["sweep", "sweep", "cycle", "flux", "flux_parts", "time_step", "step_factor", "copy_old", "residual", "restrict",
                              "prolong", "zero", "set", "option", "split_sweep", "sweeps3", "get_only", "indirect_rw", "rms", "step_factor_split",
-                             "cycles2", "check"]))
+                             "cycles2", "check", "staged_sweep"]))
         if op == "sweep":
             s.smooth(l, 1); m.sweep(l)
         elif op == "sweeps3":
@@ -165,6 +166,19 @@ def run_seed(seed, n_ops, verbose=False):
                 log.append(f"{k}: cycles went invalid: stop")
                 break
             m.cycle(); m.cycle()
+        elif op == "staged_sweep":
+            # the sweep one Runge-Kutta stage per call (mgcfd_sweep_stage, the form a partitioned level uses): after every
+            # stage MGCFD_ARR_STAGE must hold what the reference's variables hold at that point
+            if not np.all(m.L[l]["fluxes"] == 0.0): continue
+            partials = bool(rng.integers(2)) and mg.mesh_variant != 0
+            (s.sweep_begin_partials if partials else s.sweep_begin)(l)
+            stages = []
+            m.sweep(l, after_stage=lambda j: stages.append(m.L[l]["variables"].copy()))
+            for j in range(3):
+                s.sweep_stage(l, j, partials)
+                got = s.get(l, "stage")
+                if not np.array_equal(got.view(np.int64), stages[j].view(np.int64)):
+                    raise AssertionError(f"seed {seed}: staged sweep level {l}: MGCFD_ARR_STAGE after stage {j} differs\n  " + "\n  ".join(log))
         elif op == "flux":
             s.compute_fluxes(l); m.flux(l)
         elif op == "flux_parts":

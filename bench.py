@@ -1,40 +1,52 @@
 #!/usr/bin/env python3
-"""bench.py — MG-CFD hot path on MI355X: Medges/s of the edge-flux sweep.
+"""bench.py — MG-CFD hot path on MI355X: Medges/s of compute_flux_edge + wall seconds per MG V-cycle.
 
 Contract (one JSON line on rank 0):
   python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+      N = 1: runs in this process.
+      N > 1 and no WORLD_SIZE in the environment: bench.py starts N child ranks itself (a fresh
+              `python -m torch.distributed.run --nproc-per-node N ... bench.py <same flags>` child process — never a
+              re-exec of a process that has touched the GPU), relays the child's JSON line and exits with its code;
+              fewer than N visible GPUs is an error (exit 2), never a silent one-rank run.
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (what the driver does for N > 1)
+      every rank checks WORLD_SIZE == --gpus and refuses to run otherwise.
 
-Workload (BASELINE.json configs[1]): "Onera-M6 L0 only, flux+update kernels only, no MG".
-The dataset release is not available, so the M6-L0-like synthetic mesh of SURVEY.md §8d cfg2
-is used: a 67^3 jittered lattice (300,763 nodes / 888,822 internal edges) with randomly
-permuted node ids, mesh_name = m6wing (adjust + dampen 5e-8), state = far field with +-1 %
-uniform noise (seed 1234).  One STEP = one smoothing sweep on that level, exactly the
-per-level body of the reference's cycle loop (src/euler3d_cpu_double.cpp:383-508):
-  copy old <- variables; compute_step_factor; 3 x [compute_flux_edge + boundary + wall fluxes,
-  time_step]; residual.
-value = internal edges pushed through compute_flux_edge (3 per step per rank) / wall time of
-the K timed steps, max over ranks, summed over ranks (weak scaling: every rank owns one mesh
-copy, coupled through the global-min time step exactly like the reference's -m duplication:
-one all-reduce(MIN) of one fp64 per sweep over RCCL).
+Workloads (--workload; `auto` = level0 at N = 1, partitioned at N > 1):
+  level0         BASELINE.json configs[1], "Onera-M6 L0 only, flux+update kernels only, no MG", in the synthetic form of
+                 SURVEY.md §8d cfg2 (the dataset release is not available): a 67^3 jittered lattice (300,763 nodes /
+                 888,822 internal edges), node ids randomly permuted, mesh_name = m6wing, state = far field +-1 % noise.
+                 One STEP = one smoothing sweep on that level, the per-level body of the reference's cycle loop
+                 (src/euler3d_cpu_double.cpp:383-508): copy, compute_step_factor, 3 x [fluxes, time_step], residual.
+                 The same process then measures the second half of BASELINE's metric, wall seconds per 4-level V-cycle
+                 (configs[2]; `vcycle` in the JSON line; --no-vcycle skips it, e.g. under rocprofv3).
+  partitioned    configs[4]: the level tiled 8x (134^3 lattice = 2.4 M nodes / 7.2 M edges, connected), split over the
+                 N ranks by recursive coordinate bisection; every rank sweeps its owned nodes with one fused launch per
+                 Runge-Kutta stage, a halo message to every neighbouring rank after each stage (RCCL point-to-point
+                 over xGMI) and one all-reduce(MIN) of the time step per sweep.  Total work fixed: "scaling": "strong".
+  copies         the reference's own -m N mesh duplication (src/Base/io_enhanced.cpp:89-201): one level0 mesh per rank,
+                 coupled only by the global-min time step (src/Kernels/cfd_loops.cpp:137-150).  "scaling": "weak".
+  level-per-gpu  configs[3]: the 4-level hierarchy with level l on rank l % N; a STEP is one V-cycle; restricted
+                 variables / coarse residuals move between ranks as whole-array RCCL point-to-point messages.
 
-roofline: the dominant kernel, k_flux_tile — in the sweep it is launched as one whole
-Runge-Kutta stage (fluxes of all three edge classes + time_step), so one launch carries the
-ALGORITHMIC bytes of both loops it replaces: 40*E + 80*N (compute_flux_edge) + 168*N (time_step)
-(SURVEY.md §8d).  Its mean duration is measured with hipEvent pairs on the launch stream during
-the timed region (every 8th sweep runs eagerly with one pair around its three stage launches;
-the other sweeps replay a hipGraph), against 8 TB/s.  `frac_if_priced_as_flux_only` and
-`flux_kernel_alone` (the standalone compute_flux_edge kernel, 50 back-to-back launches) are
-given beside it.
-cpu_baseline: the reference's own compute_flux_edge (oracle/_ref, built from the reference
-sources) — or the C oracle port when that build is absent — timed on one host core on the
-same mesh for a bounded number of passes.
+value = internal edges pushed through compute_flux_edge by all ranks / wall time of the K timed steps (max over ranks).
+
+roofline: the kernel BASELINE's target names, compute_flux_edge (+ boundary + far-field faces) = k_flux_tile writing
+fluxes[], priced as SURVEY.md §8d prices it (40 B per edge + 80 B per node) against 8 TB/s, its duration measured
+here with hipEvents on the launch stream; `fused_stage` beside it is the launch the sweeps actually run (one whole
+Runge-Kutta stage = compute_flux_edge + time_step, 168 B per node more), timed inside the timed region.  `traffic` is
+not measurable from inside a process: it is the figure of the committed rocprofv3 --pmc profile of this command,
+labelled with the file and build it came from.
+cpu_baseline: the reference's own compute_flux_edge (oracle/_ref, built from the reference sources) — or the C oracle
+port when that build is absent — timed on one host core on the same mesh for a bounded number of passes; beside it the
+all-cores figure (the reference's race-free way to use threads: one private mesh copy per thread, its -m).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,6 +57,9 @@ sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 LATTICE = 67                 # 67^3 = 300,763 nodes, 888,822 internal edges
+LATTICE_8X = 134             # the level tiled 8x (connected): 2,406,104 nodes / 7,164,444 internal edges
+HIERARCHY = (67, 55, 48, 43) # 300,763 / 166,375 / 110,592 / 79,507 nodes
+TRAFFIC_PROFILE = os.path.join("profiles", "r2_traffic.json")
 
 
 def build_workload(lattice: int, seed: int = 0):
@@ -54,14 +69,33 @@ def build_workload(lattice: int, seed: int = 0):
     return mg, generated_to_levels(mg)
 
 
+def build_hierarchy():
+    from mgcfd import meshgen, generated_to_levels
+    mg = meshgen.make_multigrid(HIERARCHY, "m6wing", seed=0, jitter=0.2, area_noise=0.02, volume_noise=0.02)
+    return mg, generated_to_levels(mg)
+
+
 def perturbed_state(nel, ff_var, seed=1234, amplitude=0.01):
     rng = np.random.default_rng(seed)
     base = np.tile(np.asarray(ff_var, dtype=np.float64), (nel, 1))
     return base * (1.0 + amplitude * rng.uniform(-1.0, 1.0, base.shape))
 
 
+def cpu_model():
+    """CPU model string and core counts of the host, as the reference records them (src/Base/common.h:114-143)."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 0, len(os.sched_getaffinity(0))
+
+
 def cpu_baseline(levels, sample_seconds: float):
-    """Time compute_flux_edge on ONE host core for a bounded number of passes."""
+    """Time compute_flux_edge on ONE host core for a bounded number of passes, then on every core this process may use."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     L = levels[0]
@@ -75,7 +109,8 @@ def cpu_baseline(levels, sample_seconds: float):
     q = perturbed_state(L["nel"], ff.var)
     f = np.zeros_like(q)
     n_int = int(L["n_internal"])
-    if O.have_reference():
+    have_ref = O.have_reference()
+    if have_ref:
         ref = O.load_reference()
         ref.ref_init(1, 2)
         fn = lambda: ref.ref_compute_flux_edge(0, n_int, O.ptr(edges), O.ptr(q), O.ptr(f))
@@ -94,21 +129,29 @@ def cpu_baseline(levels, sample_seconds: float):
     for _ in range(passes):
         fn()
     dt = time.perf_counter() - t0
+    model, cores_total, cores_usable = cpu_model()
     out = {"value": round(n_int * passes / dt / 1e6, 3), "unit": "Medges/s", "cores": 1, "kind": kind,
-           "sample": f"{passes} passes of compute_flux_edge over the same {n_int}-edge level ({dt:.1f} s), {how}"}
+           "sample": f"{passes} passes of compute_flux_edge over the same {n_int}-edge level ({dt:.1f} s), {how}",
+           "cpu_model": model, "host_cores": cores_total, "cores_usable_by_this_process": cores_usable}
     # ... and on all the host cores this process may use, the reference's own race-free way to use threads: one
-    # private copy of the mesh state per thread (its -m duplication, src/Base/io_enhanced.cpp:89-201).  The oracle's
-    # restatement is used here (same arithmetic, no global counters to race on); a reported baseline like the first.
+    # private copy of the mesh state per thread (its -m duplication, src/Base/io_enhanced.cpp:89-201), here as one
+    # thread per copy calling the reference's compute_flux_edge on its own arrays (the reference's loop counters are
+    # process-wide statistics nobody reads here; its arithmetic touches only the arrays passed in).
     try:
         import threading
-        cores = max(1, min(len(os.sched_getaffinity(0)), 16))     # a one-GPU box's CPU share is 16 cores
+        cores = max(1, min(cores_usable, 16))              # a one-GPU box's CPU share is 16 cores whatever the host has
         per = max(2, int(sample_seconds / 4.0 / max(one, 1e-6)))
         state = [(q.copy(), np.zeros_like(q)) for _ in range(cores)]
+        if have_ref and os.environ.get("MGCFD_BENCH_ALLCORES_PORT") != "1":
+            call, all_kind, all_how = (lambda qk, fk: ref.ref_compute_flux_edge(0, n_int, O.ptr(edges), O.ptr(qk), O.ptr(fk))), "reference", how
+        else:
+            call, all_kind, all_how = (lambda qk, fk: lib.ora_compute_flux_edge(0, n_int, O.ptr(edges), O.ptr(qk), O.ptr(fk))), "port", \
+                "oracle/mgcfd_oracle.c ora_compute_flux_edge, gcc -O3 -fno-fast-math -march=native"
 
         def work(k):
             qk, fk = state[k]
             for _ in range(per):
-                lib.ora_compute_flux_edge(0, n_int, O.ptr(edges), O.ptr(qk), O.ptr(fk))
+                call(qk, fk)
 
         threads = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
         t0 = time.perf_counter()
@@ -117,22 +160,21 @@ def cpu_baseline(levels, sample_seconds: float):
         for th in threads:
             th.join()
         dt_all = time.perf_counter() - t0
-        out["all_cores"] = {"value": round(n_int * per * cores / dt_all / 1e6, 3), "unit": "Medges/s", "cores": cores, "kind": "port",
-                            "sample": f"{cores} threads x {per} passes, one private copy of the level's state per thread ({dt_all:.1f} s), "
-                                      "oracle/mgcfd_oracle.c ora_compute_flux_edge, gcc -O3 -fno-fast-math -march=native"}
+        out["all_cores"] = {"value": round(n_int * per * cores / dt_all / 1e6, 3), "unit": "Medges/s", "cores": cores, "kind": all_kind,
+                            "sample": f"{cores} threads x {per} passes, one private copy of the level's state per thread ({dt_all:.1f} s), {all_how}"}
     except Exception as e:                                   # the single-core figure stands on its own
         out["all_cores"] = {"error": str(e)}
     return out
 
 
-def vcycle_wall(fast: bool, cycles: int = 25):
+def vcycle_wall(fast: bool, cycles: int = 25, device: int = 0):
     """Second half of BASELINE.json's metric: wall seconds per MG V-cycle on the 4-level M6-like hierarchy
     (67^3/55^3/48^3/43^3 lattices = 300,763/166,375/110,592/79,507 nodes, nearest-node maps,
-    mesh_name = m6wing), 25 cycles as the reference's default (src/Base/config.cpp:63), best of 3."""
+    mesh_name = m6wing), 25 cycles as the reference's default (src/Base/config.cpp:63), best of 3 — the reference's
+    "Total" / cycles (src/Monitoring/timer.cpp:106-195) with everything resident."""
     import mgcfd
-    from mgcfd import meshgen
-    mg = meshgen.make_multigrid((67, 55, 48, 43), "m6wing", seed=0, jitter=0.2, area_noise=0.02, volume_noise=0.02)
-    s = mgcfd.Solver.from_arrays(mgcfd.generated_to_levels(mg), mg.mesh_variant)
+    mg, levels = build_hierarchy()
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant, device=device)
     s.set_option("exact", 0 if fast else 1)
     s.run_cycles(2)
     best = float("inf")
@@ -142,90 +184,208 @@ def vcycle_wall(fast: bool, cycles: int = 25):
         rms = s.run_cycles(cycles)
         best = min(best, time.perf_counter() - t0)
     edge_iters = sum(s.loop_iters(l)["flux"] for l in range(s.num_levels)) // cycles
-    out = {"workload": f"4-level M6-like synthetic hierarchy {[l.nel for l in mg.levels]} nodes, {cycles} cycles",
+    out = {"workload": f"4-level M6-like synthetic hierarchy {[l.nel for l in mg.levels]} nodes, {cycles} cycles, best of 3",
            "wall_s_per_cycle": round(best / cycles, 9), "flux_edge_iterations_per_cycle": edge_iters,
            "medges_per_s_whole_cycle": round(edge_iters * cycles / best / 1e6, 1), "rms_last": float(rms[-1])}
     s.close()
     return out
 
 
+# --------------------------------------------------------------------------------------------------------------
+# process plumbing
+# --------------------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 from a plain invocation: start the N ranks as a fresh child process tree and relay its result."""
+    rehearsal = os.environ.get("MGCFD_BENCH_REHEARSAL") == "1"
+    if not rehearsal and not args.plumbing_only:
+        import torch                      # (device_count does not initialise the GPU on this image)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to run fewer ranks than asked "
+                  f"(MGCFD_BENCH_REHEARSAL=1 runs every rank on device 0 over gloo as a functional rehearsal)", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line:
+        print(line)
+    elif rc == 0:
+        print("bench.py: the child ranks printed no result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+class quiet_stdout:
+    """The communication libraries announce themselves on stdout ("Librccl path : ...", "[Gloo] Rank ..."): keep
+    stdout for the one JSON line by pointing file descriptor 1 at stderr while they initialise."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)        # 0.15 s of GPU time: past the clock ramp of the first ms
+    ap.add_argument("--steps", type=int, default=2000)        # 0.13 s of GPU time: past the clock ramp of the first ms
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--lattice", type=int, default=LATTICE, help="nodes per side of the synthetic M6-L0-like level")
+    ap.add_argument("--workload", default="auto", choices=["auto", "level0", "partitioned", "copies", "level-per-gpu"])
+    ap.add_argument("--lattice", type=int, default=0, help="nodes per side of the synthetic level (default 67; 134 for `partitioned`)")
     ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
-    ap.add_argument("--variant", type=int, default=-1, help="MGCFD_OPT_FLUX_VARIANT (-1 automatic, 0 stream k, 1 recompute k, 2/3 edge-once tiles)")
-    ap.add_argument("--vcycle", action="store_true",
-                    help="also measure wall seconds per 4-level MG V-cycle (off by default so that a rocprofv3 "
-                         "summary of the default command holds only the timed workload's launches)")
+    ap.add_argument("--variant", type=int, default=-1, help="MGCFD_OPT_FLUX_VARIANT (see include/mgcfd.h)")
+    ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle leg (a rocprofv3 summary of the command then holds only the timed workload's launches)")
+    ap.add_argument("--vcycle", action="store_true", help="(default now; kept so older command lines still parse)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (0 disables)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="start the ranks, rendezvous, build the host-side partition and print the line without touching a GPU "
+                         "(value null): what the CPU-side test of the N > 1 launcher runs")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     # multi-process GPU work on this platform needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise); the image
     # exports it, keep it if a launcher dropped the environment
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal of the N > 1 code path on a one-GPU box (not a measurement): every rank on device 0,
-    # collectives through gloo.  MGCFD_BENCH_REHEARSAL=1 python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or with "
+                  f"--nproc-per-node equal to --gpus", file=sys.stderr)
+        sys.exit(2)
+    workload = args.workload
+    if workload == "auto":
+        workload = "level0" if world == 1 else "partitioned"
+    if workload == "copies" and world == 1:
+        workload = "level0"
+    lattice = args.lattice or (LATTICE_8X if workload == "partitioned" else LATTICE)
+    # rehearsal of the N > 1 code path on a one-GPU box (not a measurement): every rank on device 0, collectives over gloo
     rehearsal = os.environ.get("MGCFD_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the MG-CFD HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # the communication libraries announce themselves on stdout ("Librccl path : ...", "[Gloo] Rank ..."): keep
-        # stdout for the one JSON line by pointing file descriptor 1 at stderr while they initialise
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
+    if args.plumbing_only:
+        return plumbing_only(args, dist, world, rank, workload, lattice)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MG-CFD HIP path has no CPU fallback")
+    if not rehearsal and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        with quiet_stdout():
             if rehearsal:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             else:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            warm = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            warm = torch.zeros(1, dtype=torch.float64, device=dev)
             dist.all_reduce(warm)                       # the first collective loads and sets up the backend
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    backend = None if world == 1 else ("gloo (rehearsal: every rank on device 0)" if rehearsal else "nccl (RCCL)")
 
     import mgcfd
-    mg, levels = build_workload(args.lattice)
-    solver = mgcfd.Solver.from_arrays(levels, mg.mesh_variant, device=local_rank)
-    # one explicit stream for the solver's kernels AND torch's collectives (the legacy default stream
-    # cannot be shared with the library: its own stream does not synchronise with it)
+    from mgcfd.distributed import HipSolverAdapter, LevelPerRankCycle, PartitionedSweep, ShardedSweep
+    # one explicit stream for the solver's kernels AND torch's collectives (the legacy default stream cannot be
+    # shared with the library: its own stream does not synchronise with it)
     stream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(stream)
-    solver.set_stream(stream.cuda_stream)
-    solver.set_option("exact", 0 if args.fast else 1)
-    solver.set_option("flux_variant", args.variant)
-    nel, n_int = solver.nel(0), solver.num_internal_edges(0)
-    solver.set(0, "variables", perturbed_state(nel, solver.far_field()[:5]))
 
-    sharded = None
-    if world > 1:
-        from mgcfd.distributed import HipSolverAdapter, ShardedSweep
-        sharded = ShardedSweep(HipSolverAdapter(solver, torch.device("cuda", local_rank)), dist)
+    def make_solver(levels, variant, **kw):
+        s = mgcfd.Solver.from_arrays(levels, variant, device=local_rank, **kw)
+        s.set_stream(stream.cuda_stream)
+        assert torch.cuda.current_stream().cuda_stream == stream.cuda_stream
+        s.set_option("exact", 0 if args.fast else 1)
+        s.set_option("flux_variant", args.variant)
+        return s
 
-    def step():
-        if world == 1:
-            solver.smooth(0, 1)
-        else:
-            # same sweep, with the global-min time step reduced over all ranks' mesh copies
-            sharded.sweep(0)
+    config = {"numerics": "fast (FMA contraction)" if args.fast else "exact (bit-identical to the reference)"}
+    extra = {}
+    scaling = "weak"
+    edges_per_step_all_ranks = 0
+    timed_level = 0
+    levels = None
+
+    if workload in ("level0", "copies"):
+        mg, levels = build_workload(lattice)
+        solver = make_solver(levels, mg.mesh_variant)
+        nel, n_int = solver.nel(0), solver.num_internal_edges(0)
+        solver.set(0, "variables", perturbed_state(nel, solver.far_field()[:5]))
+        sharded = ShardedSweep(HipSolverAdapter(solver, dev), dist) if world > 1 else None
+        step = (lambda: solver.smooth(0, 1)) if world == 1 else (lambda: sharded.sweep(0))
+        edges_per_step_all_ranks = 3 * n_int * world
+        config.update({"workload": f"M6-L0-like synthetic level ({lattice}^3 jittered lattice, permuted ids): {nel} nodes / "
+                                   f"{n_int} internal edges per GPU, flux + update sweep, no MG",
+                       "step": "copy, compute_step_factor, 3 x (fluxes, time_step), residual (the reference's per-sweep loops; run as 3 fused launches)",
+                       "parallelism": f"{world} mesh copies (the reference's -m {world}), all-reduce(min dt) per sweep" if world > 1 else "1 GPU"})
+    elif workload == "partitioned":
+        from mgcfd.partition import halo_volume, partition_level, rcb_partition
+        mg, levels = build_workload(lattice)
+        L = levels[0]
+        part = rcb_partition(np.asarray(L["coords"]), world)
+        P = partition_level(L, part)[rank]
+        solver = make_solver([P.level], mg.mesh_variant, n_owned=[P.n_owned])
+        q = perturbed_state(L["nel"], solver.far_field()[:5])
+        solver.set(0, "variables", q[P.global_ids])
+        nel, n_int = int(L["nel"]), int(L["n_internal"])
+        sw = PartitionedSweep(HipSolverAdapter(solver, dev), P, dist,
+                              make_buffer=lambda n: torch.empty(max(n, 1), dtype=torch.float64, device=dev), fused=True)
+        sw.exchange("variables")
+        step = sw.sweep
+        scaling = "strong"
+        edges_per_step_all_ranks = 3 * n_int
+        halo_nodes = int(halo_volume(L, part)) if world > 1 else 0
+        config.update({"workload": f"M6-L0-like level tiled 8x ({lattice}^3 jittered lattice, permuted ids, connected): {nel} nodes / {n_int} "
+                                   f"internal edges in total, recursive coordinate bisection into {world} part(s)",
+                       "step": "compute_step_factor + all-reduce(min dt), 3 x (fused fluxes + time_step launch, halo message to every neighbouring rank), residual",
+                       "parallelism": f"{world} ranks, owner computes, ghosts read-only", "halo_nodes_total": halo_nodes,
+                       "halo_bytes_per_stage_all_ranks": halo_nodes * 40, "peers_of_rank0": len(sw.peers),
+                       "owned_nodes_rank0": int(P.n_owned), "local_internal_edges_rank0": int(P.level["n_internal"])})
+    else:                                                    # level-per-gpu
+        mg, levels = build_hierarchy()
+        solver = make_solver(levels, mg.mesh_variant)
+        nlev = solver.num_levels
+        cyc = LevelPerRankCycle(HipSolverAdapter(solver, dev), nlev, rank, world, dist=dist)
+        step = cyc.cycle if world > 1 else (lambda: solver.run_cycles(1))
+        n_ints = [solver.num_internal_edges(l) for l in range(nlev)]
+        # a V-cycle sweeps levels 0..n-1 then n-2..1: every level but the first and the last twice
+        edges_per_step_all_ranks = 3 * (n_ints[0] + n_ints[-1] + 2 * sum(n_ints[1:-1]))
+        scaling = "strong"
+        nel, n_int = solver.nel(0), n_ints[0]
+        config.update({"workload": f"4-level M6-like synthetic hierarchy {[solver.nel(l) for l in range(nlev)]} nodes, level l on rank l % {world}",
+                       "step": "one multigrid V-cycle (sweeps on levels 0,1,2,3,2,1; 3 restrictions, 3 prolongations); restricted variables and coarse "
+                               "residuals cross ranks as whole-array point-to-point messages",
+                       "parallelism": f"{world} ranks, one level per rank (placement, not concurrency: the V-cycle is sequential in levels)"})
 
     def barrier():
         if world > 1:
@@ -236,89 +396,127 @@ def main():
         step()
     barrier()
     solver.reset_monitoring()
-    if os.environ.get("MGCFD_BENCH_NO_TIMING") != "1":      # (diagnostic: how much the live kernel timing costs)
-        solver.set_option("timing", 2)        # hipEvent pairs around the flux launches only
+    live_timing = os.environ.get("MGCFD_BENCH_NO_TIMING") != "1" and workload in ("level0", "copies")
+    if live_timing:
+        # hipEvent pairs around the three stage launches of sampled sweeps: every 8th sweep, every sweep when K is small
+        solver.set_option("timing", 3 if args.steps <= 400 else 2)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    flux_avg, flux_launches = solver.flux_kernel_time(0)
+    flux_avg, flux_launches = solver.flux_kernel_time(timed_level) if live_timing else (0.0, 0)
     solver.set_option("timing", 0)
     rc, bad = solver.check_for_invalid_variables(0)
     if rc != 0:
         raise SystemExit(f"state became invalid during the bench (code {rc}, cell {bad})")
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # the standalone flux kernel (compute_flux_edge semantics: writes fluxes[]), 50 back-to-back
-    # launches between one hipEvent pair on the same stream
-    flux_only = solver.bench_flux(0, 50)
-
-    # HBM-side traffic per launch from the committed PMC profile of this same command (bench.py
-    # cannot collect hardware counters itself); None when the workload differs from the profiled one
-    traffic = {}
-    try:
-        if args.lattice == LATTICE and not args.fast and args.variant in (-1, 0):   # -1 resolves to 0 at this size
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-    except (OSError, ValueError):
-        traffic = {}
-
+    out = None
     if rank == 0:
-        edges_total = 3 * n_int * args.steps * world
-        # ALGORITHMIC bytes: compute_flux_edge 40*E + 80*N; time_step 168 B/node.
-        # One k_flux_tile<FUSE> launch is a whole RK stage = both loops.
-        bytes_flux = 40 * n_int + 80 * nel
-        bytes_ts = 168 * nel
-        algo_bytes = bytes_flux + bytes_ts
-        achieved = algo_bytes / flux_avg / 1e9 if flux_avg > 0 else 0.0
-        achieved_flux_only = bytes_flux / flux_only / 1e9 if flux_only > 0 else 0.0
         out = {
-            "metric": "Medges/s (compute_flux_edge)",
-            "value": round(edges_total / elapsed / 1e6, 3),
+            "metric": "Medges/s (compute_flux_edge)" + (" + MG V-cycle wall-s" if workload == "level0" and not args.no_vcycle else ""),
+            "value": round(edges_per_step_all_ranks * args.steps / elapsed / 1e6, 3),
             "unit": "Medges/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 6),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"M6-L0-like synthetic level ({args.lattice}^3 jittered lattice, permuted ids): "
-                                   f"{nel} nodes / {n_int} internal edges per GPU, flux + update sweep, no MG",
-                       "step": "copy, compute_step_factor, 3 x (fluxes, time_step), residual (the reference's per-sweep loops; run as 3 fused launches)",
-                       "numerics": "fast (FMA contraction)" if args.fast else "exact (bit-identical to the reference)",
-                       "parallelism": f"{world} mesh copies, all-reduce(min dt) per sweep" if world > 1 else "1 GPU"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic.get("k_flux_tile_fused_stage", {}).get("bytes"),
-                         "kernel": "k_flux_tile<FUSE>: one RK stage per launch = compute_flux_edge + boundary + wall fluxes + time_step",
-                         "launches": flux_launches, "avg_kernel_us": round(flux_avg * 1e6, 3),
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "algorithmic_bytes": {"compute_flux_edge (40E+80N)": bytes_flux, "time_step (168N)": bytes_ts},
-                         "frac_if_priced_as_flux_only": round(bytes_flux / flux_avg / 1e9 / HBM_PEAK_GBS, 4) if flux_avg > 0 else None,
-                         "flux_kernel_alone": {"kernel": "k_flux_tile (writes fluxes[], no time_step)",
-                                               "avg_kernel_us": round(flux_only * 1e6, 3), "launches": 50,
-                                               "algorithmic_bytes_per_launch": bytes_flux,
-                                               "achieved": round(achieved_flux_only, 1),
-                                               "traffic": traffic.get("k_flux_tile_flux_only", {}).get("bytes"),
-                                               "frac": round(achieved_flux_only / HBM_PEAK_GBS, 4),
-                                               "medges_per_s": round(n_int / flux_only / 1e6, 1) if flux_only > 0 else None}},
+            "config": dict(config, workload_kind=workload, collectives=backend),
         }
-        if world == 1 and args.vcycle:
-            out["vcycle"] = vcycle_wall(args.fast)
-        if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(levels, args.cpu_seconds)
-        print(json.dumps(out))
+        if workload == "level-per-gpu":
+            out["vcycle"] = {"wall_s_per_cycle": round(elapsed / args.steps, 9), "flux_edge_iterations_per_cycle": edges_per_step_all_ranks}
+    if workload in ("level0", "copies"):
+        # the standalone compute_flux_edge kernel (writes fluxes[]), 50 back-to-back launches between one hipEvent pair
+        # on the same stream, and the data-movement probe on the same tiles (indirect_rw: same loads and stores, the
+        # reference's trivial arithmetic) = the empirical ceiling of this layout (src/Kernels/indirect_rw_loop.cpp:8-10)
+        flux_only = solver.bench_flux(0, 50)
+        probe = solver.bench_indirect_rw(0, 50) if hasattr(solver, "bench_indirect_rw") else None
+        if rank == 0:
+            bytes_flux = 40 * n_int + 80 * nel                  # compute_flux_edge
+            bytes_ts = 168 * nel                                # time_step
+            traffic = {}
+            try:
+                if lattice == LATTICE and not args.fast and args.variant == -1:
+                    traffic = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
+            except (OSError, ValueError):
+                traffic = {}
+            ach = bytes_flux / flux_only / 1e9 if flux_only > 0 else 0.0
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic.get("flux_only", {}).get("bytes"),
+                    "traffic_source": (f"{TRAFFIC_PROFILE} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes; build {traffic.get('build')})"
+                                       if traffic else None),
+                    "kernel": "compute_flux_edge + boundary + far-field faces in one launch (writes fluxes[], no time_step): the kernel BASELINE's 60 % target names",
+                    "launches": 50, "avg_kernel_us": round(flux_only * 1e6, 3), "algorithmic_bytes_per_launch": bytes_flux,
+                    "algorithmic_bytes": "40 B per internal edge + 80 B per node (SURVEY.md §8d)",
+                    "medges_per_s": round(n_int / flux_only / 1e6, 1) if flux_only > 0 else None}
+            if probe:
+                roof["empirical_ceiling_us"] = round(probe * 1e6, 3)
+                roof["empirical_ceiling"] = "indirect_rw through the same tiles (same loads and stores, the reference's trivial arithmetic; src/Kernels/indirect_rw_loop.cpp:8-10)"
+                roof["flux_over_indirect_rw"] = round(flux_only / probe, 3)
+            if flux_avg > 0:
+                a2 = (bytes_flux + bytes_ts) / flux_avg / 1e9
+                roof["fused_stage"] = {"kernel": "one whole Runge-Kutta stage per launch = compute_flux_edge + boundary + far-field + time_step: what the timed sweeps run",
+                                       "launches": flux_launches, "avg_kernel_us": round(flux_avg * 1e6, 3),
+                                       "algorithmic_bytes_per_launch": bytes_flux + bytes_ts,
+                                       "algorithmic_bytes": {"compute_flux_edge (40E+80N)": bytes_flux, "time_step (168N)": bytes_ts},
+                                       "achieved": round(a2, 1), "frac": round(a2 / HBM_PEAK_GBS, 4),
+                                       "frac_if_priced_as_flux_only": round(bytes_flux / flux_avg / 1e9 / HBM_PEAK_GBS, 4),
+                                       "traffic": traffic.get("fused_stage", {}).get("bytes")}
+            out["roofline"] = roof
     solver.close()
     if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if world == 1 and workload == "level0" and not args.no_vcycle:
+            out["vcycle"] = vcycle_wall(args.fast, device=local_rank)
+        if args.cpu_seconds > 0 and world == 1 and workload == "level0":
+            out["cpu_baseline"] = cpu_baseline(levels, args.cpu_seconds)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
         dist.destroy_process_group()
+
+
+def plumbing_only(args, dist, world, rank, workload, lattice):
+    """No GPU: rendezvous over gloo, build this rank's share of the host-side partition (small lattice), agree on the
+    maximum of a timed no-op loop exactly as the real run does, print the line with value null."""
+    import torch
+    if world > 1:
+        with quiet_stdout():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    detail = {}
+    if workload == "partitioned":
+        from mgcfd.partition import halo_volume, partition_level, rcb_partition
+        mg, levels = build_workload(args.lattice or 12)
+        part = rcb_partition(np.asarray(levels[0]["coords"]), world)
+        P = partition_level(levels[0], part)[rank]
+        owned = torch.tensor([P.n_owned], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(owned)
+        assert int(owned.item()) == int(levels[0]["nel"]), "the parts must cover the level exactly once"
+        detail = {"nodes": int(levels[0]["nel"]), "halo_nodes_total": int(halo_volume(levels[0], part)) if world > 1 else 0}
+    t = torch.tensor([0.0], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n = dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        n = 1
+    if rank == 0:
+        print(json.dumps({"metric": "Medges/s (compute_flux_edge)", "value": None, "unit": "Medges/s", "n_gpus": n, "steps": args.steps,
+                          "warmup": args.warmup, "plumbing_only": True, "config": dict(detail, workload_kind=workload)}))
 
 
 if __name__ == "__main__":

@@ -59,7 +59,8 @@ enum {
     MGCFD_OPT_EXACT = 0,       /* 1 (default): kernels compiled without FMA contraction and summing in the
                                   reference's order => bit-identical to the reference built with
                                   -ffp-contract=off.  0: contraction allowed (faster, ~1e-16 relative). */
-    MGCFD_OPT_TIMING = 1,      /* 1: bracket every loop with hipEvents (Times.csv columns); 2: only the flux launches of every 8th sweep */
+    MGCFD_OPT_TIMING = 1,      /* 1: bracket every loop with hipEvents (Times.csv columns); 2: only the flux launches of every 8th sweep;
+                                  3: as 2 for every sweep (reads back as 2) */
     MGCFD_OPT_INDIRECT_RW = 2, /* 1: also run the indirect_rw probe each RK stage, as the reference's main() does */
     MGCFD_OPT_CHECK_INVALID = 3, /* 1 (default): NaN / negativity check every RK stage (validation.cpp:107-138) */
     MGCFD_OPT_FLUX_VARIANT = 4, /* -1 (default): automatic — 0 while a level's incidence rows fit the Infinity Cache,
@@ -249,6 +250,11 @@ int mgcfd_set_array(mgcfd_solver *s, int level, int which, const double *in);
 int mgcfd_array_devptr(mgcfd_solver *s, int level, int which, void **devptr, int64_t *count);
 int mgcfd_array_written(mgcfd_solver *s, int level, int which);
 int mgcfd_get_edges(mgcfd_solver *s, int level, mgcfd_edge *out);
+/* One multigrid level per rank: `dev_src` is the next-coarser level's `variables` as ANOTHER solver built from the same
+ * level data holds it after its mgcfd_restrict(fine_level) (its mgcfd_array_devptr, or a received copy of it).  Copies
+ * the coarse nodes that HAVE children; a coarse node without children keeps this solver's value, as mg_restrict leaves
+ * it (src/Kernels/mg_loops.cpp:63-78,174-189) — only the rank that sweeps the coarse level has that value. */
+int mgcfd_accept_restricted(mgcfd_solver *s, int fine_level, const void *dev_src);
 
 /* ---------------------------------------------------------------------------------
  * Monitoring — LoopNumIters.csv / Times.csv contents
@@ -265,6 +271,9 @@ int mgcfd_get_flux_kernel_time(mgcfd_solver *s, int level, double *avg_seconds, 
 /* Diagnostic: mean GPU time of `launches` back-to-back flux launches (internal + boundary +
  * far field, starting from zero fluxes), hipEvents around the batch on the solver's stream. */
 int mgcfd_bench_flux(mgcfd_solver *s, int level, int launches, double *avg_seconds);
+/* The same for the indirect_rw probe (src/Kernels/indirect_rw_loop.cpp:8-78; fluxes += ..., accumulating over the
+ * launches): the empirical data-movement ceiling of the flux kernel on this level's tiles. */
+int mgcfd_bench_indirect_rw(mgcfd_solver *s, int level, int launches, double *avg_seconds);
 
 /* ---------------------------------------------------------------------------------
  * Multi-GPU hooks (one process per GPU; the collectives themselves are issued by the

@@ -1126,6 +1126,86 @@ k_indirect_rw(int64_t nel, int64_t stride, const double *__restrict__ q, const i
 }
 
 // ------------------------------------------------------------------------------------------
+// indirect_rw through the LDS tiles: the probe the reference keeps to bound compute_flux_edge from above
+// (indirect_rw_loop.cpp:8-10, "same data movement, minimal arithmetic").  Here "same data movement" means the flux
+// kernel's own: the same prologue (halo ids, own and halo state into 96-byte LDS records — the derived fields filled
+// with copies, nothing is derived), the same incidence rows two at a time with the same prefetch, every byte the
+// flux kernel loads is loaded (weights of both roles and the length factor included; an empty asm consumes what the
+// probe's arithmetic does not use), the same stores.  Arithmetic: indirect_rw_kernel.elemfunc.c:41-55 in gather form.
+// Levels whose tiles leave halo nodes outside LDS or have long rows use k_indirect_rw above.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void keep_alive(double x) { asm volatile("" ::"v"(x)); }
+
+template <bool LOADK>
+__global__ void __launch_bounds__(kBlock, 3)
+k_indirect_rw_tile(const double *__restrict__ q, const int32_t *__restrict__ tile_halo, uint32_t n_tiles, int32_t pad_row,
+                   int64_t stride, int64_t nel, const int32_t *__restrict__ slice_row0, const int32_t *__restrict__ rows_int,
+                   const uint16_t *__restrict__ nbr16, const double *__restrict__ w, double *__restrict__ fluxes)
+{
+    __shared__ double2 tile[kTileCap * kLdsRecD2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const unsigned t = xcd_contiguous_block(blockIdx.x, n_tiles);
+    const int64_t i = int64_t(t) * kTile + tid;
+    const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
+    const int32_t *hrow = tile_halo + int64_t(t) * kHaloStride;
+    const int32_t hid = hrow[tid];
+    const int32_t hid2 = tid < kHaloStride - kBlock ? hrow[kBlock + tid] : -1;
+    const int32_t row0 = slice_row0[slice];
+    const int32_t n_int = rows_int[slice];
+    const int64_t hnode = hid >= 0 ? int64_t(hid) : i;
+    const double o0 = q[i], o1 = q[stride + i], o2 = q[2 * stride + i], o3 = q[3 * stride + i], o4 = q[4 * stride + i];
+    const double g0 = q[hnode], g1 = q[stride + hnode], g2 = q[2 * stride + hnode], g3 = q[3 * stride + hnode], g4 = q[4 * stride + hnode];
+    EdgeRow e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
+    EdgeRow e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
+    auto record = [](double r, double mx, double my, double mz, double en) {
+        NodeQ n;
+        n.rho = r; n.mx = mx; n.my = my; n.mz = mz; n.en = en;
+        n.vx = r; n.vy = mx; n.vz = my; n.p = mz; n.speed = en; n.c = r;      // (copies: the record keeps its 96 bytes)
+        return n;
+    };
+    lds_store_record(tile, uint32_t(tid), record(o0, o1, o2, o3, o4));
+    lds_store_record(tile, uint32_t(kTile + tid), record(g0, g1, g2, g3, g4));
+    if (hid2 >= 0) {
+        const int64_t h = hid2;
+        lds_store_record(tile, uint32_t(kTile + kBlock + tid), record(q[h], q[stride + h], q[2 * stride + h], q[3 * stride + h], q[4 * stride + h]));
+    }
+    // fluxes += ... (indirect_rw_kernel.elemfunc.c:84-94)
+    double a0 = fluxes[i], a1 = fluxes[stride + i], a2 = fluxes[2 * stride + i], a3 = fluxes[3 * stride + i], a4 = fluxes[4 * stride + i];
+    __syncthreads();
+    auto entry = [&](const EdgeRow &e) {
+        const uint32_t s = e.code & kT16SlotMask;
+        const bool v = s != kT16Pad;
+        const NodeQ n = lds_load_record(tile, v ? s : uint32_t(tid));
+        keep_alive(n.vx); keep_alive(n.vy); keep_alive(n.vz); keep_alive(n.p); keep_alive(n.speed); keep_alive(n.c);
+        keep_alive(e.fx); keep_alive(e.fy); keep_alive(e.fz);
+        if (LOADK) keep_alive(e.k);
+        if (!v) return;
+        if (e.code & kT16RoleB) {                                  // this node is the edge's b end: += q_a (:50-54)
+            a0 += n.rho; a1 += n.mx; a2 += n.my; a3 += n.mz; a4 += n.en;
+        } else {                                                    // a end: += q_b + (ex, ez, 0, 0, ey) (:41-45); the plan stores -0.5*e
+            a0 += n.rho + (-2.0 * e.fx);
+            a1 += n.mx + (-2.0 * e.fz);
+            a2 += n.my;
+            a3 += n.mz;
+            a4 += n.en + (-2.0 * e.fy);
+        }
+    };
+    int32_t r = 0;
+    for (; r + 2 < n_int; r += 2) {
+        const EdgeRow e2 = load_row<LOADK>(nbr16, w, row0 + r + 2, lane);
+        const EdgeRow e3 = load_row<LOADK>(nbr16, w, r + 3 < n_int ? row0 + r + 3 : pad_row, lane);
+        entry(e0); entry(e1);
+        e0 = e2; e1 = e3;
+    }
+    if (r < n_int) { entry(e0); entry(e1); }
+    if (i < nel) {
+        fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
+        fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // time_step (cfd_loops.cpp:241-268): variables = old + sf/(RK+1-j) * fluxes ; fluxes = 0.
 // Fused options (same operations, fewer passes over memory):
 //   * partial_min != nullptr: this is the first stage after compute_step_factor's first half —
@@ -1278,6 +1358,18 @@ k_halo_unpack(int64_t n, int64_t stride, const int32_t *__restrict__ idx, const 
     if (k >= n) return;
     const int64_t i = idx[k];
     for (int f = 0; f < 5; f++) field[f * stride + i] = msg[k * 5 + f];
+}
+
+// One multigrid level per rank: the restricted variables arrive from the rank that holds the finer level as a whole
+// [5][stride] array.  mg_restrict leaves a coarse node WITHOUT children at its old value (mg_loops.cpp:63-78,174-189),
+// and only the rank that sweeps the coarse level has that value: take the message for nodes with children only.
+__global__ void __launch_bounds__(kBlock)
+k_accept_restricted(int64_t nel_coarse, int64_t stride_coarse, const int32_t *__restrict__ child_ptr,
+                    const double *__restrict__ src, double *__restrict__ coarse_q)
+{
+    const int64_t c = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    if (c >= nel_coarse || child_ptr[c + 1] == child_ptr[c]) return;
+    for (int f = 0; f < 5; f++) coarse_q[f * stride_coarse + c] = src[f * stride_coarse + c];
 }
 
 // rms history: append a device scalar to a ring (lets a whole multigrid cycle live in one hipGraph)
@@ -1614,8 +1706,19 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
 #undef MGCFD_TILE_LAUNCH_T
 }
 
-void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, double *fluxes)
+void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, double *fluxes, int variant)
 {
+    // through the flux kernel's LDS tiles where the level allows it (no halo node left outside LDS, no long rows);
+    // variant bit 3 (8) forces the plain L1 gather
+    if (p.lds_complete && !p.has_tail && !(variant & 8)) {
+        if ((variant & 1) == 0)
+            hipLaunchKernelGGL((k_indirect_rw_tile<true>), dim3(p.n_tiles), dim3(kBlock), 0, st, q, p.tile_halo, uint32_t(p.n_tiles),
+                               p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.nbr16, p.w, fluxes);
+        else
+            hipLaunchKernelGGL((k_indirect_rw_tile<false>), dim3(p.n_tiles), dim3(kBlock), 0, st, q, p.tile_halo, uint32_t(p.n_tiles),
+                               p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.nbr16, p.w, fluxes);
+        return;
+    }
     hipLaunchKernelGGL(k_indirect_rw, dim3(p.n_tiles), dim3(kBlock), 0, st, p.nel, p.stride, q,
                        p.slice_row0, p.rows_int, p.nbr, p.w, fluxes);
 }
@@ -1650,6 +1753,9 @@ void launch_halo_pack(hipStream_t st, int64_t n, int64_t stride, const int32_t *
 
 void launch_halo_unpack(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const double *msg, double *field)
 { if (n > 0) hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, msg, field); }
+
+void launch_accept_restricted(hipStream_t st, int64_t nel_coarse, int64_t stride_coarse, const int32_t *child_ptr, const double *src, double *coarse_q)
+{ hipLaunchKernelGGL(k_accept_restricted, dim3(grid_for(nel_coarse)), dim3(kBlock), 0, st, nel_coarse, stride_coarse, child_ptr, src, coarse_q); }
 
 void launch_sum_partials_append(hipStream_t st, int n, const double *partial, double *out, double *ring, int *count, int cap)
 { hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, SumTask{partial, n, out, ring, count, cap}); }

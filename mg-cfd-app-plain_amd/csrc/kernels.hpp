@@ -15,7 +15,7 @@
                                    double *sf, double *old_variables);                                               \
     void launch_flux(hipStream_t, const DevicePlan &, const double *q, const FarField &, double *fluxes,             \
                      int classes, int accumulate, int variant, const FusedStep *fused);                              \
-    void launch_indirect_rw(hipStream_t, const DevicePlan &, const double *q, double *fluxes);                       \
+    void launch_indirect_rw(hipStream_t, const DevicePlan &, const double *q, double *fluxes, int variant);                       \
     void launch_time_step(hipStream_t, int64_t nel, int64_t stride, int j, double *sf, double *fluxes,               \
                           const double *old_variables, double *q, const int32_t *old_of_new,                         \
                           unsigned long long *err, int check, const double *partial_min, int n_partial,              \
@@ -31,6 +31,8 @@
     void launch_halo_unpack(hipStream_t, int64_t n, int64_t stride, const int32_t *idx, const double *msg,           \
                             double *field);                                                                          \
     void launch_append_scalar(hipStream_t, const double *src, double *ring, int *count, int cap);                    \
+    void launch_accept_restricted(hipStream_t, int64_t nel_coarse, int64_t stride_coarse, const int32_t *child_ptr,  \
+                                  const double *src, double *coarse_q);                                              \
     void launch_sum_partials_append(hipStream_t, int n, const double *partial, double *out, double *ring,            \
                                     int *count, int cap);                                                            \
     void launch_restrict(hipStream_t, int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine,                \

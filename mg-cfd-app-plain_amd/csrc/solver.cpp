@@ -297,8 +297,8 @@ struct mgcfd_solver {
         DeviceLevel &lv = level(l);
         settle_fluxes(lv);
         Timed t(this, l, MGCFD_LOOP_INDIRECT_RW);
-        if (opt_exact) exact::launch_indirect_rw(stream, lv.dp, lv.q, lv.fluxes);
-        else fast::launch_indirect_rw(stream, lv.dp, lv.q, lv.fluxes);
+        if (opt_exact) exact::launch_indirect_rw(stream, lv.dp, lv.q, lv.fluxes, variant_for(lv));
+        else fast::launch_indirect_rw(stream, lv.dp, lv.q, lv.fluxes, variant_for(lv));
         lv.fluxes_zero = false;
         lv.iters[MGCFD_LOOP_INDIRECT_RW] += lv.info.n_internal;
     }
@@ -586,6 +586,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
             lv.dp.tail.flux = reinterpret_cast<double2 *>(dev_alloc<double>(static_cast<size_t>(6 * P.tail_total)));
         }
         lv.dp.vin_ok = (P.halo_overflow_refs == 0 && P.halo_max <= kTile) ? 1 : 0;
+        lv.dp.lds_complete = P.halo_overflow_refs == 0 ? 1 : 0;
         lv.dp.edge_once = (P.edge_once && !std::getenv("MGCFD_NO_EDGE_ONCE")) ? 1 : 0;
         if (lv.dp.edge_once) {
             lv.dp.te_chunk_ptr = dev_upload(P.te_chunk_ptr);
@@ -761,7 +762,7 @@ int mgcfd_set_option(mgcfd_solver *s, int option, int value)
     return guarded([&] {
         switch (option) {
             case MGCFD_OPT_EXACT: s->opt_exact = value != 0; break;
-            case MGCFD_OPT_TIMING: s->use_device(); s->fold_events(); s->opt_timing = value; break;
+            case MGCFD_OPT_TIMING: s->use_device(); s->fold_events(); s->opt_timing = value == 3 ? 2 : value; s->timing_stride = value == 3 ? 1 : 8; break;
             case MGCFD_OPT_INDIRECT_RW: s->opt_indirect_rw = value != 0; break;
             case MGCFD_OPT_CHECK_INVALID: s->opt_check = value != 0; break;
             case MGCFD_OPT_FLUX_VARIANT: s->opt_variant = value; break;
@@ -967,7 +968,7 @@ static void run_sweep(mgcfd_solver *s, int level)
 {
     DeviceLevel &lv = s->level(level);
     const int64_t n = s->sweep_counter++;
-    const bool timed = s->opt_timing == 1 || (s->opt_timing == 2 && (n % s->timing_stride) == 0);
+    const bool timed = s->opt_timing == 1 || (s->opt_timing == 2 && (n % s->timing_stride) == 0);     // (stride 1 when MGCFD_OPT_TIMING was set to 3)
     // (only the fused launches are replayed: the unfused ones — the two-phase flux variant — leave host-side flags
     //  behind, fluxes_stale, that a replay would not set)
     const bool graphable = s->opt_graph && s->opt_fuse && !(s->variant_for(lv) & 4) && !s->opt_indirect_rw && !timed && lv.fluxes_zero && !lv.fluxes_stale;
@@ -1371,6 +1372,20 @@ int mgcfd_array_written(mgcfd_solver *s, int level, int which)
         if (which == MGCFD_ARR_VARIABLES) lv.min_ahead = false;
     });
 }
+// One level per rank: take a restricted `variables` array computed by the rank that holds the finer level.
+int mgcfd_accept_restricted(mgcfd_solver *s, int fine_level, const void *dev_src)
+{
+    REQUIRE(s); REQUIRE(dev_src);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &fine = s->level(fine_level);
+        DeviceLevel &coarse = s->level(fine_level + 1);
+        if (!fine.dp.child_ptr) throw std::invalid_argument("level has no coarser level");
+        exact::launch_accept_restricted(s->stream, coarse.info.nel, coarse.dp.stride, fine.dp.child_ptr,
+                                        static_cast<const double *>(dev_src), coarse.q);
+        coarse.min_ahead = false;
+    });
+}
 int mgcfd_get_edges(mgcfd_solver *s, int level, mgcfd_edge *out)
 {
     REQUIRE(s); REQUIRE(out);
@@ -1475,6 +1490,35 @@ int mgcfd_bench_flux(mgcfd_solver *s, int level, int launches, double *avg_secon
         auto go = [&] {
             if (s->opt_exact) exact::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, variant, nullptr);
             else fast::launch_flux(s->stream, lv.dp, lv.q, s->ff, lv.fluxes, 7, 0, variant, nullptr);
+        };
+        go();
+        HIP_CHECK(hipEventRecord(a, s->stream));
+        for (int k = 0; k < launches; k++) go();
+        HIP_CHECK(hipEventRecord(b, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        s->free_events.push_back(a);
+        s->free_events.push_back(b);
+        lv.fluxes_zero = false;
+        *avg_seconds = launches > 0 ? double(ms) * 1e-3 / launches : 0.0;
+    });
+}
+
+// The same for the indirect_rw probe (fluxes += ..., accumulating over the launches): the data-movement ceiling of the
+// flux kernel on this level's tiles.
+int mgcfd_bench_indirect_rw(mgcfd_solver *s, int level, int launches, double *avg_seconds)
+{
+    REQUIRE(s); REQUIRE(avg_seconds);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        s->settle_fluxes(lv);
+        hipEvent_t a = s->get_event(), b = s->get_event();
+        const int variant = s->variant_for(lv);
+        auto go = [&] {
+            if (s->opt_exact) exact::launch_indirect_rw(s->stream, lv.dp, lv.q, lv.fluxes, variant);
+            else fast::launch_indirect_rw(s->stream, lv.dp, lv.q, lv.fluxes, variant);
         };
         go();
         HIP_CHECK(hipEventRecord(a, s->stream));

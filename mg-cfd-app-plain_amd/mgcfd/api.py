@@ -98,11 +98,13 @@ _SIGNATURES = [
     ("mgcfd_array_devptr", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int64)]),
     ("mgcfd_array_written", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mgcfd_get_edges", C.c_int, [_vp, C.c_int, _vp]),
+    ("mgcfd_accept_restricted", C.c_int, [_vp, C.c_int, _vp]),
     ("mgcfd_get_loop_iters", C.c_int, [_vp, C.c_int, _vp]),
     ("mgcfd_get_loop_times", C.c_int, [_vp, C.c_int, _vp]),
     ("mgcfd_reset_monitoring", C.c_int, [_vp]),
     ("mgcfd_get_flux_kernel_time", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
     ("mgcfd_bench_flux", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    ("mgcfd_bench_indirect_rw", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_step_factor_local", C.c_int, [_vp, C.c_int]),
     ("mgcfd_step_factor_min_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_step_factor_partials_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]),
@@ -294,6 +296,10 @@ class Solver:
         self._c(self.lib.mgcfd_array_devptr(self.handle, l, ARR[name], C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def accept_restricted(self, fine: int, dev_ptr: int):
+        """Take the next-coarser level's restricted variables computed by another solver (one level per rank)."""
+        self._c(self.lib.mgcfd_accept_restricted(self.handle, fine, C.c_void_p(dev_ptr)))
+
     def array_written(self, l: int, name: str):
         self._c(self.lib.mgcfd_array_written(self.handle, l, ARR[name]))
 
@@ -422,6 +428,11 @@ class Solver:
     def bench_flux(self, l: int, launches: int) -> float:
         t = C.c_double()
         self._c(self.lib.mgcfd_bench_flux(self.handle, l, launches, C.byref(t)))
+        return t.value
+
+    def bench_indirect_rw(self, l: int, launches: int) -> float:
+        t = C.c_double()
+        self._c(self.lib.mgcfd_bench_indirect_rw(self.handle, l, launches, C.byref(t)))
         return t.value
 
     # ---- halo exchange of a partitioned level ----

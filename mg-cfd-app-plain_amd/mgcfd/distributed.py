@@ -72,6 +72,9 @@ class HipSolverAdapter:
         # launches the reduction; the returned tensor aliases its device result
         return DevScalarView(self.s.residual_sumsq_devptr(level)).tensor(self.device)
 
+    def accept_restricted(self, fine, tensor):
+        self.s.accept_restricted(fine, tensor.data_ptr())
+
     def array_tensor(self, level, name):
         """A whole node array of a level as the library holds it (the address is asked for every time: the state
         buffers rotate with every sweep)."""
@@ -240,6 +243,7 @@ class LevelPerRankCycle:
         self.dist = dist
         self.send = send or (lambda t, dst: dist.send(t, dst))
         self.recv = recv or (lambda t, src: dist.recv(t, src))
+        self._stage = {}
 
     def _hand_over(self, level, name, src, dst):
         if src == dst:
@@ -247,7 +251,17 @@ class LevelPerRankCycle:
         if self.rank == src:
             self.send(self.s.array_tensor(level, name), dst)
         elif self.rank == dst:
-            self.recv(self.s.array_tensor(level, name), src)
+            if name == "variables":
+                # restricted variables: mg_restrict leaves a coarse node without children at ITS old value
+                # (src/Kernels/mg_loops.cpp:63-78,174-189) and only this rank, which sweeps the coarse level, has it:
+                # receive into a staging array and take the nodes that have children
+                t = self.s.array_tensor(level, name)
+                if level not in self._stage:
+                    self._stage[level] = t.clone()
+                self.recv(self._stage[level], src)
+                self.s.accept_restricted(level - 1, self._stage[level])
+            else:
+                self.recv(self.s.array_tensor(level, name), src)
             self.s.array_written(level, name)
 
     def cycle(self):

@@ -304,11 +304,11 @@ class OracleMGSolver:
     """Oracle-backed stand-in for a multi-level mgcfd.api.Solver: smooth / restrict / prolong on the
     reference's own arrays, torch tensors aliasing them."""
 
-    def __init__(self, oracle):
+    def __init__(self, oracle, input_dat=None):
         import ctypes as C
         self.O, self.C = oracle, C
         self.lib = oracle.load()
-        self.case = oracle.OracleCase.from_input_dat(os.path.join(GOLDEN_3LVL, "input", "input.dat"))
+        self.case = oracle.OracleCase.from_input_dat(input_dat or os.path.join(GOLDEN_3LVL, "input", "input.dat"))
         self.ff = oracle.farfield()
         for l in range(self.case.nlevels):
             L = self.case.levels[l]
@@ -342,18 +342,26 @@ class OracleMGSolver:
     def array_tensor(self, l, name):
         return torch.from_numpy(self.case.array(l, name))
 
+    def accept_restricted(self, fine, tensor):
+        """mgcfd_accept_restricted: coarse nodes with children take the message, the others keep their value."""
+        m = np.asarray(self.case.mg_map(fine))
+        has = np.zeros(self.case.levels[fine + 1].nel, dtype=bool)
+        has[m] = True
+        v = self.case.array(fine + 1, "variables").reshape(-1, 5)
+        v[has] = tensor.numpy().reshape(-1, 5)[has]
+
     def array_written(self, l, name):
         self.written.append((l, name))
 
 
-def _level_worker(rank, world, port, cycles, out_dir):
+def _level_worker(rank, world, port, cycles, out_dir, input_dat=None):
     sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd"))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     from mgcfd.distributed import LevelPerRankCycle
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    solver = OracleMGSolver(oracle_py)
+    solver = OracleMGSolver(oracle_py, input_dat)
     cyc = LevelPerRankCycle(solver, solver.case.nlevels, rank, world, dist=dist)
     for _ in range(cycles):
         cyc.cycle()
@@ -382,6 +390,31 @@ def test_one_level_per_rank_equals_the_reference_binary(tmp_path, oracle):
     # the receiving side told its solver about every array it received
     assert set(np.load(tmp_path / "written_1.npy")) == {"1:variables", "2:residuals"}
     assert set(np.load(tmp_path / "written_0.npy")) == {"2:variables", "1:residuals"}
+
+
+@pytest.mark.timeout(300)
+def test_one_level_per_rank_with_childless_coarse_nodes(tmp_path, oracle):
+    """A hierarchy whose middle level has coarse nodes WITHOUT children (10^3 -> 9^3 nearest-node map: 11 of them):
+    mg_restrict leaves such a node at its old value, which only the rank that sweeps the coarse level holds — the
+    restricted array that arrives from the finer level's rank must not overwrite it (mgcfd_accept_restricted).  Three
+    levels on three ranks, three cycles, every level against the single-process oracle."""
+    from mgcfd import meshgen
+    world, cycles = 3, 3
+    d = tmp_path / "mesh"
+    d.mkdir()
+    mg = meshgen.make_multigrid((10, 9, 5), "m6wing", seed=3, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    meshgen.write_input(mg, str(d))
+    dat = str(d / "input.dat")
+    oc = oracle.OracleCase.from_input_dat(dat)
+    m = np.asarray(oc.mg_map(0))
+    assert len(np.unique(m)) < oc.levels[1].nel, "the case must have childless coarse nodes"
+    out = tmp_path / "out"
+    out.mkdir()
+    mp.spawn(_level_worker, args=(world, _free_port(), cycles, str(out), dat), nprocs=world, join=True)
+    rc, _, _ = oc.solve(cycles, run_indirect_rw=False)
+    assert rc == 0
+    for l in range(oc.nlevels):
+        assert np.array_equal(np.load(out / f"lvl{l}.npy").view(np.int64), oc.array(l, "variables").view(np.int64)), l
 
 
 # ------------------------------------------------------------------------------------------

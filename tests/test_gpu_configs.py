@@ -1,0 +1,318 @@
+"""BASELINE.json's configurations at their FULL sizes on the GPU, against the oracle, bit for bit.
+
+configs[0] fvcorr-like 97,335 nodes, 1,000 iterations          test_cfg1_*
+configs[1] M6-L0-like 300,763 nodes: the sweeps the bench times  test_cfg2_*
+configs[2] 4-level hierarchy 300,763/166,375/110,592/79,507     test_cfg3_*
+configs[4] the level tiled 8x (2.4 M nodes) split 8 ways         test_cfg5_*  (8 solvers on this one GPU, threads for ranks)
+configs[3] (one level per GPU) at full size is the same arithmetic as configs[2]; its in-process analogue at full size:
+                                                                 test_cfg4_*
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits_equal(got, want, what):
+    got, want = np.ascontiguousarray(got), np.ascontiguousarray(want)
+    bad = np.flatnonzero(got.ravel().view(np.int64) != want.ravel().view(np.int64))
+    assert bad.size == 0, f"{what}: {bad.size} values differ bitwise; first {bad[:5]}, max abs diff {np.abs(got - want).max():.3e}"
+
+
+def _oracle_levels(oracle, levels):
+    """OraLevel array over in-memory level dicts + the arrays that must stay alive."""
+    n = len(levels)
+    lv = (oracle.OraLevel * n)()
+    keep = []
+    for l, L in enumerate(levels):
+        vol = np.ascontiguousarray(L["volumes"], dtype=np.float64)
+        coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+        edges = np.ascontiguousarray(L["edges"]).copy()
+        state = [np.zeros((L["nel"], 5)) for _ in range(4)] + [np.zeros(L["nel"])]
+        m = None
+        lv[l].nel, lv[l].n_edges = L["nel"], len(edges)
+        lv[l].n_internal, lv[l].n_boundary, lv[l].n_wall = L["n_internal"], L["n_boundary"], L["n_wall"]
+        lv[l].internal_start, lv[l].boundary_start, lv[l].wall_start = 0, L["n_internal"], L["n_internal"] + L["n_boundary"]
+        lv[l].volumes, lv[l].coords, lv[l].edges = oracle.ptr(vol), oracle.ptr(coords), oracle.ptr(edges)
+        lv[l].variables, lv[l].old_variables, lv[l].residuals, lv[l].fluxes = (oracle.ptr(a) for a in state[:4])
+        lv[l].step_factors = oracle.ptr(state[4])
+        if L.get("mg_map") is not None and l + 1 < n:
+            m = np.ascontiguousarray(L["mg_map"], dtype=np.int64)
+            lv[l].mg_map, lv[l].mgc = oracle.ptr(m), len(m)
+        keep.append(dict(vol=vol, coords=coords, edges=edges, variables=state[0], old=state[1], residuals=state[2],
+                         fluxes=state[3], sf=state[4], map=m))
+    return lv, keep
+
+
+def test_cfg3_full_size_four_level_vcycles(oracle):
+    """BASELINE configs[2] at size: the (67, 55, 48, 43)^3 hierarchy bench.py's V-cycle leg times, 2 V-cycles from the
+    far field: every level's variables and residuals and the loop counters against ora_solve."""
+    import bench
+    import mgcfd
+    mg, levels = bench.build_hierarchy()
+    assert [L["nel"] for L in levels] == [300763, 166375, 110592, 79507]
+    cycles = 2
+    lv, keep = _oracle_levels(oracle, levels)
+    lib = oracle.load()
+    want_rms = np.zeros(cycles)
+    iters = (oracle.OraIters * len(levels))()
+    assert lib.ora_solve(lv, len(levels), mg.mesh_variant, cycles, 0, oracle.ptr(want_rms), iters) == 0
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    rms = s.run_cycles(cycles)
+    for l in range(len(levels)):
+        _bits_equal(s.get(l, "variables"), keep[l]["variables"], f"level {l} variables after {cycles} V-cycles")
+        _bits_equal(s.get(l, "residuals"), keep[l]["residuals"], f"level {l} residuals")
+        got = s.loop_iters(l)
+        want = {"flux": iters[l].flux, "update": 0, "compute_step": iters[l].compute_step, "time_step": iters[l].time_step,
+                "restrict": iters[l].restrict_, "prolong": iters[l].prolong, "indirect_rw": 0}
+        assert got == want, f"level {l} LoopNumIters: {got} vs {want}"
+    assert np.allclose(rms, want_rms, rtol=1e-12, atol=0)
+    # the same cycles with one launch per loop (what the driver's per-loop timers run) and replayed from hipGraphs
+    for opts in (dict(fuse_update=0, graph=0), dict(fuse_update=1, graph=1)):
+        s2 = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+        for k, v in opts.items():
+            s2.set_option(k, v)
+        s2.run_cycles(cycles)
+        for l in range(len(levels)):
+            _bits_equal(s2.get(l, "variables"), keep[l]["variables"], f"{opts}: level {l}")
+        s2.close()
+    s.close()
+
+
+def test_cfg2_full_size_sweeps_the_bench_times(oracle):
+    """BASELINE configs[1] at size, the path bench.py times: 4 consecutive fused sweeps on the 300,763-node level from
+    the bench's perturbed state — the first takes the k_step_factor_local branch, the next three the look-ahead one
+    (the last stage of sweep n leaves sweep n+1's step-factor minima) — against the oracle's loops, sweep by sweep."""
+    import bench
+    import mgcfd
+    mg, levels = bench.build_workload(67)
+    L = levels[0]
+    lib = oracle.load()
+    edges = np.ascontiguousarray(L["edges"]).copy()
+    coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+    lib.ora_adjust_ewt(oracle.ptr(coords), len(edges), oracle.ptr(edges))
+    lib.ora_dampen_ewt(len(edges), oracle.ptr(edges), 5e-8)
+    ff = oracle.farfield()
+    nel, ni, nb, nw = L["nel"], L["n_internal"], L["n_boundary"], L["n_wall"]
+    vol = np.ascontiguousarray(L["volumes"], dtype=np.float64)
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    q = bench.perturbed_state(nel, s.far_field()[:5])
+    s.set(0, "variables", q)
+    v, f, sf = q.copy(), np.zeros_like(q), np.zeros(nel)
+    for sweep in range(4):
+        old = v.copy()
+        lib.ora_compute_step_factor(nel, oracle.ptr(v), oracle.ptr(vol), oracle.ptr(sf))
+        for j in range(3):
+            lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f))
+            lib.ora_compute_boundary_flux_edge(ni, nb, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f))
+            lib.ora_compute_wall_flux_edge(ni + nb, nw, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f), C.byref(ff))
+            lib.ora_time_step(j, nel, oracle.ptr(sf), oracle.ptr(f), oracle.ptr(old), oracle.ptr(v))
+        s.smooth(0, 1)
+        _bits_equal(s.get(0, "variables"), v, f"sweep {sweep}: variables")
+        _bits_equal(s.get(0, "step_factors"), sf, f"sweep {sweep}: step factors")
+        _bits_equal(s.get(0, "old_variables"), old, f"sweep {sweep}: old_variables")
+        _bits_equal(s.get(0, "residuals"), v - old, f"sweep {sweep}: residuals")
+    # ... and the standalone compute_flux_edge kernel the roofline figure is quoted on, plus the indirect_rw probe
+    s.zero_fluxes(0)
+    s.compute_flux_edge(0)
+    f[:] = 0.0
+    lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f))
+    _bits_equal(s.get(0, "fluxes"), f, "compute_flux_edge at size")
+    s.indirect_rw(0)
+    lib.ora_indirect_rw(0, ni, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f))
+    _bits_equal(s.get(0, "fluxes"), f, "indirect_rw at size (through the LDS tiles)")
+    s.close()
+
+
+def test_cfg1_fvcorr_like_97k_nodes_1000_iterations(oracle):
+    """BASELINE configs[0] in its synthetic form at its full 1,000 iterations: mesh_name = fvcorr,
+    46^3 box minus its centre node = 97,335 nodes, undamped weights, local time step; state bit for bit, RMS history to
+    1e-12, then the reference's own -v rule.  (The oracle itself is pinned against the REFERENCE BINARY on this very
+    input by tests/test_host_configs.py.)"""
+    import mgcfd
+    from mgcfd import meshgen
+    mg = meshgen.make_multigrid((46,), "fvcorr", seed=0, cavity_radius=0.001)
+    levels = mgcfd.generated_to_levels(mg)
+    assert levels[0]["nel"] == 97335
+    iters = 1000
+    lv, keep = _oracle_levels(oracle, levels)
+    lib = oracle.load()
+    want_rms = np.zeros(iters)
+    assert lib.ora_solve(lv, 1, 0, iters, 0, oracle.ptr(want_rms), None) == 0
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    rms = s.run_cycles(iters)
+    got = s.get(0, "variables")
+    assert s.loop_iters(0)["flux"] == 3 * iters * levels[0]["n_internal"]
+    s.close()
+    _bits_equal(got, keep[0]["variables"], "fvcorr-like 97K nodes, 1,000 iterations")
+    assert np.allclose(rms, want_rms, rtol=1e-12, atol=0)
+    assert lib.ora_identify_differences(oracle.ptr(np.ascontiguousarray(got)), oracle.ptr(keep[0]["variables"]), levels[0]["nel"], 0) == -1
+
+
+def _in_process_ranks(n, body):
+    """Run body(rank) on n threads (ranks of one process sharing this GPU); re-raise the first error."""
+    errors = []
+
+    def run(r):
+        try:
+            body(r)
+        except Exception as e:                           # pragma: no cover
+            errors.append(e)
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_cfg5_eight_way_partition_of_the_8x_level(oracle):
+    """BASELINE configs[4] at size on one GPU: the 134^3 connected level (2,406,104 nodes / 7,164,444 edges) split by
+    recursive coordinate bisection into 8 parts = 8 solvers here (threads for ranks, an in-process copy where RCCL
+    sends), one fused partitioned sweep (stage launch + halo message, three times; global-min time step over the
+    parts) — owned nodes of every part against the ORACLE's sweep of the whole mesh, bit for bit."""
+    import torch
+    import bench
+    import mgcfd
+    from mgcfd.distributed import HipSolverAdapter, PartitionedSweep
+    from mgcfd.partition import partition_level, rcb_partition
+    n_parts = 8
+    mg, levels = bench.build_workload(bench.LATTICE_8X)
+    L = levels[0]
+    assert L["nel"] == 134 ** 3
+    nel, ni, nb, nw = L["nel"], L["n_internal"], L["n_boundary"], L["n_wall"]
+    parts = partition_level(L, rcb_partition(np.asarray(L["coords"]), n_parts))
+    assert sum(p.n_owned for p in parts) == nel
+    # the oracle's sweep of the whole level
+    lib = oracle.load()
+    edges = np.ascontiguousarray(L["edges"]).copy()
+    coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+    lib.ora_adjust_ewt(oracle.ptr(coords), len(edges), oracle.ptr(edges))
+    lib.ora_dampen_ewt(len(edges), oracle.ptr(edges), 5e-8)
+    ff = oracle.farfield()
+    vol = np.ascontiguousarray(L["volumes"], dtype=np.float64)
+    q0 = bench.perturbed_state(nel, np.array(ff.var))
+    v, old, f, sf = q0.copy(), q0.copy(), np.zeros_like(q0), np.zeros(nel)
+    lib.ora_compute_step_factor(nel, oracle.ptr(v), oracle.ptr(vol), oracle.ptr(sf))
+    for j in range(3):
+        lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f))
+        lib.ora_compute_boundary_flux_edge(ni, nb, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f))
+        lib.ora_compute_wall_flux_edge(ni + nb, nw, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f), C.byref(ff))
+        lib.ora_time_step(j, nel, oracle.ptr(sf), oracle.ptr(f), oracle.ptr(old), oracle.ptr(v))
+    del edges, coords, f
+
+    dev = torch.device("cuda", 0)
+    tstream = torch.cuda.Stream()
+    solvers, sweepers = [], []
+    barrier = threading.Barrier(n_parts)
+
+    def exchange(sw):
+        barrier.wait()                                   # every part has enqueued its packs
+        for peer, buf in sw.buf_recv.items():
+            buf.copy_(sweepers[peer].buf_send[sw.part.rank])
+        barrier.wait()                                   # nobody repacks before all copies are enqueued
+
+    def allreduce_min(sw, level=0, partials=False):
+        barrier.wait()
+        if sw.part.rank == 0:
+            m = torch.stack([x.s.min_tensor(0) for x in sweepers]).min(dim=0).values
+            for x in sweepers:
+                x.s.min_tensor(0).copy_(m)
+        barrier.wait()
+
+    for P in parts:
+        s = mgcfd.Solver.from_arrays([P.level], mg.mesh_variant, n_owned=[P.n_owned])
+        s.set_stream(tstream.cuda_stream)
+        s.set(0, "variables", q0[P.global_ids])          # ghosts start current
+        solvers.append(s)
+        sweepers.append(PartitionedSweep(HipSolverAdapter(s, dev), P, None, exchange=exchange, allreduce_min=allreduce_min,
+                                         make_buffer=lambda n: torch.empty(max(n, 1), dtype=torch.float64, device=dev), fused=True))
+
+    def body(r):
+        torch.cuda.set_device(0)
+        torch.cuda.set_stream(tstream)                   # the current stream is per thread
+        sweepers[r].sweep()
+    _in_process_ranks(n_parts, body)
+    for P, s in zip(parts, solvers):
+        own = P.global_ids[:P.n_owned]
+        _bits_equal(s.get(0, "variables")[:P.n_owned], v[own], f"part {P.rank}: owned variables")
+        _bits_equal(s.get(0, "variables")[P.n_owned:], v[P.global_ids[P.n_owned:]], f"part {P.rank}: ghosts after the last message")
+        _bits_equal(s.get(0, "step_factors")[:P.n_owned], sf[own], f"part {P.rank}: step factors")
+        s.close()
+
+
+def test_cfg4_one_level_per_solver_at_full_size(oracle):
+    """BASELINE configs[3] (one multigrid level per GPU) at size, in process: four solvers, solver l sweeps only level
+    l, the restricted variables / coarse residuals move between them as whole-array device copies (where RCCL
+    point-to-point messages go); 2 V-cycles against ora_solve on every level's owner."""
+    import torch
+    import bench
+    import mgcfd
+    from mgcfd.distributed import HipSolverAdapter, LevelPerRankCycle
+    mg, levels = bench.build_hierarchy()
+    n = len(levels)
+    cycles = 2
+    lv, keep = _oracle_levels(oracle, levels)
+    lib = oracle.load()
+    want_rms = np.zeros(cycles)
+    assert lib.ora_solve(lv, n, mg.mesh_variant, cycles, 0, oracle.ptr(want_rms), None) == 0
+    dev = torch.device("cuda", 0)
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    solvers = []
+    for r in range(n):
+        s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+        s.set_stream(tstream.cuda_stream)
+        solvers.append(HipSolverAdapter(s, dev))
+    mailbox = {}
+    lock = threading.Condition()
+
+    def send(r):
+        def f(t, dst):
+            with lock:
+                mailbox[(r, dst)] = t
+                lock.notify_all()
+        return f
+
+    def recv(r):
+        def f(t, src):
+            with lock:
+                lock.wait_for(lambda: (src, r) in mailbox, timeout=120)
+                t.copy_(mailbox.pop((src, r)))
+        return f
+
+    def body(r):
+        torch.cuda.set_device(0)
+        torch.cuda.set_stream(tstream)
+        cyc = LevelPerRankCycle(solvers[r], n, r, n, send=send(r), recv=recv(r))
+        for _ in range(cycles):
+            cyc.cycle()
+        torch.cuda.synchronize()
+    _in_process_ranks(n, body)
+    for l in range(n):
+        _bits_equal(solvers[l].get(l, "variables"), keep[l]["variables"], f"level {l} on its owner")
+    for s in solvers:
+        s.s.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_bench_rehearsal_two_ranks_on_this_gpu():
+    """`python bench.py --gpus 2` from a plain invocation starts two ranks itself (here both on device 0 with gloo
+    collectives: MGCFD_BENCH_REHEARSAL=1, a functional rehearsal of the N > 1 path, not a measurement) and reports
+    n_gpus = 2 from the process group; partitioned (the N > 1 default) and mesh copies."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGCFD_BENCH_REHEARSAL="1")
+    for extra, kind, scaling in ((["--lattice", "30"], "partitioned", "strong"), (["--workload", "copies", "--lattice", "24"], "copies", "weak")):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"] + extra,
+                           capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["config"]["workload_kind"] == kind and line["scaling"] == scaling
+        assert line["value"] > 0

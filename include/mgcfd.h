@@ -72,6 +72,12 @@ enum {
                                    mgcfd_level_has_edge_once);
                                    bit 2 (4): two-phase design point — edge fluxes written to memory, then a node-centred
                                    sum (the reference's FLUX_FISSION idea); kernel-granular and unfused sweeps only.
+                                   bit 4 (16): indexed weights — a tile lists every edge's weights once, 24 B, and the
+                                   row entries (4 B) point at them; a design point: the second end point's gather
+                                   through L1 costs more than the bytes it saves (24 us against 17.5);
+                                   bit 5 (32): half rows — every internal edge of a tile evaluated once, by one of its
+                                   end points, the flux terms handed to the other through LDS (k_flux_half; levels that
+                                   qualify, see mgcfd_level_has_half_rows; others run the node gather).
                                    Every variant gives bit-identical results. */
     MGCFD_OPT_FUSE_UPDATE = 5, /* 1 (default): mgcfd_smooth / mgcfd_run_cycles run each Runge-Kutta stage as ONE
                                   launch (fluxes + time_step, same operations); 0: one launch per loop */
@@ -160,6 +166,9 @@ void mgcfd_destroy(mgcfd_solver *s);
 int mgcfd_set_option(mgcfd_solver *s, int option, int value);
 /* *yes = 1 when level `level` can run the edge-once flux variant (MGCFD_OPT_FLUX_VARIANT bit 1). */
 int mgcfd_level_has_edge_once(const mgcfd_solver *s, int level, int *yes);
+/* *yes = 1 when level `level` can run the half-row flux kernel (MGCFD_OPT_FLUX_VARIANT bit 5): no long rows, no halo node
+ * left outside LDS, at most 5 edges evaluated per node. */
+int mgcfd_level_has_half_rows(const mgcfd_solver *s, int level, int *yes);
 /* What the tiling of level `level` looks like (the figures MGCFD_VERBOSE=1 prints at creation):
  * out[0] tiles of 256 nodes, out[1] halo nodes of all tiles together, out[2] the largest halo, out[3] halo nodes a
  * tile can stage in LDS, out[4] incidence-row entries that refer to a halo node beyond that (each a gather from

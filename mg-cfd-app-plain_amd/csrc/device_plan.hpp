@@ -85,6 +85,14 @@ struct DevicePlan {
     int32_t *te_chunk_ptr = nullptr, *te_count = nullptr;
     uint16_t *te_slots = nullptr, *gat16 = nullptr;
     double *te_w = nullptr;
+    double *te_w3 = nullptr;            // [chunk*256 + p][3]: the same a-side weights as 24-byte records (k_flux_tile WMODE 2)
+    // half rows (preprocess.hpp: LevelPlan::hr_*); half == 0: not available on this level
+    int half = 0;
+    int32_t hr_pad_row = 0;             // index of a half row of padding after the last one
+    int32_t *hr_row0 = nullptr;         // [n_slices+1]
+    uint32_t *hr_code = nullptr;        // [half row][64]
+    uint16_t *hg16 = nullptr;
+    double *hr_w = nullptr;             // [half row][3][64]
     int has_tail = 0;                   // long rows: some tile leaves entries to its workgroup (k_flux_tile<..., TAIL>)
     TailPlan tail;
     // two-phase ("fission") design point: per-edge arrays, edge-flux scratch [5][n_edges_pad], rows' edge references

@@ -22,6 +22,7 @@
 //     the reference recomputes the very same per-node expressions for every incident edge.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "device_plan.hpp"
@@ -32,6 +33,17 @@
 
 namespace mgcfd {
 namespace MGCFD_KERNEL_NS {
+
+// Diagnostic build only (tools/phase_half.py, -DMGCFD_PHASES): thread 0 of every workgroup adds the wall-clock ticks
+// between phase boundaries of k_flux_half to its own slot.  The shipped build defines the marks away.
+#ifdef MGCFD_PHASES
+__device__ unsigned long long g_phase[4096 * 8];
+#define PH_MARK(k) do { if (threadIdx.x == 0) { unsigned long long now_ = wall_clock64(); g_phase[(blockIdx.x & 4095) * 8 + (k)] += now_ - ph_last_; ph_last_ = now_; } } while (0)
+#define PH_BEGIN() unsigned long long ph_last_ = wall_clock64(); if (threadIdx.x == 0) g_phase[(blockIdx.x & 4095) * 8 + 7] += 1ull
+#else
+#define PH_MARK(k) do { } while (0)
+#define PH_BEGIN() do { } while (0)
+#endif
 
 namespace {
 
@@ -351,10 +363,42 @@ __device__ __forceinline__ EdgeRow load_row(const uint16_t *__restrict__ nbr, co
     return e;
 }
 
-__device__ __forceinline__ EdgeRow pad_row()
+__device__ __forceinline__ EdgeRow pad_row_entry()
 {
     EdgeRow e;
     e.code = kT16Pad; e.fx = 0.0; e.fy = 0.0; e.fz = 0.0; e.k = 0.0;
+    return e;
+}
+
+// Indexed weights (WMODE 2): a tile's internal edges are listed ONCE (preprocess.cpp: te_*; 24 bytes each, the a-side
+// weights -0.5*e), and a row entry is 4 bytes: the neighbour's LDS slot (nbr16) and the position of the entry's edge in
+// its tile's list (gat16, role bit = this node is the edge's b end: it sees the negated weights).  Both end points of
+// an edge inside the tile read the same 24 bytes — the second one from L1/L2 — so a launch moves 24 B per edge and
+// tile + 4 B per entry instead of 26-34 B per entry (two per edge); the length factor is recomputed from the weights.
+struct RowRef { uint32_t code, pos; };
+
+__device__ __forceinline__ RowRef load_ref(const uint16_t *__restrict__ nbr16, const uint16_t *__restrict__ gat16, int64_t row, int lane)
+{
+    RowRef r;
+    r.code = nbr16[(row << 6) + lane];
+    r.pos = gat16[(row << 6) + lane];
+    return r;
+}
+
+__device__ __forceinline__ EdgeRow gather_weights(const double *__restrict__ tw, const RowRef &r)
+{
+    const uint32_t p = r.pos & kT16SlotMask;
+    const bool pad = p == kT16Pad;
+    const double *wp = tw + (pad ? 0u : p) * 3u;
+    const double x = wp[0], y = wp[1], z = wp[2];
+    const bool neg = (r.pos & kT16RoleB) != 0;
+    EdgeRow e;
+    e.code = r.code;
+    // (padding must carry zero weights: its +-0.0 contribution is what leaves a sum that started at +0.0 unchanged)
+    e.fx = pad ? 0.0 : (neg ? -x : x);
+    e.fy = pad ? 0.0 : (neg ? -y : y);
+    e.fz = pad ? 0.0 : (neg ? -z : z);
+    e.k = 0.0;
     return e;
 }
 
@@ -494,7 +538,8 @@ __device__ __forceinline__ void boundary_rows(const NodeQ &me, const FluxC &fm, 
 // squares and the look-ahead (last stage), 1 = neither: the paths a stage cannot take are compiled out.
 // TAIL: the level has long rows (TailPlan): the per-node loop stops at the tile's row limit and the workgroup
 // evaluates the remaining entries together (see below).
-template <int MINW, bool LOADK, bool FUSE, bool ACC, int ROLE, bool TAIL>
+// WMODE: 0 = the length factor k recomputed from the row's weights, 1 = k streamed with them, 2 = indexed weights (above).
+template <int MINW, int WMODE, bool FUSE, bool ACC, int ROLE, bool TAIL>
 __global__ void __launch_bounds__(kBlock, MINW)
 k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at wave launch (Makefile:
             // -amdgpu-kernarg-preload-count): what the first loads of the prologue need comes first
@@ -503,8 +548,12 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
             const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
             const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
-            double *__restrict__ fluxes, int classes, FusedStep fs, TailPlan tp)
+            double *__restrict__ fluxes, int classes, FusedStep fs, TailPlan tp,
+            const uint16_t *__restrict__ gat16, const int32_t *__restrict__ te_chunk_ptr, const double *__restrict__ te_w3)
 {
+    constexpr bool LOADK = WMODE == 1;
+    constexpr bool IDXW = WMODE == 2;
+    static_assert(!(IDXW && TAIL), "indexed weights: levels without long rows only");
     __shared__ double2 tile[kTileCap * kLdsRecD2];
 
     // FUSE: this launch is a whole Runge-Kutta stage — the node's complete flux never leaves
@@ -539,6 +588,17 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     const int64_t hnode = has_halo ? int64_t(hid) : i;
     double o0, o1, o2, o3, o4, g0, g1, g2, g3, g4;
     EdgeRow e0, e1;
+    // indexed weights: the first four rows' references go out right behind the halo ids (the weights they point at are
+    // the second link of a chain as long as ids -> halo state); the tile's edge list starts at its first chunk
+    RowRef i0{}, i1{}, i2{}, i3{};
+    const double *tw = nullptr;
+    if (IDXW) {
+        i0 = load_ref(nbr16, gat16, n_int > 0 ? row0 : pad_row, lane);
+        i1 = load_ref(nbr16, gat16, n_int > 1 ? row0 + 1 : pad_row, lane);
+        i2 = load_ref(nbr16, gat16, n_int > 2 ? row0 + 2 : pad_row, lane);
+        i3 = load_ref(nbr16, gat16, n_int > 3 ? row0 + 3 : pad_row, lane);
+        tw = te_w3 + int64_t(te_chunk_ptr[t]) * (kEdgeChunk * 3);
+    }
     if (FUSE && ROLE == 5) {
         // The input state of this stage does not exist in memory: it is the first stage's time_step,
         // old + (min_dt/volume/vin_div) * flux, applied here to every staged node (own and halo) from the
@@ -557,8 +617,11 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         const double h0 = fl[hnode], h1 = fl[stride + hnode], h2 = fl[2 * stride + hnode], h3 = fl[3 * stride + hnode],
                      h4 = fl[4 * stride + hnode];
         const double vh = fs.volumes[hnode];
-        e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
-        e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
+        if (IDXW) { e0 = gather_weights(tw, i0); e1 = gather_weights(tw, i1); }
+        else {
+            e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
+            e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
+        }
         double pm = pmv[0];
 #pragma unroll
         for (int u = 1; u < kPartPre; u++) pm = fmin(pm, pmv[u]);
@@ -584,8 +647,11 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         g0 = q[hnode]; g1 = q[stride + hnode]; g2 = q[2 * stride + hnode]; g3 = q[3 * stride + hnode]; g4 = q[4 * stride + hnode];
         // (a row the slice does not have is read from pad_row, a row of padding after the last one: the
         //  load itself is never conditional, so the compiler can count the loads in flight exactly)
-        e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
-        e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
+        if (IDXW) { e0 = gather_weights(tw, i0); e1 = gather_weights(tw, i1); }
+        else {
+            e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
+            e1 = load_row<LOADK>(nbr16, w, n_int > 1 ? row0 + 1 : pad_row, lane);
+        }
     }
     // (the step-factor partials: wanted only at the staging barrier, so requested after everything on the critical chain)
     if (FUSE && ROLE == 0) {                         // (role 0 is launched only with fs.partial_min set)
@@ -670,6 +736,16 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     {
         // every pair but the last, each prefetching the pair after it
         int32_t r = 0;
+        if (IDXW) {
+            // references two pairs ahead, the weights they point at one pair ahead
+            for (; r + 2 < n_int; r += 2) {
+                const RowRef i4 = load_ref(nbr16, gat16, r + 4 < n_int ? row0 + r + 4 : pad_row, lane);
+                const RowRef i5 = load_ref(nbr16, gat16, r + 5 < n_int ? row0 + r + 5 : pad_row, lane);
+                const EdgeRow e2 = gather_weights(tw, i2), e3 = gather_weights(tw, i3);
+                MGCFD_ROW_PAIR();
+                e0 = e2; e1 = e3; i2 = i4; i3 = i5;
+            }
+        } else
         for (; r + 2 < n_int; r += 2) {
             const EdgeRow e2 = load_row<LOADK>(nbr16, w, row0 + r + 2, lane);
             const EdgeRow e3 = load_row<LOADK>(nbr16, w, r + 3 < n_int ? row0 + r + 3 : pad_row, lane);
@@ -1019,6 +1095,185 @@ k_flux_edge_once(const double *__restrict__ q, const int32_t *__restrict__ tile_
 }
 
 // ------------------------------------------------------------------------------------------
+// flux_half: the same three loops with every internal edge of a tile evaluated ONCE, by one of its end points.
+//
+// k_flux_tile streams a 26-34 byte row entry and evaluates the flux for BOTH end points of every edge; its time is the
+// time to move those bytes (the indirect_rw probe through the same tiles takes 0.96 of it).  Here the plan gives every
+// internal edge that touches a tile one EVALUATOR among its end points inside the tile (preprocess.hpp: half rows), so
+// a tile streams one 26-byte entry per edge.  With the node records staged as in k_flux_tile, every lane walks its
+// half rows — its own record in registers, the other end's from LDS, the same edge_flux as seen from this node — and
+// keeps the results (at most kHalfMaxRows x 5 values) in registers; when the whole workgroup is done the records
+// are dead and the results take their place in LDS (position = half row within the tile * 64 + lane, five arrays: conflict-free
+// stores); every node then adds its incident edges in its own row order = the reference's accumulation order, its own
+// evaluations as they are, those of its neighbours negated — which is what the reference's expressions for the other
+// end evaluate to bit for bit (every term negates exactly).  An edge cut by the tile boundary is evaluated by the tile
+// of each end, from identical operands.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ EdgeRow load_half_row(const uint32_t *__restrict__ code, const double *__restrict__ w3, int64_t row, int lane)
+{
+    EdgeRow e;
+    e.code = code[(row << 6) + lane];
+    const double *wr = w3 + row * (3 * kSlice) + lane;
+    e.fx = wr[0]; e.fy = wr[64]; e.fz = wr[128];
+    e.k = 0.0;
+    return e;
+}
+
+template <bool FUSE, bool ACC>
+__global__ void __launch_bounds__(kBlock, 3)
+k_flux_half(// (the first 16 dwords are preloaded into SGPRs: what the prologue's first loads need)
+            const double *__restrict__ q, const int32_t *__restrict__ tile_halo, uint32_t n_tiles, int32_t hr_pad_row,
+            int64_t stride, int64_t nel, const int32_t *__restrict__ hr_row0, const uint32_t *__restrict__ hr_code,
+            const double *__restrict__ hr_w, const uint16_t *__restrict__ hg16, const int32_t *__restrict__ slice_row0,
+            const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd, int32_t pad_row,
+            const uint16_t *__restrict__ nbr16, const double *__restrict__ w, FarField ff, double *__restrict__ fluxes,
+            int classes, FusedStep fs)
+{
+    __shared__ double2 tile[kTileCap * kLdsRecD2];
+
+    PH_BEGIN();
+    double min_dt = 0.0;
+    if (FUSE && fs.partial_min) min_dt = block_min_of_partials(fs.partial_min, fs.n_partial);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const unsigned t = xcd_contiguous_block(blockIdx.x, n_tiles);
+    const int64_t i = int64_t(t) * kTile + tid;
+    const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
+
+    // load issue order as in k_flux_tile: halo ids, own state, the first two half rows, then the halo state by id;
+    // nothing under a branch
+    const int32_t *hrow = tile_halo + int64_t(t) * kHaloStride;
+    const int32_t hid = hrow[tid];
+    const int32_t hid2 = tid < kHaloStride - kBlock ? hrow[kBlock + tid] : -1;
+    const int32_t h0 = hr_row0[slice];
+    const int32_t h0_tile = hr_row0[slice & ~3];               // the tile's first half row: flux-term positions count from it
+    const int32_t n_h = (classes & 1) ? hr_row0[slice + 1] - h0 : 0;
+    const int32_t row0 = slice_row0[slice];
+    const int32_t n_int = (classes & 1) ? rows_int[slice] : 0;
+    const int32_t n_bnd = rows_bnd[slice];
+    const double o0 = q[i], o1 = q[stride + i], o2 = q[2 * stride + i], o3 = q[3 * stride + i], o4 = q[4 * stride + i];
+    EdgeRow e0 = load_half_row(hr_code, hr_w, n_h > 0 ? h0 : hr_pad_row, lane);
+    EdgeRow e1 = load_half_row(hr_code, hr_w, n_h > 1 ? h0 + 1 : hr_pad_row, lane);
+    const int64_t hnode = hid >= 0 ? int64_t(hid) : i;
+    const double g0 = q[hnode], g1 = q[stride + hnode], g2 = q[2 * stride + hnode], g3 = q[3 * stride + hnode], g4 = q[4 * stride + hnode];
+
+    // ---- phase 1: stage + derive, as k_flux_tile ----
+#ifdef MGCFD_ABL_DERIVE        /* diagnostic: nothing derived (results wrong) */
+    auto fake = [](double r, double mx, double my, double mz, double en) { NodeQ n; n.rho = r; n.mx = mx; n.my = my; n.mz = mz; n.en = en; n.vx = mx; n.vy = my; n.vz = mz; n.p = en; n.speed = r; n.c = r; return n; };
+    const NodeQ me = fake(o0, o1, o2, o3, o4);
+    lds_store_record(tile, uint32_t(tid), me);
+    lds_store_record(tile, uint32_t(kTile + tid), fake(g0, g1, g2, g3, g4));
+#else
+    const NodeQ me = make_nodeq(o0, o1, o2, o3, o4);
+    lds_store_record(tile, uint32_t(tid), me);
+    lds_store_record(tile, uint32_t(kTile + tid), make_nodeq(g0, g1, g2, g3, g4));     // unconditional, see k_flux_tile
+#endif
+    if (hid2 >= 0) lds_store_record(tile, uint32_t(kTile + kBlock + tid), load_and_derive(q, stride, hid2));
+    __syncthreads();
+    PH_MARK(0);
+
+    // ---- phase 2: this node's half rows one at a time, the two after it in flight.  (One at a time, and the node's own
+    //      flux contribution recomputed per edge: the results of up to kHalfMaxRows edges wait in registers, and the
+    //      kernel is bound by the bytes it moves, not by its arithmetic.) ----
+    Flux5 F[kHalfMaxRows];
+#pragma unroll
+    for (int j = 0; j < kHalfMaxRows; j++) { F[j].d = 0.0; F[j].mx = 0.0; F[j].my = 0.0; F[j].mz = 0.0; F[j].en = 0.0; }
+    uint32_t live = 0;                              // bit j: half row j of this lane holds an edge
+#pragma unroll
+    for (int j = 0; j < kHalfMaxRows; j++) {
+        if (j < n_h) {                              // (uniform over the wave)
+            EdgeRow e2 = pad_row_entry();
+            if (j + 2 < kHalfMaxRows)               // compile time
+                e2 = load_half_row(hr_code, hr_w, j + 2 < n_h ? h0 + j + 2 : hr_pad_row, lane);
+            const uint32_t s0 = e0.code & kT16SlotMask;
+            const bool v0 = s0 != kT16Pad;
+            const NodeQ n0 = lds_load_record(tile, v0 ? s0 : uint32_t(tid));
+            // an evaluation another node owns (the plan found no room in that node's lane): its record comes from LDS too
+            NodeQ m0 = me;
+            if (__builtin_expect(__any((e0.code & kHalfForeign) != 0), 0)) {
+                if (e0.code & kHalfForeign) m0 = lds_load_record(tile, (e0.code >> 16) & 0xFFu);
+            }
+#ifdef MGCFD_ABL_EVAL          /* diagnostic: the evaluation replaced by a few adds (results wrong) */
+            F[j].d = m0.rho + n0.rho + e0.fx; F[j].mx = m0.mx + n0.mx + e0.fy; F[j].my = m0.my + n0.my + e0.fz; F[j].mz = m0.mz + n0.mz + n0.c; F[j].en = m0.en + n0.en + n0.p + n0.vx + n0.speed;
+#else
+            F[j] = edge_flux<false>(m0, flux_contribution(m0), n0, e0);
+#endif
+            live |= (v0 ? 1u : 0u) << j;
+            e0 = e1; e1 = e2;
+        }
+    }
+    // the node's gather list: requested now, wanted after the hand-over
+    uint32_t gc[kGatherPre];
+#pragma unroll
+    for (int k = 0; k < kGatherPre; k++) gc[k] = hg16[(int64_t(k < n_int ? row0 + k : pad_row) << 6) + lane];
+
+    // ---- phase 3: the records are dead; the edge fluxes take their place ----
+    double *fb = reinterpret_cast<double *>(tile);
+    PH_MARK(1);
+    __syncthreads();
+    PH_MARK(2);
+#pragma unroll
+    for (int j = 0; j < kHalfMaxRows; j++) {
+        if (live & (1u << j)) {
+            double *slot = fb + (h0 - h0_tile + j) * kSlice + lane;
+            slot[0] = F[j].d; slot[kHalfSlots] = F[j].mx; slot[2 * kHalfSlots] = F[j].my; slot[3 * kHalfSlots] = F[j].mz; slot[4 * kHalfSlots] = F[j].en;
+        }
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+    if (ACC) {
+        a0 = fluxes[i]; a1 = fluxes[stride + i]; a2 = fluxes[2 * stride + i];
+        a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
+    }
+    __syncthreads();
+    PH_MARK(3);
+
+    // ---- phase 4: every node adds its incident edges in row order ----
+    auto add_entry = [&](uint32_t code) {
+        const uint32_t p = code & kT16SlotMask;
+        if (p == kT16Pad) return;
+        const double *sl = fb + p;
+        const double f0 = sl[0], f1 = sl[kHalfSlots], f2 = sl[2 * kHalfSlots], f3 = sl[3 * kHalfSlots], f4 = sl[4 * kHalfSlots];
+        const bool neg = (code & kT16RoleB) != 0;                   // evaluated by the other end point
+        a0 = neg ? a0 - f0 : a0 + f0;  a1 = neg ? a1 - f1 : a1 + f1;  a2 = neg ? a2 - f2 : a2 + f2;
+        a3 = neg ? a3 - f3 : a3 + f3;  a4 = neg ? a4 - f4 : a4 + f4;
+    };
+#pragma unroll
+    for (int k = 0; k < kGatherPre; k++)
+        if (k < n_int) add_entry(gc[k]);
+    for (int32_t r = kGatherPre; r < n_int; r++) add_entry(hg16[(int64_t(row0 + r) << 6) + lane]);
+
+    PH_MARK(4);
+    if ((classes & 6) && n_bnd > 0) {
+        // (inline, as in k_flux_tile: handing the five sums to boundary_rows by reference parks two of them in scratch)
+        const FluxC fm = flux_contribution(me);
+        const int64_t first_bnd = int64_t(row0) + rows_int[slice];
+        for (int32_t r = 0; r < n_bnd; r++) {
+            const EdgeRow e = load_row<false>(nbr16, w, first_bnd + r, lane);
+            const double fx = e.fx, fy = e.fy, fz = e.fz;
+            if (e.code == kT16Wall && (classes & 2)) {
+                // flux_boundary_kernel.elemfunc.c:37-64: pressure force only
+                a0 += 0.0;
+                a1 += fx * me.p;
+                a2 += fy * me.p;
+                a3 += fz * me.p;
+                a4 += 0.0;
+            } else if (e.code == kT16Far && (classes & 4)) {
+                // flux_wall_kernel.elemfunc.c:51-88: average with the far-field state
+                a0 += fx * (ff.var[1] + me.mx) + fy * (ff.var[2] + me.my) + fz * (ff.var[3] + me.mz);
+                a4 += fx * (ff.fc_de[0] + fm.ex) + fy * (ff.fc_de[1] + fm.ey) + fz * (ff.fc_de[2] + fm.ez);
+                a1 += fx * (ff.fc_mx[0] + fm.xx) + fy * (ff.fc_mx[1] + fm.xy) + fz * (ff.fc_mx[2] + fm.xz);
+                a2 += fx * (ff.fc_my[0] + fm.xy) + fy * (ff.fc_my[1] + fm.yy) + fz * (ff.fc_my[2] + fm.yz);
+                a3 += fx * (ff.fc_mz[0] + fm.xz) + fy * (ff.fc_mz[1] + fm.yz) + fz * (ff.fc_mz[2] + fm.zz);
+            }
+        }
+    }
+
+    finish_node<FUSE>(i, nel, stride, a0, a1, a2, a3, a4, fluxes, fs, min_dt, t);
+    PH_MARK(5);
+}
+
+// ------------------------------------------------------------------------------------------
 // Two-phase ("fission") design point, MGCFD_OPT_FLUX_VARIANT bit 2 — the GPU form of the
 // reference's FLUX_FISSION build (flux_kernel.elemfunc.c:193-204 + update_edges,
 // cfd_loops.cpp:159-213): phase 1 evaluates every internal edge once, edge-parallel, and writes its
@@ -1153,7 +1408,13 @@ k_indirect_rw_tile(const double *__restrict__ q, const int32_t *__restrict__ til
     const int32_t hid2 = tid < kHaloStride - kBlock ? hrow[kBlock + tid] : -1;
     const int32_t row0 = slice_row0[slice];
     const int32_t n_int = rows_int[slice];
+#if defined(MGCFD_ABL_NO_HALO)      /* diagnostic: the halo state not gathered: the dependent ids -> state chain is gone (results wrong) */
+    const int64_t hnode = hid >= 0 ? i : i;
+#elif defined(MGCFD_ABL_HALO_COALESCED)   /* diagnostic: the chain ids -> state kept, but the gather made contiguous (results wrong) */
+    const int64_t hnode = hid >= 0 ? ((int64_t(__builtin_amdgcn_readfirstlane(hid)) & ~int64_t(255)) + tid) : i;
+#else
     const int64_t hnode = hid >= 0 ? int64_t(hid) : i;
+#endif
     const double o0 = q[i], o1 = q[stride + i], o2 = q[2 * stride + i], o3 = q[3 * stride + i], o4 = q[4 * stride + i];
     const double g0 = q[hnode], g1 = q[stride + hnode], g2 = q[2 * stride + hnode], g3 = q[3 * stride + hnode], g4 = q[4 * stride + hnode];
     EdgeRow e0 = load_row<LOADK>(nbr16, w, n_int > 0 ? row0 : pad_row, lane);
@@ -1176,7 +1437,11 @@ k_indirect_rw_tile(const double *__restrict__ q, const int32_t *__restrict__ til
     auto entry = [&](const EdgeRow &e) {
         const uint32_t s = e.code & kT16SlotMask;
         const bool v = s != kT16Pad;
+#if defined(MGCFD_ABL_LDS_OWN)      /* diagnostic: every lane reads its own record: no bank conflicts (results wrong) */
+        const NodeQ n = lds_load_record(tile, uint32_t(tid));
+#else
         const NodeQ n = lds_load_record(tile, v ? s : uint32_t(tid));
+#endif
         keep_alive(n.vx); keep_alive(n.vy); keep_alive(n.vz); keep_alive(n.p); keep_alive(n.speed); keep_alive(n.c);
         keep_alive(e.fx); keep_alive(e.fy); keep_alive(e.fz);
         if (LOADK) keep_alive(e.k);
@@ -1642,15 +1907,23 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     const dim3 grid(p.n_tiles);
     FusedStep fs{};
     if (fused) fs = *fused;
+
     // 3 tiles of 52.5 KiB LDS fit a CU => at least 3 waves per SIMD wanted
-#define MGCFD_TILE_LAUNCH_T(LOADK, FUSE, ACC, ROLE, TAIL)                                                      \
-    hipLaunchKernelGGL((k_flux_tile<3, LOADK, FUSE, ACC, ROLE, TAIL>), grid, block, 0, st, q, p.tile_halo,     \
+#define MGCFD_TILE_LAUNCH_T(WMODE, FUSE, ACC, ROLE, TAIL)                                                      \
+    hipLaunchKernelGGL((k_flux_tile<3, WMODE, FUSE, ACC, ROLE, TAIL>), grid, block, 0, st, q, p.tile_halo,     \
                        uint32_t(p.n_tiles), p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.rows_bnd,  \
-                       p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs, p.tail)
+                       p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs, p.tail, p.gat16,     \
+                       p.te_chunk_ptr, p.te_w3)
     // levels with long rows (tetrahedral meshes, hubs) run the instantiation that hands them to the workgroup
     const bool tail = p.has_tail && (classes & 1);
+    // variant bit 4 (16): indexed weights — every edge's weights once per tile (needs the tile edge lists: p.edge_once)
+    const bool indexed = (variant & 16) && p.edge_once && p.te_w3 && !tail;
 #define MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, ROLE)                                                            \
-    do { if (tail) MGCFD_TILE_LAUNCH_T(LOADK, FUSE, ACC, ROLE, true); else MGCFD_TILE_LAUNCH_T(LOADK, FUSE, ACC, ROLE, false); } while (0)
+    do {                                                                                                       \
+        if (tail) MGCFD_TILE_LAUNCH_T(LOADK ? 1 : 0, FUSE, ACC, ROLE, true);                                   \
+        else if (indexed) MGCFD_TILE_LAUNCH_T(2, FUSE, ACC, ROLE, false);                                      \
+        else MGCFD_TILE_LAUNCH_T(LOADK ? 1 : 0, FUSE, ACC, ROLE, false);                                       \
+    } while (0)
     // fused stages: the role decides which optional paths exist in the launched kernel
     const int role = !fused ? 1 : (fs.vin_flux ? 5 : fs.partial_min ? 0 : (fs.next_partial_min ? 3 : (fs.next_legacy_sf ? 4 : (fs.residuals ? 2 : 1))));
 #define MGCFD_TILE_LAUNCH(LOADK, FUSE, ACC)                                                                    \
@@ -1673,6 +1946,19 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
         else
             hipLaunchKernelGGL(k_fission_node_sum<false>, grid, block, 0, st, p.nel, p.stride, p.n_edges_pad, q, p.slice_row0,
                                p.rows_int, p.rows_bnd, p.row_edge, p.nbr16, p.w, p.edge_flux, ff, fluxes, classes);
+        return;
+    }
+    // variant bit 5 (32): half rows — every edge evaluated once per tile by one of its end points (k_flux_half); the
+    // split sweep's absorbed first stage (role 5) stays with the node gather
+    if ((variant & 32) && p.half && (classes & 1) && !(fused && fs.vin_flux)) {
+#define MGCFD_HALF_LAUNCH(FUSE, ACC)                                                                            \
+    hipLaunchKernelGGL((k_flux_half<FUSE, ACC>), grid, block, 0, st, q, p.tile_halo, uint32_t(p.n_tiles),       \
+                       p.hr_pad_row, p.stride, p.nel, p.hr_row0, p.hr_code, p.hr_w, p.hg16, p.slice_row0,       \
+                       p.rows_int, p.rows_bnd, p.pad_row, p.nbr16, p.w, ff, fluxes, classes, fs)
+        if (fused) MGCFD_HALF_LAUNCH(true, false);
+        else if (accumulate) MGCFD_HALF_LAUNCH(false, true);
+        else MGCFD_HALF_LAUNCH(false, false);
+#undef MGCFD_HALF_LAUNCH
         return;
     }
     const bool loadk = (variant & 1) == 0;      // odd variants recompute k = -|e|*s*0.5 from the weights
@@ -1789,3 +2075,12 @@ void launch_prolong(hipStream_t st, const DevicePlan &p, int64_t stride_coarse, 
 
 } // namespace MGCFD_KERNEL_NS
 } // namespace mgcfd
+
+#if defined(MGCFD_PHASES) && defined(MGCFD_PHASE_EXPORT)
+extern "C" void mgcfd_debug_phases(unsigned long long *out, int reset)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mgcfd::MGCFD_KERNEL_NS::g_phase), sizeof(unsigned long long) * 4096 * 8);
+    if (reset) { static unsigned long long z[4096 * 8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(mgcfd::MGCFD_KERNEL_NS::g_phase), z, sizeof(z)); }
+}
+#endif

@@ -4,7 +4,9 @@
 #include "preprocess.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -292,19 +294,55 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     }
     else if (opt.ordering == 1) order = cuthill_mckee(g, nel);
     else { order.resize(static_cast<size_t>(nel)); std::iota(order.begin(), order.end(), 0); }
+    // ---- half rows (preprocess.hpp): which end point evaluates an internal edge.  An edge whose end points share a
+    //      tile (and are both owned) is evaluated by ONE of them; any other edge by each owned end point in its own tile.
+    //      Orientation: greedy to the less loaded end, then flips from a node to a neighbour at least two below it until
+    //      none is left (loads of adjacent nodes then differ by at most one along every such edge). ----
+    std::vector<int8_t> half_eval_a(static_cast<size_t>(L.n_internal), int8_t(-1));
+    std::vector<int32_t> half_load(static_cast<size_t>(nel), 0);
+    {
+        std::vector<int32_t> tile_of(static_cast<size_t>(nel));
+        for (int64_t n = 0; n < nel; n++) tile_of[static_cast<size_t>(order[static_cast<size_t>(n)])] = static_cast<int32_t>(n / kTile);
+        std::vector<int64_t> shared;
+        for (int64_t k = 0; k < L.n_internal; k++) {
+            const mgcfd_edge &E = edges[static_cast<size_t>(L.internal_start + k)];
+            if (owned(E.a) && owned(E.b) && tile_of[static_cast<size_t>(E.a)] == tile_of[static_cast<size_t>(E.b)]) shared.push_back(k);
+            else { if (owned(E.a)) half_load[static_cast<size_t>(E.a)]++; if (owned(E.b)) half_load[static_cast<size_t>(E.b)]++; }
+        }
+        for (int64_t k : shared) {
+            const mgcfd_edge &E = edges[static_cast<size_t>(L.internal_start + k)];
+            const bool to_a = half_load[static_cast<size_t>(E.a)] <= half_load[static_cast<size_t>(E.b)];
+            half_eval_a[static_cast<size_t>(k)] = to_a ? 1 : 0;
+            half_load[static_cast<size_t>(to_a ? E.a : E.b)]++;
+        }
+        for (int pass = 0; pass < 64; pass++) {
+            bool moved = false;
+            for (int64_t k : shared) {
+                const mgcfd_edge &E = edges[static_cast<size_t>(L.internal_start + k)];
+                const bool at_a = half_eval_a[static_cast<size_t>(k)] == 1;
+                int32_t &from = half_load[static_cast<size_t>(at_a ? E.a : E.b)], &to = half_load[static_cast<size_t>(at_a ? E.b : E.a)];
+                if (from >= to + 2) { from--; to++; half_eval_a[static_cast<size_t>(k)] = at_a ? 0 : 1; moved = true; }
+            }
+            if (!moved) break;
+        }
+    }
     std::vector<int32_t> bnd_count(static_cast<size_t>(nel), 0);
     for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++) if (owned(edges[e].b)) bnd_count[static_cast<size_t>(edges[e].b)]++;
     for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++) if (owned(edges[e].b)) bnd_count[static_cast<size_t>(edges[e].b)]++;
     if (opt.degree_sort) {
         // Inside each tile sort by (internal degree, boundary faces) so the 64 nodes of a
         // slice have equal row counts and ELL padding stays small; tile membership is kept.
+        // Third key: the number of edges the node evaluates in the half-row plan (decided above: it depends on which
+        // nodes share a tile, not on their order inside it), so the lanes of a slice walk equally many half rows.
+        const std::vector<int32_t> &cut_count = half_load;
         const int64_t W = kTile;
         for (int64_t s = 0; s < nel; s += W) {
             auto b = order.begin() + s, e = order.begin() + std::min(nel, s + W);
             std::stable_sort(b, e, [&](int32_t x, int32_t y) {
                 int dx = rows_of(x), dy = rows_of(y);
                 if (dx != dy) return dx > dy;
-                return bnd_count[static_cast<size_t>(x)] > bnd_count[static_cast<size_t>(y)];
+                if (bnd_count[static_cast<size_t>(x)] != bnd_count[static_cast<size_t>(y)]) return bnd_count[static_cast<size_t>(x)] > bnd_count[static_cast<size_t>(y)];
+                return cut_count[static_cast<size_t>(x)] > cut_count[static_cast<size_t>(y)];
             });
         }
     }
@@ -386,6 +424,13 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     P.edge_once = true;
     {
         std::vector<int32_t> halo, tile_edges;
+        std::vector<std::array<int64_t, 4>> half_ents;      // {edge, entry index, thread of the node, its half row or -1}
+        std::vector<std::pair<int32_t, int32_t>> half_where;
+        P.half = true;
+        P.hr_row0.assign(static_cast<size_t>(P.n_slices) + 1, 0);
+        P.hr_code.clear(); P.hr_w.clear(); P.hr_foreign = 0;
+        P.hg16.assign(P.nbr.size(), static_cast<uint16_t>(kT16Pad));
+        P.hr_entries = 0;
         int64_t te_total = 0;
         const int32_t halo_cap = kTileCap - kTile;
         const int32_t ovf_cap = int32_t(kT16Far) - kTileCap;          // overflow slots a 15-bit code can name
@@ -504,6 +549,98 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                 }
                 P.te_chunk_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(chunk0 + n_chunks);
             }
+            // half rows: every entry of this tile whose node OWNS the evaluation of its edge (half_eval_a, decided before
+            // the nodes were ordered) is placed in a (half row, lane) slot of the tile: in the node's own lane while its
+            // slice has rows left (the evaluator then has its record in registers), otherwise in any lane with a free
+            // slot ("foreign": that lane reads the owner's record from LDS as well).  A tile gets ceil(evaluations / 64)
+            // half rows, spread over its slices in proportion to what their nodes own, so slots are ~98 % used.
+            if (P.half) {
+                if (n_halo > staged) P.half = false;
+                const int32_t n_here = static_cast<int32_t>(std::min<int64_t>(kTile, nel - base));
+                int32_t own[kTile] = {0};
+                half_ents.clear();
+                for (int32_t tid = 0; tid < n_here; tid++) {
+                    const int32_t n = base + tid;
+                    const int32_t s = n / kSlice, lane = n % kSlice;
+                    for (int32_t r = 0; r < P.rows_int[static_cast<size_t>(s)]; r++) {
+                        const int64_t e = (int64_t(P.slice_row0[static_cast<size_t>(s)]) + r) * kSlice + lane;
+                        const int32_t ge = entry_edge[static_cast<size_t>(e)];
+                        if (ge < 0) continue;
+                        const int8_t who = half_eval_a[static_cast<size_t>(ge)];        // -1: both end points (each in its tile), 1: a, 0: b
+                        const bool is_a = (P.nbr[static_cast<size_t>(e)] & kRoleB) == 0;
+                        const bool evaluates = who < 0 || (who == 1) == is_a;
+                        if (evaluates) own[tid]++;
+                        half_ents.push_back({ge, e, tid, evaluates ? 1 : 0});
+                    }
+                }
+                int32_t n_eval = 0, own_slice[kTile / kSlice] = {0}, lanes[kTile / kSlice] = {0};
+                for (int32_t tid = 0; tid < n_here; tid++) { n_eval += own[tid]; own_slice[tid / kSlice] += own[tid]; lanes[tid / kSlice]++; }
+                // rows per slice: proportional to what the slice's nodes own, then one more wherever the capacity is short
+                int32_t rows_h[kTile / kSlice] = {0};
+                int32_t cap_total = 0;
+                for (int32_t sl = 0; sl < kTile / kSlice; sl++) {
+                    rows_h[sl] = lanes[sl] ? own_slice[sl] / lanes[sl] : 0;                 // floor of the slice's mean
+                    cap_total += rows_h[sl] * lanes[sl];
+                }
+                while (cap_total < n_eval) {
+                    int32_t best = -1; double need = -1.0;
+                    for (int32_t sl = 0; sl < kTile / kSlice; sl++) {
+                        if (!lanes[sl] || rows_h[sl] >= kHalfMaxRows) continue;
+                        const double d = double(own_slice[sl]) / lanes[sl] - rows_h[sl];      // how far the slice's mean is above its rows
+                        if (d > need) { need = d; best = sl; }
+                    }
+                    if (best < 0) { P.half = false; break; }
+                    rows_h[best]++; cap_total += lanes[best];
+                }
+                for (int32_t sl = 0; sl < kTile / kSlice; sl++)
+                    P.hr_row0[static_cast<size_t>(s0 + sl) + 1] = P.hr_row0[static_cast<size_t>(s0 + sl)] + rows_h[sl];
+                if (P.hr_row0[static_cast<size_t>(s1)] - P.hr_row0[static_cast<size_t>(s0)] > kHalfTileRows) P.half = false;
+                if (P.half) {
+                    const size_t rows_end = static_cast<size_t>(P.hr_row0[static_cast<size_t>(s1)]);
+                    P.hr_code.resize(rows_end * kSlice, kHalfPad);
+                    P.hr_w.resize(rows_end * 3 * kSlice, 0.0);
+                    int32_t used[kTile] = {0};
+                    half_where.clear();                                   // (edge, position of its flux terms) of this tile's evaluations
+                    auto place = [&](const std::array<int64_t, 4> &en, int32_t host) {
+                        const int32_t owner = static_cast<int32_t>(en[2]);
+                        const int32_t sl = host / kSlice, lane = host % kSlice, j = used[host]++;
+                        const size_t hrow = static_cast<size_t>(P.hr_row0[static_cast<size_t>(s0 + sl)]) + static_cast<size_t>(j);
+                        const int64_t e = en[1];
+                        P.hr_code[hrow * kSlice + lane] = uint32_t(P.nbr16[static_cast<size_t>(e)]) | (uint32_t(owner) << 16) | (host != owner ? kHalfForeign : 0u);
+                        const EdgeW &W = P.w[static_cast<size_t>(e)];
+                        P.hr_w[(hrow * 3 + 0) * kSlice + lane] = W.x;
+                        P.hr_w[(hrow * 3 + 1) * kSlice + lane] = W.y;
+                        P.hr_w[(hrow * 3 + 2) * kSlice + lane] = W.z;
+                        const int32_t pos = static_cast<int32_t>(hrow - static_cast<size_t>(P.hr_row0[static_cast<size_t>(s0)])) * kSlice + lane;
+                        P.hg16[static_cast<size_t>(e)] = static_cast<uint16_t>(pos);
+                        half_where.emplace_back(static_cast<int32_t>(en[0]), pos);
+                        P.hr_entries++;
+                        if (host != owner) P.hr_foreign++;
+                    };
+                    // own lane first (entries come node by node, in the node's row order) ...
+                    for (auto &en : half_ents) {
+                        if (en[3] != 1) continue;
+                        const int32_t tid = static_cast<int32_t>(en[2]);
+                        if (used[tid] < rows_h[tid / kSlice]) { place(en, tid); en[3] = 2; }
+                    }
+                    // ... the rest wherever a slot is free
+                    int32_t host = 0;
+                    for (auto &en : half_ents) {
+                        if (en[3] != 1) continue;
+                        while (host < n_here && used[host] >= rows_h[host / kSlice]) host++;
+                        if (host >= n_here) throw std::logic_error("half rows: no free slot left in the tile");
+                        place(en, host);
+                        en[3] = 2;
+                    }
+                    std::sort(half_where.begin(), half_where.end());
+                    for (const auto &en : half_ents) {
+                        if (en[3] != 0) continue;                        // the other end point owns the evaluation: its position, negated
+                        auto it = std::lower_bound(half_where.begin(), half_where.end(), std::make_pair(static_cast<int32_t>(en[0]), int32_t(-1)));
+                        if (it == half_where.end() || it->first != static_cast<int32_t>(en[0])) throw std::logic_error("half rows: an edge without an evaluator in its tile");
+                        P.hg16[static_cast<size_t>(en[1])] = static_cast<uint16_t>(uint32_t(it->second) | kT16RoleB);
+                    }
+                }
+            }
             P.tile_halo.insert(P.tile_halo.end(), halo.begin(), halo.begin() + staged);
             P.tile_halo_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(P.tile_halo.size());
             P.tile_ovf.insert(P.tile_ovf.end(), halo.begin() + staged, halo.end());
@@ -611,6 +748,10 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     P.tail_tile_ptr[static_cast<size_t>(P.n_tiles)] = static_cast<int32_t>(P.tail_rec.size() / 6);
     P.tail_total = static_cast<int64_t>(P.tail_rec.size() / 6);
     if (!P.has_tail) { P.tail_begin.clear(); P.tail_count.clear(); }
+    // half rows: levels without long rows whose every slice fits the per-thread row limit
+    if (P.has_tail) P.half = false;
+    if (!P.half) { P.hr_row0.clear(); P.hr_code.clear(); P.hr_w.clear(); P.hg16.clear(); P.hr_entries = 0; P.hr_foreign = 0; }
+    else P.hr_padding = int64_t(P.hr_row0.back()) * kSlice - P.hr_entries;
 
     P.n_internal_entries = useful;
     int64_t int_slots = 0;

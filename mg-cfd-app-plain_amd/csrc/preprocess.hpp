@@ -31,6 +31,12 @@ static_assert(kHaloStride <= 2 * kTile, "the staging code reads at most two halo
 constexpr int kProCap = 768;
 constexpr int kEdgeChunk = 256;
 constexpr int kMaxEdgeChunks = 5;
+constexpr uint32_t kHalfForeign = 1u << 24;
+constexpr uint32_t kHalfPad = 0x00007FFFu;   // (low 15 bits = kT16Pad)
+constexpr int kHalfMaxRows = 5;            // half rows (edges a node evaluates) a thread keeps the results of in registers
+constexpr int kHalfTileRows = 21;          // half rows of a tile's four slices together (21 * 64 * 40 B = the whole LDS tile)
+constexpr int kHalfSlots = kHalfTileRows * kSlice;   // flux-term slots of a tile in LDS: 5 fields x 1344 x 8 B = 52.5 KiB
+static_assert(kHalfSlots * 40 <= kTileCap * 96, "the edge fluxes replace the node records in LDS");
 static_assert(kMaxEdgeChunks * kEdgeChunk * 40 <= kTileCap * 96, "edge fluxes must fit the LDS tile");
 
 // neighbour codes in Sell::nbr
@@ -85,6 +91,21 @@ struct LevelPlan {
     std::vector<double> te_w;             // [chunk][4][256] a-side weights: -0.5*e (x,y,z) and k = -|e|*smoothing*0.5
     std::vector<uint16_t> gat16;          // [rows*64] internal rows: position p of the entry's edge in its tile's list
                                           //   | kT16RoleB when this node is the edge's b end (it gets -F); kT16Pad
+    // ---- half rows (k_flux_half): every internal edge that touches a tile is EVALUATED by exactly one of its end points
+    //      in the tile (an edge inside the tile by the less loaded of the two, an edge cut by the tile boundary by the end
+    //      inside), so a tile streams one 28-byte row entry per edge instead of one of 26-34 bytes per end point, and
+    //      evaluates each edge once.  The evaluator leaves the five flux terms in LDS at position (half row within the tile) * 64 + lane;
+    //      every node then adds its incident edges in row order from there (hg16: position | kT16RoleB when the entry's
+    //      edge was evaluated by the OTHER end point: that node adds the negated terms, which is what the reference's
+    //      expressions for the other end evaluate to bit for bit) ----
+    bool half = false;                    // false: some slice needs more than kHalfMaxRows rows (a tile more than kHalfTileRows), or a tile has unstaged halo nodes
+    std::vector<int32_t> hr_row0;         // [n_slices+1] first half row of each slice
+    std::vector<uint32_t> hr_code;        // [half rows*64] low 16 bits as nbr16 (the other end's LDS slot | kT16RoleB when the OWNING end
+                                          //   is the edge's b end), bits 16-23 the owning node's thread, kHalfForeign when the slot
+                                          //   sits in another node's lane (that lane reads the owner's record from LDS too); kHalfPad
+    std::vector<double> hr_w;             // [half rows][3][64] the evaluator's weights (as w.x, w.y, w.z of its own entry)
+    std::vector<uint16_t> hg16;           // [rows*64] internal rows: where the entry's flux terms are | kT16RoleB = subtract; kT16Pad
+    int64_t hr_entries = 0, hr_padding = 0, hr_foreign = 0;
     // ---- long rows: a node's internal entries beyond its tile's row limit.  The per-node loop stops at the limit;
     //      the whole workgroup then evaluates the remaining entries one per thread, leaves the five results in a
     //      global scratch, and every owner adds its own in row order — the summation order is unchanged, but the

@@ -412,7 +412,7 @@ mgcfd_solver::~mgcfd_solver()
         void *ptrs[] = {lv.q_alt, lv.sf_alt, lv.tile_sumsq, lv.dp.nbr16, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
                         lv.cbrt_vol, lv.min_dt, lv.partial_min, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.child4, lv.dp.pro_w, lv.dp.pro_p, lv.dp.pro_tile_n, lv.dp.pro_tile_ids, lv.dp.pro_s16, lv.dp.pro_own16,
-                        lv.dp.pro_parent, lv.dp.pro_wsum, lv.dp.te_chunk_ptr, lv.dp.te_count, lv.dp.te_slots, lv.dp.te_w,
+                        lv.dp.pro_parent, lv.dp.pro_wsum, lv.dp.te_chunk_ptr, lv.dp.te_count, lv.dp.te_slots, lv.dp.te_w, lv.dp.te_w3, lv.dp.hr_row0, lv.dp.hr_code, lv.dp.hr_w, lv.dp.hg16,
                         lv.dp.gat16, lv.dp.fe_ab, lv.dp.fe_w, lv.dp.row_edge, lv.dp.edge_flux,
                         const_cast<int32_t *>(lv.dp.tail.rows_main), const_cast<int32_t *>(lv.dp.tail.tile_ptr),
                         const_cast<double2 *>(lv.dp.tail.rec), const_cast<int32_t *>(lv.dp.tail.begin),
@@ -480,6 +480,10 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
                          l, (long)d.nel, lv.plan.n_tiles, lv.plan.halo_mean, lv.plan.halo_max, kTileCap - kTile,
                          (long)lv.plan.halo_overflow_refs, 100.0 * lv.plan.pad_fraction, lv.plan.te_mean, lv.plan.te_max,
                          lv.plan.edge_once ? "yes" : "no");
+        if (std::getenv("MGCFD_VERBOSE"))
+            std::fprintf(stderr, "[mgcfd] level %d: half rows %s: %ld evaluations (%.2f per node), %ld in another node's lane, %ld padding slots (%.1f%%)\n", l, lv.plan.half ? "yes" : "no",
+                         (long)lv.plan.hr_entries, double(lv.plan.hr_entries) / double(d.nel), (long)lv.plan.hr_foreign, (long)lv.plan.hr_padding,
+                         lv.plan.hr_entries ? 100.0 * double(lv.plan.hr_padding) / double(lv.plan.hr_entries) : 0.0);
         if (std::getenv("MGCFD_VERBOSE") && lv.plan.has_tail) {
             int64_t rows_full = 0, rows_cut = 0;
             for (size_t q = 0; q < lv.plan.rows_int.size(); q++) { rows_full += lv.plan.rows_int[q]; rows_cut += lv.plan.rows_main[q]; }
@@ -595,9 +599,31 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
             lv.plan.te_w.resize(P.te_w.size() + 4 * kEdgeChunk, 0.0);
             lv.dp.te_slots = dev_upload(P.te_slots);
             lv.dp.te_w = dev_upload(P.te_w);
+            {   // the same weights as 24-byte records, one per listed edge (k_flux_tile WMODE 2: indexed weights)
+                const size_t n_chunks = P.te_w.size() / (4 * kEdgeChunk);
+                std::vector<double> w3(n_chunks * kEdgeChunk * 3);
+                for (size_t c = 0; c < n_chunks; c++)
+                    for (size_t ln = 0; ln < size_t(kEdgeChunk); ln++)
+                        for (size_t k = 0; k < 3; k++) w3[(c * kEdgeChunk + ln) * 3 + k] = P.te_w[(c * 4 + k) * kEdgeChunk + ln];
+                lv.dp.te_w3 = dev_upload(w3);
+            }
             lv.plan.gat16.resize(P.gat16.size() + 2 * kSlice, static_cast<uint16_t>(kT16Pad));   // two rows of padding
             lv.dp.gat16 = dev_upload(P.gat16);
         }
+        lv.dp.half = (P.half && !std::getenv("MGCFD_NO_HALF_ROWS")) ? 1 : 0;
+        if (lv.dp.half) {
+            lv.dp.hr_pad_row = P.hr_row0.back();
+            lv.dp.hr_row0 = dev_upload(P.hr_row0);
+            lv.plan.hr_code.resize(P.hr_code.size() + 2 * kSlice, kHalfPad);      // two half rows of padding
+            lv.plan.hr_w.resize(P.hr_w.size() + 2 * 3 * kSlice, 0.0);
+            lv.plan.hg16.resize(P.hg16.size() + 2 * kSlice, static_cast<uint16_t>(kT16Pad));
+            lv.dp.hr_code = dev_upload(P.hr_code);
+            lv.dp.hr_w = dev_upload(P.hr_w);
+            lv.dp.hg16 = dev_upload(P.hg16);
+        }
+        lv.plan.hr_code.clear(); lv.plan.hr_code.shrink_to_fit();
+        lv.plan.hr_w.clear(); lv.plan.hr_w.shrink_to_fit();
+        lv.plan.hg16.clear(); lv.plan.hg16.shrink_to_fit();
         lv.plan.te_slots.clear(); lv.plan.te_slots.shrink_to_fit();
         lv.plan.te_w.clear(); lv.plan.te_w.shrink_to_fit();
         lv.plan.gat16.clear(); lv.plan.gat16.shrink_to_fit();
@@ -771,6 +797,13 @@ int mgcfd_set_option(mgcfd_solver *s, int option, int value)
             default: throw std::invalid_argument("unknown option");
         }
     });
+}
+int mgcfd_level_has_half_rows(const mgcfd_solver *s, int level, int *yes)
+{
+    REQUIRE(s); REQUIRE(yes);
+    if (level < 0 || level >= static_cast<int>(s->L.size())) { g_last_error = "level out of range"; return MGCFD_ERR_ARG; }
+    *yes = s->L[static_cast<size_t>(level)].dp.half;
+    return MGCFD_OK;
 }
 int mgcfd_level_has_edge_once(const mgcfd_solver *s, int level, int *yes)
 {

@@ -68,6 +68,7 @@ _SIGNATURES = [
     ("mgcfd_destroy", None, [_vp]),
     ("mgcfd_set_option", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mgcfd_level_has_edge_once", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    ("mgcfd_level_has_half_rows", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_level_tiling", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
     ("mgcfd_invalid_state_location", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     ("mgcfd_get_option", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
@@ -316,6 +317,11 @@ class Solver:
         keys = ("tiles", "halo_nodes", "halo_max", "halo_capacity", "overflow_refs", "row_entries", "padding_entries", "coordinate_boxes",
                 "list_entries", "loop_rows")
         return dict(zip(keys, (int(v) for v in out)))
+
+    def has_half_rows(self, l: int) -> bool:
+        yes = C.c_int(0)
+        self._c(self.lib.mgcfd_level_has_half_rows(self.handle, l, C.byref(yes)))
+        return bool(yes.value)
 
     def has_edge_once(self, l: int) -> bool:
         v = C.c_int()

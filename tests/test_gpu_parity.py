@@ -179,7 +179,7 @@ def test_vcycles_three_levels(oracle, mesh3_dir, exact, fuse):
 
 
 @pytest.mark.parametrize("fuse", [True, False])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 16, 32])
 def test_vcycles_flux_variants(oracle, mesh3_dir, variant, fuse):
     """Every flux variant (length factor streamed / recomputed, node gather / edge-once tiles / the
     two-phase design point) runs the same V-cycles bit-identically to the oracle."""
@@ -481,7 +481,7 @@ def test_randomised_hierarchies(oracle, seed):
     want, want_rms = _oracle_solve_arrays(oracle, levels, mg.mesh_variant, cycles)
     s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
     s.set_option("fuse_update", int(rng.integers(0, 2)))
-    s.set_option("flux_variant", int(rng.choice([-1, 0, 1, 2, 3])))
+    s.set_option("flux_variant", int(rng.choice([-1, 0, 1, 2, 3, 16, 32])))
     s.set_option("graph", int(rng.integers(0, 2)))
     rms = s.run_cycles(cycles)
     for l in range(len(levels)):
@@ -1262,14 +1262,15 @@ def test_full_size_flux_variants_agree(big):
     mgcfd, s, q, levels = big
     assert s.has_edge_once(0)
     out = {}
-    for v in (0, 1, 2, 3, 4):
+    assert s.has_half_rows(0)
+    for v in (0, 1, 2, 3, 4, 16, 32):
         s.set_option("flux_variant", v)
         s.set(0, "variables", q)
         s.zero_fluxes(0)
         s.compute_fluxes(0)
         out[v] = s.get(0, "fluxes")
     s.set_option("flux_variant", 0)
-    for v in (1, 2, 3, 4):
+    for v in (1, 2, 3, 4, 16, 32):
         assert np.array_equal(out[0].view(np.int64), out[v].view(np.int64)), v
 
 

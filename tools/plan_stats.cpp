@@ -1,0 +1,29 @@
+// Host-only diagnostic: build the gather plan of level 0 of an input.dat and print what the half-row plan looks like.
+//   g++ -O2 -std=c++17 -Iinclude -Img-cfd-app-plain_amd/csrc tools/plan_stats.cpp -Lmg-cfd-app-plain_amd/csrc -lmgcfd_hip -Wl,-rpath,$PWD/mg-cfd-app-plain_amd/csrc -o /tmp/plan_stats
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+#include "mgcfd.h"
+#include "preprocess.hpp"
+int main(int argc, char **argv)
+{
+    mgcfd_mesh *m = nullptr;
+    if (mgcfd_mesh_load("input.dat", argv[1], 1, &m) != MGCFD_OK) { std::fprintf(stderr, "%s\n", mgcfd_last_error()); return 1; }
+    mgcfd_level_desc d;
+    mgcfd_mesh_level(m, 0, &d);
+    std::vector<mgcfd_edge> edges(d.edges, d.edges + d.n_edges);
+    mgcfd::adjust_and_dampen(d, mgcfd_mesh_variant(m), edges);
+    mgcfd::LevelPlan P;
+    mgcfd::PlanOptions opt;
+    mgcfd::build_level_plan(d, edges, opt, P);
+    std::printf("nel %ld tiles %d halo mean %.1f max %d overflow refs %ld tail %d edge_once %d\n", (long)d.nel, P.n_tiles, P.halo_mean, P.halo_max,
+                (long)P.halo_overflow_refs, int(P.has_tail), int(P.edge_once));
+    std::printf("half %d evaluations %ld (%.2f per node) foreign %ld padding %ld (%.1f %%)\n", int(P.half), (long)P.hr_entries, double(P.hr_entries) / d.nel,
+                (long)P.hr_foreign, (long)P.hr_padding, P.hr_entries ? 100.0 * P.hr_padding / P.hr_entries : 0.0);
+    if (!P.hr_row0.empty()) {
+        int hist[16] = {0};
+        for (size_t s = 0; s + 1 < P.hr_row0.size(); s++) hist[std::min(15, P.hr_row0[s + 1] - P.hr_row0[s])]++;
+        for (int k = 0; k < 16; k++) if (hist[k]) std::printf("  slices with %d half rows: %d\n", k, hist[k]);
+    }
+    return 0;
+}

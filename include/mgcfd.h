@@ -332,6 +332,45 @@ int mgcfd_halo_unpack(mgcfd_solver *s, int level, int plan, int which, const voi
  * rms = sqrt(sum / global_nel)). */
 int mgcfd_residual_sumsq(mgcfd_solver *s, int level, void **devptr);
 
+/* ---------------------------------------------------------------------------------
+ * Multi-GPU in the C++ host: a level PARTITIONED over ranks (mgcfd_create_partitioned), the whole
+ * sweep loop inside the library.  The reference has no distributed path; what a partitioned level
+ * needs follows from its loops: one all-reduce(MIN) of the time step per sweep
+ * (src/Kernels/cfd_loops.cpp:137-150) and, because every RK stage reads the neighbours' new state
+ * (src/Kernels/flux_loops.cpp:133-136 after cfd_loops.cpp:241-268), one halo message per neighbouring
+ * rank after every stage.  Per stage the library runs the tiles next to ghost nodes first, packs every
+ * peer's segment with ONE launch, sends (RCCL ncclSend/ncclRecv grouped on a second stream; between the
+ * solvers of one process hipMemcpyPeerAsync over xGMI), runs the interior tiles while the message travels,
+ * and unpacks with ONE launch before the next stage's boundary tiles.  Results equal the unpartitioned
+ * level's bit for bit on owned nodes.
+ *
+ * Two ways to be a rank:
+ *   one rank per PROCESS (RCCL):  mgcfd_rccl_unique_id on rank 0, the 128 bytes handed to every rank by the
+ *       launcher (MPI, torch.distributed, a file), mgcfd_rank_attach_rccl, mgcfd_rank_set_halo,
+ *       mgcfd_rank_exchange once, then mgcfd_rank_sweeps.  librccl is loaded when first needed.
+ *   the solvers of ONE process (one per device): mgcfd_group_create, mgcfd_rank_set_halo on each,
+ *       mgcfd_group_exchange once, then mgcfd_group_sweeps — what euler3d_gpu_double --gpus N runs.
+ * --------------------------------------------------------------------------------- */
+typedef struct mgcfd_group mgcfd_group;
+int mgcfd_rccl_unique_id(void *out128);
+int mgcfd_rank_attach_rccl(mgcfd_solver *s, int rank, int world, const void *id128);
+int mgcfd_rank_detach(mgcfd_solver *s);
+/* The level's neighbours: peers[k] ascending; send_ids[k] = the OWNED local nodes peer k holds as ghosts, recv_ids[k] =
+ * the local GHOSTS peer k owns, both in an order the two ranks agree on (ascending global id).  Also splits the level's
+ * tiles into boundary / interior for the overlapped exchange. */
+int mgcfd_rank_set_halo(mgcfd_solver *s, int level, int n_peers, const int *peers, const int64_t *send_counts,
+                        const int64_t *const *send_ids, const int64_t *recv_counts, const int64_t *const *recv_ids);
+int mgcfd_rank_halo_info(const mgcfd_solver *s, int level, int64_t out[4]);   /* boundary tiles, interior tiles, nodes sent, nodes received */
+int mgcfd_rank_exchange(mgcfd_solver *s, int level);          /* ghosts of `variables` <- owners (after mgcfd_set_array) */
+int mgcfd_rank_sweeps(mgcfd_solver *s, int level, int sweeps); /* the per-level body of the cycle loop, `sweeps` times; asynchronous */
+int mgcfd_rank_residual_sumsq(mgcfd_solver *s, int level, double *sum_all_ranks);
+int mgcfd_group_create(int n, mgcfd_solver *const *solvers, mgcfd_group **out);   /* solvers[r] becomes rank r of n */
+void mgcfd_group_destroy(mgcfd_group *g);
+int mgcfd_group_exchange(mgcfd_group *g, int level);
+int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps);
+int mgcfd_group_rms(mgcfd_group *g, int level, double *rms);
+int mgcfd_group_synchronize(mgcfd_group *g);
+
 #ifdef __cplusplus
 }
 #endif

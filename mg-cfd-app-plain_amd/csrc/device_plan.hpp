@@ -44,6 +44,10 @@ struct FusedStep {
     double *next_partial_min = nullptr;       // first half of compute_step_factor: per-tile minima of 0.5*cbrt(vol)/(|v|+c)
     const double *cbrt_vol = nullptr;
     double *next_legacy_sf = nullptr;         // mesh_name = fvcorr: next sweep's step factors 0.5/(sqrt(vol)*(|v|+c)) (cfd_loops.cpp:37-61) go here
+    // a launch over PART of the level's tiles (a partitioned level: the tiles next to ghost nodes first, so that their
+    // results can travel while the others are computed): tile_list[k] = tile of workgroup k; nullptr = all tiles
+    const int32_t *tile_list = nullptr;
+    int32_t n_list = 0;
 };
 
 // "Add up these partial sums" as an argument: k_sum_partials does only that; k_restrict can take it along.

@@ -569,7 +569,8 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const unsigned t = xcd_contiguous_block(blockIdx.x, n_tiles);      // n_tiles == gridDim.x, without the hidden-argument load
+    unsigned t = xcd_contiguous_block(blockIdx.x, n_tiles);            // n_tiles == gridDim.x, without the hidden-argument load
+    if (FUSE && fs.tile_list) t = unsigned(fs.tile_list[t]);           // a launch over part of the level (uniform branch)
     const int64_t base = int64_t(t) * kTile;
     const int64_t i = base + tid;
     const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
@@ -1904,14 +1905,16 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
                  int classes, int accumulate, int variant, const FusedStep *fused)
 {
     const dim3 block(kBlock);
-    const dim3 grid(p.n_tiles);
     FusedStep fs{};
     if (fused) fs = *fused;
+    const bool part = fused && fs.tile_list;                        // part of the level's tiles (node gather only)
+    const dim3 grid(part ? fs.n_list : p.n_tiles);
+    if (part && fs.n_list <= 0) return;
 
     // 3 tiles of 52.5 KiB LDS fit a CU => at least 3 waves per SIMD wanted
 #define MGCFD_TILE_LAUNCH_T(WMODE, FUSE, ACC, ROLE, TAIL)                                                      \
     hipLaunchKernelGGL((k_flux_tile<3, WMODE, FUSE, ACC, ROLE, TAIL>), grid, block, 0, st, q, p.tile_halo,     \
-                       uint32_t(p.n_tiles), p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.rows_bnd,  \
+                       uint32_t(grid.x), p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.rows_bnd,  \
                        p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs, p.tail, p.gat16,     \
                        p.te_chunk_ptr, p.te_w3)
     // levels with long rows (tetrahedral meshes, hubs) run the instantiation that hands them to the workgroup
@@ -1950,7 +1953,7 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     }
     // variant bit 5 (32): half rows — every edge evaluated once per tile by one of its end points (k_flux_half); the
     // split sweep's absorbed first stage (role 5) stays with the node gather
-    if ((variant & 32) && p.half && (classes & 1) && !(fused && fs.vin_flux)) {
+    if ((variant & 32) && p.half && (classes & 1) && !(fused && fs.vin_flux) && !part) {
 #define MGCFD_HALF_LAUNCH(FUSE, ACC)                                                                            \
     hipLaunchKernelGGL((k_flux_half<FUSE, ACC>), grid, block, 0, st, q, p.tile_halo, uint32_t(p.n_tiles),       \
                        p.hr_pad_row, p.stride, p.nel, p.hr_row0, p.hr_code, p.hr_w, p.hg16, p.slice_row0,       \
@@ -1964,7 +1967,7 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     const bool loadk = (variant & 1) == 0;      // odd variants recompute k = -|e|*s*0.5 from the weights
     // variants 2, 3: every edge evaluated once per tile (needs the internal class and a level whose
     // tiles fit the edge-once limits; otherwise the node gather below)
-    if ((variant & 2) && p.edge_once && (classes & 1)) {
+    if ((variant & 2) && p.edge_once && (classes & 1) && !part) {
 #define MGCFD_EO_LAUNCH(LOADK, FUSE, ACC)                                                                      \
     hipLaunchKernelGGL((k_flux_edge_once<LOADK, FUSE, ACC>), grid, block, 0, st, q, p.tile_halo,               \
                        uint32_t(p.n_tiles), p.pad_row, p.stride, p.nel, p.te_chunk_ptr, p.te_count,            \

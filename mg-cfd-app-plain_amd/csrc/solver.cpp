@@ -5,6 +5,7 @@
 // level's gather plan, and exposes the reference's kernel set one call per loop plus the
 // V-cycle state machine (src/euler3d_cpu_double.cpp:371-694).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -54,6 +55,26 @@ template <typename T> static T *dev_upload(const std::vector<T> &v)
 
 struct EventPair { hipEvent_t start, stop; int level, loop; bool is_flux_internal; int launches; };
 
+// The halo exchange of one partitioned level as the C++ host runs it (mgcfd_rank_* / mgcfd_group_*): ONE packed message
+// per exchange holding every peer's segment (one pack and one unpack launch whatever the number of peers), double
+// buffered by exchange parity, and the level's tiles split into those next to ghost nodes ("boundary": they read ghosts,
+// and every node a peer needs lies in one of them) and the rest ("interior"), which run while the message travels.
+struct HaloExchange {
+    std::vector<int> peer;                               // neighbouring ranks, ascending
+    std::vector<int64_t> send_off, recv_off;             // [n_peers+1] node offsets of the peers' segments
+    int32_t *send_idx = nullptr, *recv_idx = nullptr;    // device: library node ids, all peers concatenated
+    double *send_buf[2] = {nullptr, nullptr}, *recv_buf[2] = {nullptr, nullptr};   // device: [nodes][5]
+    int32_t *tiles_boundary = nullptr, *tiles_interior = nullptr;
+    int32_t n_boundary = 0, n_interior = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t packed[2] = {nullptr, nullptr}, arrived[2] = {nullptr, nullptr};
+    int parity = 0;                                      // buffer set of the NEXT exchange
+    bool in_flight = false;                              // an exchange has been started and not yet unpacked
+    double *gmin = nullptr;                              // device [world]: every rank's minimum time step (in-process groups)
+    int64_t total_send() const { return send_off.empty() ? 0 : send_off.back(); }
+    int64_t total_recv() const { return recv_off.empty() ? 0 : recv_off.back(); }
+};
+
 struct DeviceLevel {
     mgcfd_level_desc info{};             // sizes only (pointers nulled)
     std::vector<mgcfd_edge> edges;       // final edge weights, original order
@@ -90,6 +111,7 @@ struct DeviceLevel {
     double *stage_out = nullptr;         // ... and the buffer the last one wrote (MGCFD_ARR_STAGE)
     int64_t n_owned = 0;                 // < nel on a partitioned level: original ids >= n_owned are ghosts
     std::vector<std::pair<int32_t *, int64_t>> halo_plans;   // device id lists of the halo messages
+    std::unique_ptr<HaloExchange> hx;    // the C++-side exchange of a partitioned level (mgcfd_rank_set_halo)
     bool has_transfer = false;           // plan to the next-coarser level present
     int64_t iters[MGCFD_NUM_LOOPS] = {0};
     double times[MGCFD_NUM_LOOPS] = {0};
@@ -117,6 +139,7 @@ struct mgcfd_solver {
     int check_seq = 0;
     int64_t invalid_cell = -1; int invalid_cycle = -1;                     // where the last reported invalid state was found
     int next_check() { if (!opt_check) return 0; if (check_seq < (1 << 22)) check_seq++; return check_seq; }
+    int force_check = -1;                    // >= 0: the sequence number the next fused stage carries (a stage launched in two parts)
     int timing_stride = 8;                  // OPT_TIMING == 2: bracket the flux launches of every Nth sweep
     int64_t sweep_counter = 0;
     bool in_timed_group = false;
@@ -264,10 +287,13 @@ struct mgcfd_solver {
     // the next sweep's step-factor work behind (partial minima in partial_min, or fvcorr's factors in sf_alt)
     void op_fused_stage(int l, int j, const double *in, double *out, int apply_min, bool with_residual,
                         const double *old = nullptr, bool look_ahead = false, bool sumsq = false,
-                        const double *vin_flux = nullptr)
+                        const double *vin_flux = nullptr, const int32_t *tile_list = nullptr, int32_t n_list = 0,
+                        bool count_iters = true, const double *min_list = nullptr, int n_min = 0)
     {
         DeviceLevel &lv = level(l);
         FusedStep fs;
+        fs.tile_list = tile_list;
+        fs.n_list = n_list;
         fs.rk_div = double(MGCFD_RK + 1 - j);
         fs.step_factors = lv.step_factors;
         fs.old_variables = old ? old : lv.old_variables;
@@ -276,8 +302,8 @@ struct mgcfd_solver {
         fs.next_legacy_sf = (look_ahead && mesh_variant == MGCFD_MESH_FVCORR) ? lv.sf_alt : nullptr;
         fs.cbrt_vol = lv.cbrt_vol;
         if (out == lv.q) lv.min_ahead = false;      // (a caller that looks ahead sets it after its last stage)
-        fs.partial_min = apply_min == 1 ? lv.partial_min : (apply_min == 2 ? lv.min_dt : nullptr);
-        fs.n_partial = apply_min == 2 ? 1 : static_cast<int>((lv.info.nel + 255) / 256);
+        fs.partial_min = apply_min == 1 ? lv.partial_min : (apply_min == 2 ? lv.min_dt : (apply_min == 3 ? min_list : nullptr));
+        fs.n_partial = apply_min == 2 ? 1 : (apply_min == 3 ? n_min : static_cast<int>((lv.info.nel + 255) / 256));
         fs.volumes = lv.volumes;
         fs.residuals = with_residual ? lv.residuals : nullptr;
         fs.sumsq_partial = (with_residual && sumsq) ? lv.tile_sumsq : nullptr;
@@ -285,12 +311,14 @@ struct mgcfd_solver {
         fs.vin_div = double(MGCFD_RK + 1);
         fs.old_of_new = lv.dp.old_of_new;
         fs.err = err;
-        fs.check = next_check();
+        fs.check = force_check >= 0 ? force_check : next_check();
         Timed t(this, l, MGCFD_LOOP_FLUX, true);
         if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs);
         else fast::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs);
-        lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
-        lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
+        if (count_iters) {                          // (a stage launched in two parts counts once)
+            lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
+            lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
+        }
     }
     void op_indirect_rw(int l)
     {
@@ -419,6 +447,13 @@ mgcfd_solver::~mgcfd_solver()
                         const_cast<int32_t *>(lv.dp.tail.count), lv.dp.tail.flux};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         for (auto &hp : lv.halo_plans) if (hp.first) (void)hipFree(hp.first);
+        if (lv.hx) {
+            HaloExchange &hx = *lv.hx;
+            void *hp[] = {hx.send_idx, hx.recv_idx, hx.send_buf[0], hx.send_buf[1], hx.recv_buf[0], hx.recv_buf[1], hx.tiles_boundary, hx.tiles_interior, hx.gmin};
+            for (void *p : hp) if (p) (void)hipFree(p);
+            for (int b = 0; b < 2; b++) { if (hx.packed[b]) (void)hipEventDestroy(hx.packed[b]); if (hx.arrived[b]) (void)hipEventDestroy(hx.arrived[b]); }
+            if (hx.comm_stream) (void)hipStreamDestroy(hx.comm_stream);
+        }
     }
     if (err) (void)hipFree(err);
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -1565,6 +1600,455 @@ int mgcfd_bench_indirect_rw(mgcfd_solver *s, int level, int launches, double *av
         lv.fluxes_zero = false;
         *avg_seconds = launches > 0 ? double(ms) * 1e-3 / launches : 0.0;
     });
+}
+
+} // extern "C"
+
+// ==========================================================================================================
+// Multi-GPU in the C++ host (include/mgcfd.h "Multi-GPU in the C++ host").
+//
+// One level partitioned over ranks: mgcfd_rank_set_halo gives a solver its neighbours and the node lists of the
+// messages; mgcfd_rank_sweeps then runs whole smoothing sweeps — the per-level body of the reference's cycle loop,
+// src/euler3d_cpu_double.cpp:383-508 — with the coupling a partitioned level needs: one all-reduce(MIN) of the time
+// step per sweep (src/Kernels/cfd_loops.cpp:137-150) and one halo message per neighbour after every Runge-Kutta stage.
+// Per stage: the tiles next to ghost nodes first, ONE pack launch for all peers, the message on its way (RCCL:
+// ncclSend/ncclRecv grouped on a second stream; in-process groups: hipMemcpyPeerAsync), the interior tiles meanwhile,
+// then ONE unpack launch before the next stage's boundary tiles.  Same arithmetic as mgcfd_sweep_stage, bit for bit.
+// ==========================================================================================================
+namespace {
+
+// ---- RCCL, loaded at run time (only a multi-process run needs it; a process that already holds torch's copy gets that one)
+struct Rccl {
+    struct Id { char b[128]; };                   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    static constexpr int kDouble = 8, kMin = 3, kSum = 0;     // ncclDouble, ncclMin, ncclSum (rccl.h)
+};
+Rccl g_rccl;
+
+void rccl_load()
+{
+    if (g_rccl.lib) return;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) throw std::runtime_error(std::string("cannot load librccl: ") + dlerror());
+    auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p) throw std::runtime_error(std::string("librccl lacks ") + n); return p; };
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
+    g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(sym("ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(sym("ncclGroupEnd"));
+    g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(sym("ncclSend"));
+    g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(sym("ncclRecv"));
+    g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(sym("ncclAllReduce"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+    g_rccl.lib = h;
+}
+#define RCCL_CHECK(x) do { const int rc_ = (x); if (rc_ != 0) throw std::runtime_error(std::string("RCCL: ") + #x + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc_) : "error")); } while (0)
+
+} // namespace
+
+// what a solver knows about the ranks around it
+struct mgcfd_comm {
+    int rank = 0, world = 1;
+    void *rccl = nullptr;                         // ncclComm_t (one rank per process)
+    struct mgcfd_group *group = nullptr;          // or: the in-process group this solver is rank `rank` of
+};
+struct mgcfd_group { std::vector<mgcfd_solver *> ranks; };
+
+static std::map<mgcfd_solver *, mgcfd_comm> g_comms;     // (one host thread per solver; groups are driven by one thread)
+
+static mgcfd_comm &comm_of(mgcfd_solver *s)
+{
+    auto it = g_comms.find(s);
+    if (it == g_comms.end()) throw std::invalid_argument("the solver is not a rank of anything: call mgcfd_rank_attach_rccl or mgcfd_group_create first");
+    return it->second;
+}
+
+static void build_halo(mgcfd_solver *s, int level, int n_peers, const int *peers, const int64_t *send_counts, const int64_t *const *send_ids,
+                       const int64_t *recv_counts, const int64_t *const *recv_ids, int world)
+{
+    s->use_device();
+    DeviceLevel &lv = s->level(level);
+    auto hx = std::make_unique<HaloExchange>();
+    std::vector<int32_t> sidx, ridx;
+    hx->send_off.push_back(0); hx->recv_off.push_back(0);
+    for (int k = 0; k < n_peers; k++) {
+        if (k > 0 && peers[k] <= peers[k - 1]) throw std::invalid_argument("peers must be ascending");
+        hx->peer.push_back(peers[k]);
+        for (int64_t i = 0; i < send_counts[k]; i++) {
+            const int64_t id = send_ids[k][i];
+            if (id < 0 || id >= lv.n_owned) throw std::invalid_argument("a node sent to a peer must be owned");
+            sidx.push_back(lv.plan.new_of_old[static_cast<size_t>(id)]);
+        }
+        for (int64_t i = 0; i < recv_counts[k]; i++) {
+            const int64_t id = recv_ids[k][i];
+            if (id < lv.n_owned || id >= lv.info.nel) throw std::invalid_argument("a node received from a peer must be a ghost");
+            ridx.push_back(lv.plan.new_of_old[static_cast<size_t>(id)]);
+        }
+        hx->send_off.push_back(static_cast<int64_t>(sidx.size()));
+        hx->recv_off.push_back(static_cast<int64_t>(ridx.size()));
+    }
+    hx->send_idx = dev_upload(sidx);
+    hx->recv_idx = dev_upload(ridx);
+    for (int b = 0; b < 2; b++) {
+        hx->send_buf[b] = dev_alloc<double>(sidx.size() * 5);
+        hx->recv_buf[b] = dev_alloc<double>(ridx.size() * 5);
+        HIP_CHECK(hipEventCreateWithFlags(&hx->packed[b], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&hx->arrived[b], hipEventDisableTiming));
+    }
+    HIP_CHECK(hipStreamCreateWithFlags(&hx->comm_stream, hipStreamNonBlocking));
+    hx->gmin = dev_alloc<double>(static_cast<size_t>(std::max(world, 1)));
+    // tiles next to ghosts: a tile that holds a ghost node, or an owned node with an edge to one
+    std::vector<char> boundary(static_cast<size_t>(lv.plan.n_tiles), 0);
+    auto tile_of = [&](int64_t original) { return lv.plan.new_of_old[static_cast<size_t>(original)] / kTile; };
+    for (int64_t g = lv.n_owned; g < lv.info.nel; g++) boundary[static_cast<size_t>(tile_of(g))] = 1;
+    for (int64_t e = lv.info.internal_start; e < lv.info.internal_start + lv.info.n_internal; e++) {
+        const mgcfd_edge &E = lv.edges[static_cast<size_t>(e)];
+        if (E.a >= lv.n_owned || E.b >= lv.n_owned) { boundary[static_cast<size_t>(tile_of(E.a))] = 1; boundary[static_cast<size_t>(tile_of(E.b))] = 1; }
+    }
+    std::vector<int32_t> tb, ti;
+    for (int32_t t = 0; t < lv.plan.n_tiles; t++) (boundary[static_cast<size_t>(t)] ? tb : ti).push_back(t);
+    hx->n_boundary = static_cast<int32_t>(tb.size());
+    hx->n_interior = static_cast<int32_t>(ti.size());
+    hx->tiles_boundary = dev_upload(tb);
+    hx->tiles_interior = dev_upload(ti);
+    lv.hx = std::move(hx);
+}
+
+// the message of the state `field` (the buffer a stage just wrote, or `variables`): pack, start the transfer
+static void halo_start(mgcfd_solver *s, int level, const double *field)
+{
+    DeviceLevel &lv = s->level(level);
+    HaloExchange &hx = *lv.hx;
+    mgcfd_comm &c = comm_of(s);
+    const int b = hx.parity;
+    if (hx.total_send() > 0)
+        exact::launch_halo_pack(s->stream, hx.total_send(), lv.dp.stride, hx.send_idx, field, hx.send_buf[b]);
+    HIP_CHECK(hipEventRecord(hx.packed[b], s->stream));
+    if (c.rccl) {
+        HIP_CHECK(hipStreamWaitEvent(hx.comm_stream, hx.packed[b], 0));
+        RCCL_CHECK(g_rccl.GroupStart());
+        for (size_t k = 0; k < hx.peer.size(); k++) {
+            const int64_t ns = hx.send_off[k + 1] - hx.send_off[k], nr = hx.recv_off[k + 1] - hx.recv_off[k];
+            if (ns > 0) RCCL_CHECK(g_rccl.Send(hx.send_buf[b] + hx.send_off[k] * 5, static_cast<size_t>(ns) * 5, Rccl::kDouble, hx.peer[k], c.rccl, hx.comm_stream));
+            if (nr > 0) RCCL_CHECK(g_rccl.Recv(hx.recv_buf[b] + hx.recv_off[k] * 5, static_cast<size_t>(nr) * 5, Rccl::kDouble, hx.peer[k], c.rccl, hx.comm_stream));
+        }
+        RCCL_CHECK(g_rccl.GroupEnd());
+        HIP_CHECK(hipEventRecord(hx.arrived[b], hx.comm_stream));
+    }
+    // (in-process group: the copies are issued by group_deliver once every rank has packed)
+    hx.in_flight = true;
+}
+
+// in-process group: every rank's segments copied into its peers' receive buffers (device to device, over xGMI between
+// devices), each destination's copies on its own comm stream behind the sources' pack events
+static void group_deliver(mgcfd_group *g, int level)
+{
+    for (mgcfd_solver *dst : g->ranks) {
+        dst->use_device();
+        DeviceLevel &ld = dst->level(level);
+        HaloExchange &hd = *ld.hx;
+        const int b = hd.parity;
+        const int me = comm_of(dst).rank;
+        for (size_t k = 0; k < hd.peer.size(); k++) {
+            mgcfd_solver *src = g->ranks[static_cast<size_t>(hd.peer[k])];
+            HaloExchange &hs = *src->level(level).hx;
+            const auto it = std::find(hs.peer.begin(), hs.peer.end(), me);
+            if (it == hs.peer.end()) throw std::logic_error("halo lists of two ranks do not match");
+            const size_t ks = static_cast<size_t>(it - hs.peer.begin());
+            const int64_t n = hd.recv_off[k + 1] - hd.recv_off[k];
+            if (n != hs.send_off[ks + 1] - hs.send_off[ks]) throw std::logic_error("halo message lengths of two ranks do not match");
+            if (n == 0) continue;
+            HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, hs.packed[b], 0));
+            HIP_CHECK(hipMemcpyPeerAsync(hd.recv_buf[b] + hd.recv_off[k] * 5, dst->device, hs.send_buf[b] + hs.send_off[ks] * 5, src->device,
+                                         sizeof(double) * 5 * static_cast<size_t>(n), hd.comm_stream));
+        }
+        HIP_CHECK(hipEventRecord(hd.arrived[b], hd.comm_stream));
+    }
+}
+
+// wait for the message in flight and write it into the ghosts of `field`
+static void halo_finish(mgcfd_solver *s, int level, double *field)
+{
+    DeviceLevel &lv = s->level(level);
+    HaloExchange &hx = *lv.hx;
+    if (!hx.in_flight) return;
+    const int b = hx.parity;
+    HIP_CHECK(hipStreamWaitEvent(s->stream, hx.arrived[b], 0));
+    if (hx.total_recv() > 0)
+        exact::launch_halo_unpack(s->stream, hx.total_recv(), lv.dp.stride, hx.recv_idx, hx.recv_buf[b], field);
+    hx.parity ^= 1;
+    hx.in_flight = false;
+}
+
+// One stage of a partitioned sweep on one rank, part 1: the ghosts of the stage's input arrive, the boundary tiles run,
+// their results are packed and sent.  Part 2 (stage_interior) runs the other tiles while the message travels.
+static void stage_boundary(mgcfd_solver *s, int level, int j, int apply_min, const double *min_list, int n_min)
+{
+    DeviceLevel &lv = s->level(level);
+    HaloExchange &hx = *lv.hx;
+    double *const start = lv.q, *const b1 = lv.q_alt, *const b2 = lv.old_variables;
+    double *in = j == 0 ? start : (j == 1 ? b1 : b2);
+    double *out = j == 0 ? b1 : (j == 1 ? b2 : b1);
+    halo_finish(s, level, in);                              // (stage 0: the previous sweep's last message, into `variables`)
+    if (j == 0) {
+        if (!lv.fluxes_zero) throw std::invalid_argument("a partitioned sweep needs zero fluxes (as after time_step)");
+        s->settle_fluxes(lv);
+    }
+    s->force_check = s->next_check();                       // both parts of the stage are one time_step for check_for_invalid_variables
+    s->op_fused_stage(level, j, in, out, j == 0 ? apply_min : 0, j == 2, start, false, false, nullptr, hx.tiles_boundary, hx.n_boundary, true, min_list, n_min);
+    lv.stage_out = out;
+    halo_start(s, level, out);
+}
+static void stage_interior(mgcfd_solver *s, int level, int j, int apply_min, const double *min_list, int n_min)
+{
+    DeviceLevel &lv = s->level(level);
+    HaloExchange &hx = *lv.hx;
+    double *const start = lv.q, *const b1 = lv.q_alt, *const b2 = lv.old_variables;
+    double *in = j == 0 ? start : (j == 1 ? b1 : b2);
+    double *out = j == 0 ? b1 : (j == 1 ? b2 : b1);
+    s->op_fused_stage(level, j, in, out, j == 0 ? apply_min : 0, j == 2, start, false, false, nullptr, hx.tiles_interior, hx.n_interior, false, min_list, n_min);
+    s->force_check = -1;
+    if (j == 2) {
+        lv.rot = (lv.rot + 1) % 3;                          // variables = b1, q_alt = b2, old_variables = start
+        lv.apply_rot();
+        lv.stage_out = lv.q;
+        lv.min_ahead = false;
+    }
+}
+
+static void sweep_first_half(mgcfd_solver *s, int level)
+{
+    DeviceLevel &lv = s->level(level);
+    if (!lv.hx) throw std::invalid_argument("the level has no halo lists: call mgcfd_rank_set_halo first");
+    if (lv.stage_next != 0) throw std::invalid_argument("a sweep is under way (mgcfd_sweep_stage)");
+    // the previous sweep's last message must be in the ghosts before compute_step_factor reads `variables`
+    halo_finish(s, level, lv.q);
+    const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
+    s->op_step_factor(level, true, false);                  // first half of compute_step_factor (owned and ghost nodes alike: the ghosts' values are the owners')
+    if (global_dt) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
+}
+
+extern "C" {
+
+int mgcfd_rccl_unique_id(void *out128)
+{
+    REQUIRE(out128);
+    return guarded([&] { rccl_load(); RCCL_CHECK(g_rccl.GetUniqueId(out128)); });
+}
+
+int mgcfd_rank_attach_rccl(mgcfd_solver *s, int rank, int world, const void *id128)
+{
+    REQUIRE(s); REQUIRE(id128);
+    return guarded([&] {
+        if (rank < 0 || rank >= world) throw std::invalid_argument("rank out of range");
+        s->use_device();
+        rccl_load();
+        Rccl::Id id;
+        std::memcpy(id.b, id128, sizeof(id.b));
+        mgcfd_comm c;
+        c.rank = rank; c.world = world;
+        RCCL_CHECK(g_rccl.CommInitRank(&c.rccl, world, id, rank));
+        g_comms[s] = c;
+    });
+}
+
+int mgcfd_rank_detach(mgcfd_solver *s)
+{
+    REQUIRE(s);
+    return guarded([&] {
+        auto it = g_comms.find(s);
+        if (it == g_comms.end()) return;
+        if (it->second.rccl) { s->use_device(); (void)hipStreamSynchronize(s->stream); (void)g_rccl.CommDestroy(it->second.rccl); }
+        g_comms.erase(it);
+    });
+}
+
+int mgcfd_rank_set_halo(mgcfd_solver *s, int level, int n_peers, const int *peers, const int64_t *send_counts, const int64_t *const *send_ids,
+                        const int64_t *recv_counts, const int64_t *const *recv_ids)
+{
+    REQUIRE(s);
+    if (n_peers > 0) { REQUIRE(peers); REQUIRE(send_counts); REQUIRE(send_ids); REQUIRE(recv_counts); REQUIRE(recv_ids); }
+    return guarded([&] { build_halo(s, level, n_peers, peers, send_counts, send_ids, recv_counts, recv_ids, comm_of(s).world); });
+}
+
+// Bring the ghosts of `variables` up to date (after mgcfd_set_array, before the first sweep).  In an in-process group
+// call mgcfd_group_exchange instead.
+int mgcfd_rank_exchange(mgcfd_solver *s, int level)
+{
+    OP({
+        if (!comm_of(s).rccl) throw std::invalid_argument("in-process ranks exchange through mgcfd_group_exchange");
+        DeviceLevel &lv = s->level(level);
+        if (!lv.hx) throw std::invalid_argument("the level has no halo lists");
+        halo_finish(s, level, lv.q);
+        halo_start(s, level, lv.q);
+        halo_finish(s, level, lv.q);
+        lv.min_ahead = false;
+    });
+}
+
+int mgcfd_rank_sweeps(mgcfd_solver *s, int level, int sweeps)
+{
+    OP({
+        mgcfd_comm &c = comm_of(s);
+        if (!c.rccl) throw std::invalid_argument("in-process ranks sweep through mgcfd_group_sweeps");
+        DeviceLevel &lv = s->level(level);
+        const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
+        for (int k = 0; k < sweeps; k++) {
+            sweep_first_half(s, level);
+            if (global_dt) RCCL_CHECK(g_rccl.AllReduce(lv.min_dt, lv.min_dt, 1, Rccl::kDouble, Rccl::kMin, c.rccl, s->stream));
+            for (int j = 0; j < MGCFD_RK; j++) {
+                stage_boundary(s, level, j, global_dt ? 2 : 0, nullptr, 0);
+                stage_interior(s, level, j, global_dt ? 2 : 0, nullptr, 0);
+            }
+        }
+        halo_finish(s, level, lv.q);                        // the ghosts of `variables` are current when the call returns
+    });
+}
+
+// calc_rms over a partitioned level (src/Kernels/validation.cpp:91-105): the sum of squared residuals over the OWNED nodes
+// of every rank (all-reduce SUM of one fp64); rms = sqrt(sum / nodes of the whole level).  Synchronises.
+int mgcfd_rank_residual_sumsq(mgcfd_solver *s, int level, double *sum_all_ranks)
+{
+    REQUIRE(sum_all_ranks);
+    OP({
+        mgcfd_comm &c = comm_of(s);
+        if (!c.rccl) throw std::invalid_argument("in-process ranks: mgcfd_group_rms");
+        DeviceLevel &lv = s->level(level);
+        if (!lv.hx) throw std::invalid_argument("the level has no halo lists");
+        exact::launch_sumsq(s->stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
+        RCCL_CHECK(g_rccl.AllReduce(lv.sumsq, lv.hx->gmin, 1, Rccl::kDouble, Rccl::kSum, c.rccl, s->stream));
+        HIP_CHECK(hipMemcpyAsync(sum_all_ranks, lv.hx->gmin, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+    });
+}
+
+// ---- in-process groups: the ranks are solvers of this process (one per device — or several on one device in tests) ----
+int mgcfd_group_create(int n, mgcfd_solver *const *solvers, mgcfd_group **out)
+{
+    REQUIRE(solvers); REQUIRE(out);
+    return guarded([&] {
+        if (n < 1) throw std::invalid_argument("a group needs at least one rank");
+        auto g = std::make_unique<mgcfd_group>();
+        for (int r = 0; r < n; r++) {
+            if (!solvers[r]) throw std::invalid_argument("null solver");
+            g->ranks.push_back(solvers[r]);
+        }
+        // peer access between the devices of the group (xGMI): a copy between two devices then goes direct
+        for (int a = 0; a < n; a++)
+            for (int b = 0; b < n; b++) {
+                if (solvers[a]->device == solvers[b]->device) continue;
+                int can = 0;
+                HIP_CHECK(hipDeviceCanAccessPeer(&can, solvers[a]->device, solvers[b]->device));
+                if (can) { solvers[a]->use_device(); const hipError_t e = hipDeviceEnablePeerAccess(solvers[b]->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_CHECK(e); (void)hipGetLastError(); }
+            }
+        for (int r = 0; r < n; r++) {
+            mgcfd_comm c;
+            c.rank = r; c.world = n; c.group = g.get();
+            g_comms[solvers[r]] = c;
+        }
+        *out = g.release();
+    });
+}
+
+void mgcfd_group_destroy(mgcfd_group *g)
+{
+    if (!g) return;
+    for (mgcfd_solver *s : g->ranks) g_comms.erase(s);
+    delete g;
+}
+
+int mgcfd_group_exchange(mgcfd_group *g, int level)
+{
+    REQUIRE(g);
+    return guarded([&] {
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); DeviceLevel &lv = s->level(level); if (!lv.hx) throw std::invalid_argument("a rank has no halo lists"); halo_finish(s, level, lv.q); }
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); halo_start(s, level, s->level(level).q); }
+        group_deliver(g, level);
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); DeviceLevel &lv = s->level(level); halo_finish(s, level, lv.q); lv.min_ahead = false; }
+    });
+}
+
+int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps)
+{
+    REQUIRE(g);
+    return guarded([&] {
+        const int n = static_cast<int>(g->ranks.size());
+        const bool global_dt = g->ranks[0]->mesh_variant != MGCFD_MESH_FVCORR;
+        for (int k = 0; k < sweeps; k++) {
+            for (mgcfd_solver *s : g->ranks) { s->use_device(); sweep_first_half(s, level); }
+            if (global_dt) {
+                // all-reduce(MIN) of one fp64 over the group: every rank's minimum lands in slot r of every rank's list
+                // (8-byte peer copies on the destinations' comm streams); the first stage takes the minimum over the list
+                for (mgcfd_solver *src : g->ranks) { src->use_device(); HaloExchange &hs = *src->level(level).hx; HIP_CHECK(hipEventRecord(hs.packed[hs.parity], src->stream)); }
+                for (mgcfd_solver *dst : g->ranks) {
+                    dst->use_device();
+                    HaloExchange &hd = *dst->level(level).hx;
+                    for (int r = 0; r < n; r++) {
+                        mgcfd_solver *src = g->ranks[static_cast<size_t>(r)];
+                        HaloExchange &hs = *src->level(level).hx;
+                        HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, hs.packed[hs.parity], 0));
+                        HIP_CHECK(hipMemcpyPeerAsync(hd.gmin + r, dst->device, src->level(level).min_dt, src->device, sizeof(double), hd.comm_stream));
+                    }
+                    HIP_CHECK(hipEventRecord(hd.arrived[hd.parity], hd.comm_stream));
+                    HIP_CHECK(hipStreamWaitEvent(dst->stream, hd.arrived[hd.parity], 0));
+                }
+            }
+            for (int j = 0; j < MGCFD_RK; j++) {
+                for (mgcfd_solver *s : g->ranks) { s->use_device(); stage_boundary(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, n); }
+                group_deliver(g, level);
+                for (mgcfd_solver *s : g->ranks) { s->use_device(); stage_interior(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, n); }
+            }
+        }
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); halo_finish(s, level, s->level(level).q); }
+    });
+}
+
+// calc_rms over the whole level: sqrt(sum over the ranks' owned nodes of residual^2 / owned nodes of all ranks).  Synchronises.
+int mgcfd_group_rms(mgcfd_group *g, int level, double *rms)
+{
+    REQUIRE(g); REQUIRE(rms);
+    return guarded([&] {
+        double sum = 0.0;
+        int64_t nodes = 0;
+        for (mgcfd_solver *s : g->ranks) {
+            s->use_device();
+            DeviceLevel &lv = s->level(level);
+            exact::launch_sumsq(s->stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
+            double part = 0.0;
+            HIP_CHECK(hipMemcpyAsync(&part, lv.sumsq, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            HIP_CHECK(hipStreamSynchronize(s->stream));
+            sum += part;
+            nodes += lv.n_owned;
+        }
+        *rms = std::sqrt(sum / double(nodes));
+    });
+}
+
+int mgcfd_group_synchronize(mgcfd_group *g)
+{
+    REQUIRE(g);
+    return guarded([&] { for (mgcfd_solver *s : g->ranks) { s->use_device(); HIP_CHECK(hipStreamSynchronize(s->stream)); HIP_CHECK(hipGetLastError()); } });
+}
+
+// how a level's tiles split for the overlapped exchange: out[0] boundary tiles, out[1] interior tiles, out[2] nodes sent, out[3] nodes received
+int mgcfd_rank_halo_info(const mgcfd_solver *s, int level, int64_t out[4])
+{
+    REQUIRE(s); REQUIRE(out);
+    if (level < 0 || level >= static_cast<int>(s->L.size()) || !s->L[static_cast<size_t>(level)].hx) { g_last_error = "the level has no halo lists"; return MGCFD_ERR_ARG; }
+    const HaloExchange &hx = *s->L[static_cast<size_t>(level)].hx;
+    out[0] = hx.n_boundary; out[1] = hx.n_interior; out[2] = hx.total_send(); out[3] = hx.total_recv();
+    return MGCFD_OK;
 }
 
 } // extern "C"

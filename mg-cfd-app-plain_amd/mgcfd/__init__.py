@@ -4,5 +4,5 @@
 ``mgcfd.meshgen``  synthetic meshes in the reference's file formats
 """
 from . import meshgen  # noqa: F401
-from .api import (EXPORTED_SYMBOLS, LIB_PATH, LOOPS, MgcfdError, Mesh, Solver,  # noqa: F401
-                  generated_to_levels, load_library)
+from .api import (EXPORTED_SYMBOLS, LIB_PATH, LOOPS, Group, MgcfdError, Mesh, Solver,  # noqa: F401
+                  generated_to_levels, load_library, rccl_unique_id)

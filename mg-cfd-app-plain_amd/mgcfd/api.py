@@ -117,6 +117,20 @@ _SIGNATURES = [
     ("mgcfd_sweep_flux0", C.c_int, [_vp, C.c_int]),
     ("mgcfd_sweep_end", C.c_int, [_vp, C.c_int]),
     ("mgcfd_residual_sumsq", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    ("mgcfd_rccl_unique_id", C.c_int, [_vp]),
+    ("mgcfd_rank_attach_rccl", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    ("mgcfd_rank_detach", C.c_int, [_vp]),
+    ("mgcfd_rank_set_halo", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp)]),
+    ("mgcfd_rank_halo_info", C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
+    ("mgcfd_rank_exchange", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_rank_sweeps", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("mgcfd_rank_residual_sumsq", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
+    ("mgcfd_group_create", C.c_int, [C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
+    ("mgcfd_group_destroy", None, [_vp]),
+    ("mgcfd_group_exchange", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_group_sweeps", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("mgcfd_group_rms", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
+    ("mgcfd_group_synchronize", C.c_int, [_vp]),
 ]
 EXPORTED_SYMBOLS = tuple(name for name, _, _ in _SIGNATURES)
 
@@ -476,6 +490,38 @@ class Solver:
     def sweep_begin_partials(self, l): self._c(self.lib.mgcfd_sweep_begin_partials(self.handle, l))
     def sweep_end_partials(self, l): self._c(self.lib.mgcfd_sweep_end_partials(self.handle, l))
 
+    # ---- a rank of a partitioned level, the sweep loop inside the library (include/mgcfd.h "Multi-GPU in the C++ host") ----
+    def rank_set_halo(self, l: int, part):
+        """part: mgcfd.partition.LevelPart — its send / recv lists (local ids per peer, ascending global id)."""
+        peers = sorted(set(part.send) | set(part.recv))
+        n = len(peers)
+        keep = [np.ascontiguousarray(part.send.get(p, np.zeros(0, np.int64)), dtype=np.int64) for p in peers] + \
+               [np.ascontiguousarray(part.recv.get(p, np.zeros(0, np.int64)), dtype=np.int64) for p in peers]
+        pa = (C.c_int * max(n, 1))(*peers)
+        sc = (_i64 * max(n, 1))(*[len(a) for a in keep[:n]])
+        rc = (_i64 * max(n, 1))(*[len(a) for a in keep[n:]])
+        sp = (_vp * max(n, 1))(*[a.ctypes.data for a in keep[:n]])
+        rp = (_vp * max(n, 1))(*[a.ctypes.data for a in keep[n:]])
+        self._c(self.lib.mgcfd_rank_set_halo(self.handle, l, n, pa, sc, sp, rc, rp))
+
+    def rank_halo_info(self, l: int) -> dict:
+        out = (_i64 * 4)()
+        self._c(self.lib.mgcfd_rank_halo_info(self.handle, l, out))
+        return dict(zip(("boundary_tiles", "interior_tiles", "nodes_sent", "nodes_received"), [int(v) for v in out]))
+
+    def rank_attach_rccl(self, rank: int, world: int, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._c(self.lib.mgcfd_rank_attach_rccl(self.handle, rank, world, buf))
+
+    def rank_detach(self): self._c(self.lib.mgcfd_rank_detach(self.handle))
+    def rank_exchange(self, l: int): self._c(self.lib.mgcfd_rank_exchange(self.handle, l))
+    def rank_sweeps(self, l: int, sweeps: int = 1): self._c(self.lib.mgcfd_rank_sweeps(self.handle, l, sweeps))
+
+    def rank_residual_sumsq(self, l: int) -> float:
+        v = C.c_double()
+        self._c(self.lib.mgcfd_rank_residual_sumsq(self.handle, l, C.byref(v)))
+        return v.value
+
     def residual_sumsq_devptr(self, l) -> int:
         p = _vp()
         self._c(self.lib.mgcfd_residual_sumsq(self.handle, l, C.byref(p)))
@@ -490,3 +536,37 @@ def generated_to_levels(mg: MultigridMesh) -> List[dict]:
         out.append({"nel": lvl.nel, "volumes": lvl.volumes, "coords": lvl.coords, "edges": edges,
                     "n_internal": ni, "n_boundary": nb, "n_wall": nw, "mg_map": lvl.mg_map})
     return out
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 calls it; the launcher hands the 128 bytes to every rank)."""
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    _check(lib, lib.mgcfd_rccl_unique_id(buf))
+    return buf.raw
+
+
+class Group:
+    """The solvers of THIS process as the ranks of one partitioned level (mgcfd_group_*): solvers[r] = rank r."""
+
+    def __init__(self, solvers):
+        self.lib = load_library()
+        self.solvers = list(solvers)
+        arr = (_vp * len(self.solvers))(*[s.handle for s in self.solvers])
+        h = _vp()
+        _check(self.lib, self.lib.mgcfd_group_create(len(self.solvers), arr, C.byref(h)))
+        self.handle = h
+
+    def exchange(self, l: int = 0): _check(self.lib, self.lib.mgcfd_group_exchange(self.handle, l))
+    def sweeps(self, l: int = 0, n: int = 1): _check(self.lib, self.lib.mgcfd_group_sweeps(self.handle, l, n))
+    def synchronize(self): _check(self.lib, self.lib.mgcfd_group_synchronize(self.handle))
+
+    def rms(self, l: int = 0) -> float:
+        v = C.c_double()
+        _check(self.lib, self.lib.mgcfd_group_rms(self.handle, l, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self.handle:
+            self.lib.mgcfd_group_destroy(self.handle)
+            self.handle = None

@@ -316,3 +316,94 @@ def test_bench_rehearsal_two_ranks_on_this_gpu():
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["n_gpus"] == 2 and line["config"]["workload_kind"] == kind and line["scaling"] == scaling
         assert line["value"] > 0
+
+
+def _group_sweeps_check(mg, n_parts, sweeps, oracle_state=None):
+    """Level 0 of `mg` split into n_parts solvers, the sweeps run by the LIBRARY's own loop (mgcfd_group_sweeps: boundary
+    tiles, one pack, device-to-device messages, interior tiles meanwhile, one unpack) against the unpartitioned run."""
+    import mgcfd
+    from conftest import perturbed_state
+    from mgcfd.partition import partition_level, rcb_partition
+    L = mgcfd.generated_to_levels(mg)[0]
+    parts = partition_level(L, rcb_partition(np.asarray(L["coords"]), n_parts))
+    whole = mgcfd.Solver.from_arrays([L], mg.mesh_variant)
+    q0 = perturbed_state(L["nel"], whole.far_field()[:5], seed=21)
+    whole.set(0, "variables", q0)
+    whole.smooth(0, sweeps)
+    want_v, want_res, want_sf, want_rms = whole.get(0, "variables"), whole.get(0, "residuals"), whole.get(0, "step_factors"), whole.calc_rms(0)
+    whole.close()
+    solvers = []
+    for P in parts:
+        s = mgcfd.Solver.from_arrays([P.level], mg.mesh_variant, n_owned=[P.n_owned])
+        s.set(0, "variables", q0[P.global_ids])
+        solvers.append(s)
+    g = mgcfd.Group(solvers)
+    for P, s in zip(parts, solvers):
+        s.rank_set_halo(0, P)
+        info = s.rank_halo_info(0)
+        assert info["nodes_sent"] == sum(len(v) for v in P.send.values()) and info["nodes_received"] == sum(len(v) for v in P.recv.values())
+        assert info["boundary_tiles"] + info["interior_tiles"] == -(-P.n_local // 256)
+    g.exchange(0)
+    g.sweeps(0, sweeps)
+    g.synchronize()
+    for P, s in zip(parts, solvers):
+        own = P.global_ids[:P.n_owned]
+        _bits_equal(s.get(0, "variables")[:P.n_owned], want_v[own], f"part {P.rank}: owned variables")
+        _bits_equal(s.get(0, "variables")[P.n_owned:], want_v[P.global_ids[P.n_owned:]], f"part {P.rank}: ghosts")
+        _bits_equal(s.get(0, "residuals")[:P.n_owned], want_res[own], f"part {P.rank}: residuals")
+        _bits_equal(s.get(0, "step_factors")[:P.n_owned], want_sf[own], f"part {P.rank}: step factors")
+    assert abs(g.rms(0) - want_rms) <= 1e-12 * want_rms
+    g.close()
+    for s in solvers:
+        s.close()
+
+
+@pytest.mark.parametrize("kind,n_parts", [("lattice", 2), ("lattice", 5), ("fvcorr", 3), ("tet", 4)])
+def test_library_runs_the_partitioned_sweeps_itself(kind, n_parts):
+    """mgcfd_group_sweeps (the C++ host's own loop over the ranks of one process) on small levels: a lattice, a
+    local-time-step (fvcorr) level, a tetrahedral level with long rows — three sweeps, owned nodes and ghosts bit for
+    bit against mgcfd_smooth on the whole level, RMS over the owned nodes of all parts."""
+    from mgcfd import meshgen
+    if kind == "tet":
+        mg = meshgen.make_tet_multigrid((5000,), "m6wing", seed=6)
+    elif kind == "fvcorr":
+        mg = meshgen.make_multigrid((14,), "fvcorr", seed=4, cavity_radius=0.01, volume_noise=0.02)
+    else:
+        mg = meshgen.make_multigrid((20,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    _group_sweeps_check(mg, n_parts, 3)
+
+
+def test_cfg5_eight_parts_library_loop():
+    """BASELINE configs[4] at size with the sweep loop in the library: the 134^3 level in 8 parts as an in-process group
+    (all on this GPU), two sweeps, against mgcfd_smooth on the whole 2.4 M-node level."""
+    import bench
+    mg, _ = bench.build_workload(bench.LATTICE_8X)
+    _group_sweeps_check(mg, 8, 2)
+
+
+def test_rccl_loads_and_a_one_rank_communicator_sweeps():
+    """The RCCL transport with the one rank this box has: librccl is found at run time, ncclCommInitRank succeeds, and
+    mgcfd_rank_sweeps (all-reduce on one rank, no peers) equals mgcfd_smooth bit for bit."""
+    import mgcfd
+    from conftest import perturbed_state
+    from mgcfd import meshgen
+    from mgcfd.partition import partition_level, rcb_partition
+    mg = meshgen.make_multigrid((16,), "m6wing", seed=2, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    L = mgcfd.generated_to_levels(mg)[0]
+    P = partition_level(L, rcb_partition(np.asarray(L["coords"]), 1))[0]
+    ref = mgcfd.Solver.from_arrays([L], mg.mesh_variant)
+    q0 = perturbed_state(L["nel"], ref.far_field()[:5], seed=3)
+    ref.set(0, "variables", q0)
+    ref.smooth(0, 3)
+    want = ref.get(0, "variables")
+    ref.close()
+    s = mgcfd.Solver.from_arrays([P.level], mg.mesh_variant, n_owned=[P.n_owned])
+    s.set(0, "variables", q0[P.global_ids])
+    s.rank_attach_rccl(0, 1, mgcfd.rccl_unique_id())
+    s.rank_set_halo(0, P)
+    s.rank_exchange(0)
+    s.rank_sweeps(0, 3)
+    _bits_equal(s.get(0, "variables"), want, "one-rank RCCL sweeps")
+    assert s.rank_residual_sumsq(0) > 0
+    s.rank_detach()
+    s.close()

@@ -255,6 +255,8 @@ def main():
     ap.add_argument("--lattice", type=int, default=0, help="nodes per side of the synthetic level (default 67; 134 for `partitioned`)")
     ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
     ap.add_argument("--variant", type=int, default=-1, help="MGCFD_OPT_FLUX_VARIANT (see include/mgcfd.h)")
+    ap.add_argument("--exchange", default="library", choices=["library", "torch"],
+                    help="partitioned workload: who runs the sweep loop and the halo exchange (the library over RCCL, or torch.distributed from Python)")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle leg (a rocprofv3 summary of the command then holds only the timed workload's launches)")
     ap.add_argument("--vcycle", action="store_true", help="(default now; kept so older command lines still parse)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (0 disables)")
@@ -362,6 +364,41 @@ def main():
                               make_buffer=lambda n: torch.empty(max(n, 1), dtype=torch.float64, device=dev), fused=True)
         sw.exchange("variables")
         step = sw.sweep
+        exchange = "torch.distributed: a fused launch per stage, pack / batch_isend_irecv / unpack per peer from Python"
+        if world == 1:
+            step, exchange = (lambda: solver.smooth(0, 1)), None
+        elif args.exchange == "library" and not rehearsal:
+            # the sweep loop inside the library (mgcfd_rank_sweeps): boundary tiles, one pack, ncclSend/ncclRecv grouped on a
+            # second stream, the interior tiles under the transfer, one unpack.  Before it is trusted it must reproduce, on
+            # this rank, the sweep the torch path makes from the same state, bit for bit; otherwise the torch path runs
+            # and the line says so.
+            try:
+                uid = [mgcfd.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                solver.rank_attach_rccl(rank, world, uid[0])
+                solver.rank_set_halo(0, P)
+                sw.sweep()
+                torch.cuda.synchronize()
+                want = solver.get(0, "variables")
+                solver.set(0, "variables", q[P.global_ids])
+                solver.rank_exchange(0)
+                solver.rank_sweeps(0, 1)
+                torch.cuda.synchronize()
+                same = bool(np.array_equal(solver.get(0, "variables").view(np.int64), want.view(np.int64)))
+                ok = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if float(ok.item()) != 1.0:
+                    raise RuntimeError("the library's sweep differs from the torch path's on some rank")
+                step = lambda: solver.rank_sweeps(0, 1)
+                info = solver.rank_halo_info(0)
+                exchange = (f"libmgcfd_hip (mgcfd_rank_sweeps): RCCL ncclSend/ncclRecv grouped on a second stream under the interior tiles; "
+                            f"rank 0: {info['boundary_tiles']} boundary + {info['interior_tiles']} interior tiles; checked against the torch path at start-up")
+            except Exception as e:                       # the torch path stands
+                if rank == 0:
+                    print(f"bench.py: library exchange not used: {e}", file=sys.stderr)
+                solver.set(0, "variables", q[P.global_ids])
+                sw.exchange("variables")
+                exchange += f" (the library's RCCL loop was not used: {e})"
         scaling = "strong"
         edges_per_step_all_ranks = 3 * n_int
         halo_nodes = int(halo_volume(L, part)) if world > 1 else 0
@@ -370,7 +407,7 @@ def main():
                        "step": "compute_step_factor + all-reduce(min dt), 3 x (fused fluxes + time_step launch, halo message to every neighbouring rank), residual",
                        "parallelism": f"{world} ranks, owner computes, ghosts read-only", "halo_nodes_total": halo_nodes,
                        "halo_bytes_per_stage_all_ranks": halo_nodes * 40, "peers_of_rank0": len(sw.peers),
-                       "owned_nodes_rank0": int(P.n_owned), "local_internal_edges_rank0": int(P.level["n_internal"])})
+                       "owned_nodes_rank0": int(P.n_owned), "local_internal_edges_rank0": int(P.level["n_internal"]), "exchange": exchange})
     else:                                                    # level-per-gpu
         mg, levels = build_hierarchy()
         solver = make_solver(levels, mg.mesh_variant)

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "mgcfd.h"
+#include "multi_gpu.hpp"
 
 namespace {
 
@@ -36,6 +37,8 @@ struct Config {                       // the reference's `config` (src/Base/conf
     bool indirect_rw = true;          // the reference runs the probe every RK stage; --no-indirect-rw skips it
     bool legacy_ordering = false;     // --legacy-ordering: the reference's -DLEGACY_ORDERING edge sort (a compile-time flag there)
     int device = 0;
+    int gpus = 1;                     // --gpus N: a single-level input partitioned over N GPUs, a multigrid input one level per GPU
+    bool gpus_share_device = false;   // --gpus-share-device: all N ranks on --device (rehearsal on a one-GPU box)
 };
 
 std::string trim(const std::string &s)
@@ -110,7 +113,11 @@ void print_help()
         "  --output-fluxes                  Write flux accumulations to file\n"
         "  --output-step-factors            Write step factors to file\n\n"
         "GPU ARGUMENTS (extensions)\n"
-        "  --device=INT                     GPU to run on (default 0)\n"
+        "  --device=INT                     GPU to run on (default 0); with --gpus the first of the N devices\n"
+        "  --gpus=INT                       Run on N GPUs of this node: a single-level input is partitioned over them\n"
+        "                                   (halo messages after every Runge-Kutta stage), a multigrid input runs one\n"
+        "                                   level per GPU; fused path (as --no-timers)\n"
+        "  --gpus-share-device              With --gpus: every rank on the one device (functional rehearsal)\n"
         "  --no-timers                      One fused launch per Runge-Kutta stage; no per-loop times\n"
         "  --no-indirect-rw                 Skip the indirect_rw bandwidth probe each RK stage\n"
         "  --fast                           Allow FMA contraction (results within 1e-12 relative)\n"
@@ -140,6 +147,8 @@ bool parse_arguments(int argc, char **argv, Config &c)
         {"no-indirect-rw", no_argument, nullptr, 1006},
         {"fast", no_argument, nullptr, 1007},
         {"legacy-ordering", no_argument, nullptr, 1008},
+        {"gpus", required_argument, nullptr, 1009},
+        {"gpus-share-device", no_argument, nullptr, 1010},
         {nullptr, 0, nullptr, 0}};
     int optc;
     while ((optc = getopt_long(argc, argv, "hc:i:d:p:o:m:g:v", long_opts, nullptr)) != -1) {
@@ -161,6 +170,8 @@ bool parse_arguments(int argc, char **argv, Config &c)
             case 1006: c.indirect_rw = false; break;
             case 1007: c.fast_math = true; break;
             case 1008: c.legacy_ordering = true; break;
+            case 1009: c.gpus = std::atoi(optarg); break;
+            case 1010: c.gpus_share_device = true; break;
             default: std::printf("Unknown command line parameter '%c'\n", optc);
         }
     }
@@ -210,7 +221,7 @@ const char *mesh_name(int v)
 // The 16 identification columns of src/Base/io_enhanced.cpp:858-1016, re-read for a GPU build:
 // CC = hipcc's clang, Instruction set = gfx950, Num threads = number of GPUs, CPU = device name.
 void csv_identification(const Config &c, int size, int mesh_variant, const std::string &device_name,
-                        std::string &header, std::string &line)
+                        std::string &header, std::string &line, int num_gpus = 1)
 {
     std::ostringstream h, d;
     h << "Size,";                  d << size << ",";
@@ -225,7 +236,7 @@ void csv_identification(const Config &c, int size, int mesh_variant, const std::
     h << "SIMD,";                  d << "N,";
     h << "SIMD len,";              d << "1,";
     h << "OpenMP,";                d << "Off,";
-    h << "Num threads,";           d << "1,";
+    h << "Num threads,";           d << num_gpus << ",";
     h << "Permit scatter OpenMP,"; d << "N,";
     h << "Flux fission,";          d << "N,";
     h << "CPU,";                   d << device_name << ",";
@@ -257,6 +268,64 @@ int fail(const char *what)
     return EXIT_FAILURE;
 }
 
+// --gpus N (multi_gpu.cpp): the same outputs as the one-GPU run from N ranks of this process
+int run_on_several_gpus(const Config &conf, mgcfd_mesh *mesh, int levels, int mesh_variant, int problem_size)
+{
+    try {
+        multi_gpu::Options o;
+        o.gpus = conf.gpus; o.first_device = conf.device; o.share_device = conf.gpus_share_device; o.fast_math = conf.fast_math;
+        const auto tb = std::chrono::steady_clock::now();
+        multi_gpu::Run run(mesh, o);
+        std::fprintf(stderr, "[euler3d_gpu_double] %d ranks (%s), set up in %.2f s\n", run.ranks(),
+                     run.partitioned() ? "level 0 partitioned by recursive coordinate bisection" : "one multigrid level per GPU",
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count());
+        std::vector<double> rms(static_cast<size_t>(conf.num_cycles > 0 ? conf.num_cycles : 0));
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = run.run_cycles(conf.num_cycles, rms.data());
+        const double total_compute_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (int i = 0; i < conf.num_cycles; i++)
+            std::printf(levels <= 1 ? "\nCycle %d / %d (RMS = %.3e)" : "\nMG cycle %d / %d (RMS = %.3e)", i + 1, conf.num_cycles, rms[static_cast<size_t>(i)]);
+        std::printf("\n");
+        if (rc == MGCFD_ERR_NAN || rc == MGCFD_ERR_NEG_DENSITY || rc == MGCFD_ERR_NEG_ENERGY) {
+            std::printf(rc == MGCFD_ERR_NAN ? "\nERROR: NaN detected!\n" : rc == MGCFD_ERR_NEG_DENSITY ? "\nERROR: Negative density detected!\n" : "\nERROR: Negative density.energy detected!\n");
+            return EXIT_FAILURE;
+        }
+        if (rc != MGCFD_OK) return fail("running the cycles");
+        std::printf("Total runtime = %g\n\n", total_compute_time);
+        mgcfd_level_desc d0;
+        mgcfd_mesh_level(mesh, 0, &d0);
+        auto dump = [&](int which, const char *name, int ncols) {
+            std::vector<double> a(static_cast<size_t>(d0.nel) * ncols);
+            run.get_level0(which, ncols, a.data());
+            const std::string path = output_filepath(conf, name, 0);
+            if (which == MGCFD_ARR_VARIABLES) std::printf("Dumping variables[] to file: %s\n", path.c_str());
+            if (mgcfd_write_array(path.c_str(), a.data(), d0.nel, ncols) != MGCFD_OK) { fail("writing a dump"); std::exit(EXIT_FAILURE); }
+        };
+        if (conf.output_variables) dump(MGCFD_ARR_VARIABLES, "variables", MGCFD_NVAR);
+        if (conf.output_step_factors) dump(MGCFD_ARR_STEP_FACTORS, "step_factors", 1);
+        std::string device_name = "unknown GPU";
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, conf.device) == hipSuccess) device_name = prop.name;
+        std::string ih, il;
+        csv_identification(conf, problem_size, mesh_variant, device_name, ih, il, run.ranks());
+        std::vector<std::vector<std::string>> times(static_cast<size_t>(levels)), iters(static_cast<size_t>(levels));
+        for (int l = 0; l < levels; l++) {
+            int64_t n[MGCFD_NUM_LOOPS];
+            run.loop_iters(l, conf.num_cycles, n);
+            for (int k = 0; k < MGCFD_NUM_LOOPS; k++) { times[static_cast<size_t>(l)].push_back("0"); iters[static_cast<size_t>(l)].push_back(std::to_string(n[k])); }
+        }
+        const std::string tpath = csv_filepath(conf, "Times.csv"), ipath = csv_filepath(conf, "LoopNumIters.csv");
+        write_csv(tpath, ih, il, levels, times, true, total_compute_time);
+        std::printf("Loop runtimes written to: %s\n", tpath.c_str());
+        write_csv(ipath, ih, il, levels, iters, false, 0.0);
+        std::printf("Loop stats written to: %s\n", ipath.c_str());
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "ERROR: %s\n", e.what());
+        return EXIT_FAILURE;
+    }
+}
+
 } // namespace
 
 int main(int argc, char **argv)
@@ -275,6 +344,8 @@ int main(int argc, char **argv)
     const int levels = mgcfd_mesh_num_levels(mesh);
     const int mesh_variant = mgcfd_mesh_variant(mesh);
     const int problem_size = mgcfd_mesh_size(mesh);
+
+    if (conf.gpus > 1) return run_on_several_gpus(conf, mesh, levels, mesh_variant, problem_size);
 
     mgcfd_solver *solver = nullptr;
     if (mgcfd_create_from_mesh(mesh, conf.device, &solver) != MGCFD_OK) return fail("creating the GPU solver");

@@ -1,0 +1,319 @@
+// multi_gpu.cpp — euler3d_gpu_double --gpus N: the drop-in driver on N GPUs of one node, one process, written against
+// the C ABI of include/mgcfd.h only (like main.cpp).
+//
+//   single-level input   the level is split over the N GPUs by recursive coordinate bisection (BASELINE configs[4]);
+//                        every GPU owns its nodes and keeps read-only ghosts of the neighbours' nodes its edges touch;
+//                        the sweep loop runs inside the library (mgcfd_group_sweeps: one all-reduce(MIN) of the time step
+//                        per sweep, a halo message per neighbour after every Runge-Kutta stage, hidden under the
+//                        interior tiles).  Owned nodes equal the one-GPU run bit for bit.
+//   multigrid input      level l lives on GPU l % N (BASELINE configs[3]); the restricted variables go up and the coarse
+//                        residuals come down as whole-array device-to-device copies (hipMemcpyPeerAsync over xGMI).
+//                        The V-cycle is sequential in levels: this is placement, not concurrency.
+//
+// The reference has no multi-device path; its cycle loop (src/euler3d_cpu_double.cpp:371-694) fixes what has to move.
+#include "multi_gpu.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <stdexcept>
+
+#include <hip/hip_runtime_api.h>
+
+namespace multi_gpu {
+
+namespace {
+
+struct Part {
+    int64_t n_owned = 0;
+    std::vector<int64_t> gids;                        // global id of every local node: owned (ascending), then ghosts (ascending)
+    std::vector<double> volumes, coords;
+    std::vector<mgcfd_edge> edges;                    // internal | boundary | wall, the whole mesh's relative order kept
+    int64_t ni = 0, nb = 0, nw = 0;
+    std::map<int, std::vector<int64_t>> send, recv;   // peer -> local ids (ascending global id on both sides)
+};
+
+// recursive coordinate bisection: split along the longest axis of the bounding box into halves whose sizes are
+// proportional to the parts each will hold (equal counts to within a node, any n >= 1)
+void rcb(const double *coords, std::vector<int64_t> &ids, int64_t b, int64_t e, int first, int count, std::vector<int> &part)
+{
+    if (count == 1 || e <= b) { for (int64_t k = b; k < e; k++) part[static_cast<size_t>(ids[static_cast<size_t>(k)])] = first; return; }
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t k = b; k < e; k++)
+        for (int d = 0; d < 3; d++) {
+            const double c = coords[3 * ids[static_cast<size_t>(k)] + d];
+            lo[d] = std::min(lo[d], c); hi[d] = std::max(hi[d], c);
+        }
+    int axis = 0;
+    for (int d = 1; d < 3; d++) if (hi[d] - lo[d] > hi[axis] - lo[axis]) axis = d;
+    std::stable_sort(ids.begin() + b, ids.begin() + e, [&](int64_t x, int64_t y) { return coords[3 * x + axis] < coords[3 * y + axis]; });
+    const int left = count / 2;
+    const int64_t cut = b + ((e - b) * left) / count;
+    rcb(coords, ids, b, cut, first, left, part);
+    rcb(coords, ids, cut, e, first + left, count - left, part);
+}
+
+std::vector<Part> partition_level(const mgcfd_level_desc &L, const std::vector<int> &part, int n_parts)
+{
+    std::vector<Part> parts(static_cast<size_t>(n_parts));
+    const mgcfd_edge *E = L.edges;
+    std::vector<int64_t> local(static_cast<size_t>(L.nel));
+    for (int r = 0; r < n_parts; r++) {
+        Part &P = parts[static_cast<size_t>(r)];
+        std::vector<char> touched(static_cast<size_t>(L.nel), 0);
+        for (int64_t i = 0; i < L.nel; i++) if (part[static_cast<size_t>(i)] == r) P.gids.push_back(i);
+        P.n_owned = static_cast<int64_t>(P.gids.size());
+        std::vector<int64_t> keep;
+        for (int64_t e = L.internal_start; e < L.internal_start + L.n_internal; e++)
+            if (part[static_cast<size_t>(E[e].a)] == r || part[static_cast<size_t>(E[e].b)] == r) {
+                keep.push_back(e);
+                touched[static_cast<size_t>(E[e].a)] = touched[static_cast<size_t>(E[e].b)] = 1;
+            }
+        P.ni = static_cast<int64_t>(keep.size());
+        for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++) if (part[static_cast<size_t>(E[e].b)] == r) { keep.push_back(e); P.nb++; }
+        for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++) if (part[static_cast<size_t>(E[e].b)] == r) { keep.push_back(e); P.nw++; }
+        for (int64_t i = 0; i < L.nel; i++) if (touched[static_cast<size_t>(i)] && part[static_cast<size_t>(i)] != r) P.gids.push_back(i);   // ghosts, ascending
+        std::fill(local.begin(), local.end(), int64_t(-1));
+        for (size_t k = 0; k < P.gids.size(); k++) local[static_cast<size_t>(P.gids[k])] = static_cast<int64_t>(k);
+        for (int64_t g : P.gids) {
+            P.volumes.push_back(L.volumes[g]);
+            if (L.coords) for (int d = 0; d < 3; d++) P.coords.push_back(L.coords[3 * g + d]);
+        }
+        for (size_t k = 0; k < keep.size(); k++) {
+            mgcfd_edge e = E[keep[k]];
+            if (static_cast<int64_t>(k) < P.ni) e.a = local[static_cast<size_t>(e.a)];      // boundary / far-field faces keep their code in a
+            e.b = local[static_cast<size_t>(e.b)];
+            P.edges.push_back(e);
+        }
+        for (size_t k = static_cast<size_t>(P.n_owned); k < P.gids.size(); k++)
+            P.recv[part[static_cast<size_t>(P.gids[k])]].push_back(static_cast<int64_t>(k));
+    }
+    // what a peer receives from me, in the same (ascending global id) order
+    for (int r = 0; r < n_parts; r++)
+        for (auto &kv : parts[static_cast<size_t>(r)].recv) {
+            Part &Q = parts[static_cast<size_t>(kv.first)];
+            std::vector<int64_t> &out = Q.send[r];
+            for (int64_t lg : kv.second) {
+                const int64_t g = parts[static_cast<size_t>(r)].gids[static_cast<size_t>(lg)];
+                const auto it = std::lower_bound(Q.gids.begin(), Q.gids.begin() + Q.n_owned, g);
+                out.push_back(static_cast<int64_t>(it - Q.gids.begin()));
+            }
+        }
+    return parts;
+}
+
+void check(int rc, const char *what)
+{
+    if (rc != MGCFD_OK) throw std::runtime_error(std::string(what) + ": " + mgcfd_last_error());
+}
+
+int device_of_rank(const Options &o, int r) { return o.share_device ? o.first_device : o.first_device + r; }
+
+} // namespace
+
+struct Run::Impl {
+    Options opt;
+    int levels = 0, mesh_variant = 0;
+    bool partitioned = false;
+    std::vector<mgcfd_solver *> solvers;
+    mgcfd_group *group = nullptr;
+    std::vector<Part> parts;
+    int64_t nel0 = 0;
+    std::vector<int64_t> n_internal, nel;             // whole-mesh sizes per level (the reference's loop counts)
+    std::vector<hipStream_t> streams;
+    // level-per-GPU: staging arrays for the restricted variables
+    std::vector<void *> stage;
+};
+
+Run::Run(const mgcfd_mesh *mesh, const Options &opt) : p(new Impl)
+{
+    p->opt = opt;
+    p->levels = mgcfd_mesh_num_levels(mesh);
+    p->mesh_variant = mgcfd_mesh_variant(mesh);
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess) have = 0;
+    if (!opt.share_device && opt.first_device + opt.gpus > have)
+        throw std::runtime_error("--gpus " + std::to_string(opt.gpus) + " but only " + std::to_string(have) + " GPU(s) are visible");
+    for (int l = 0; l < p->levels; l++) {
+        mgcfd_level_desc d;
+        check(mgcfd_mesh_level(mesh, l, &d), "reading a level");
+        p->nel.push_back(d.nel);
+        p->n_internal.push_back(d.n_internal);
+    }
+    p->nel0 = p->nel[0];
+    p->partitioned = p->levels == 1;
+    if (p->partitioned) {
+        mgcfd_level_desc L;
+        check(mgcfd_mesh_level(mesh, 0, &L), "reading level 0");
+        std::vector<int> part(static_cast<size_t>(L.nel), 0);
+        if (L.coords) {
+            std::vector<int64_t> ids(static_cast<size_t>(L.nel));
+            std::iota(ids.begin(), ids.end(), int64_t(0));
+            rcb(L.coords, ids, 0, L.nel, 0, opt.gpus, part);
+        } else {
+            // no coordinates (a single-level fvcorr input has no .coords file): equal ranges of node ids — any
+            // partition gives the same results, a good one fewer ghosts
+            for (int64_t i = 0; i < L.nel; i++) part[static_cast<size_t>(i)] = static_cast<int>((i * opt.gpus) / L.nel);
+        }
+        p->parts = partition_level(L, part, opt.gpus);
+        for (int r = 0; r < opt.gpus; r++) {
+            Part &P = p->parts[static_cast<size_t>(r)];
+            mgcfd_level_desc d{};
+            d.nel = static_cast<int64_t>(P.gids.size());
+            d.n_edges = static_cast<int64_t>(P.edges.size());
+            d.n_internal = P.ni; d.n_boundary = P.nb; d.n_wall = P.nw;
+            d.internal_start = 0; d.boundary_start = P.ni; d.wall_start = P.ni + P.nb;
+            d.volumes = P.volumes.data();
+            d.coords = P.coords.empty() ? nullptr : P.coords.data();
+            d.edges = P.edges.data();
+            mgcfd_solver *s = nullptr;
+            check(mgcfd_create_partitioned(&d, 1, p->mesh_variant, device_of_rank(opt, r), &P.n_owned, &s), "creating a rank's solver");
+            p->solvers.push_back(s);
+        }
+        check(mgcfd_group_create(opt.gpus, p->solvers.data(), &p->group), "forming the group");
+        for (int r = 0; r < opt.gpus; r++) {
+            Part &P = p->parts[static_cast<size_t>(r)];
+            std::vector<int> peers;
+            for (auto &kv : P.send) peers.push_back(kv.first);
+            for (auto &kv : P.recv) if (!P.send.count(kv.first)) peers.push_back(kv.first);
+            std::sort(peers.begin(), peers.end());
+            std::vector<int64_t> sc, rc;
+            std::vector<const int64_t *> sp, rp;
+            static const int64_t none = 0;
+            for (int q : peers) {
+                const auto &sv = P.send[q], &rv = P.recv[q];
+                sc.push_back(static_cast<int64_t>(sv.size())); rc.push_back(static_cast<int64_t>(rv.size()));
+                sp.push_back(sv.empty() ? &none : sv.data()); rp.push_back(rv.empty() ? &none : rv.data());
+            }
+            check(mgcfd_rank_set_halo(p->solvers[static_cast<size_t>(r)], 0, static_cast<int>(peers.size()), peers.data(), sc.data(), sp.data(), rc.data(), rp.data()),
+                  "setting a rank's halo lists");
+        }
+        check(mgcfd_group_exchange(p->group, 0), "the first halo exchange");
+    } else {
+        // one multigrid level per GPU: every rank holds the hierarchy (plans and static data), sweeps only its levels
+        for (int r = 0; r < std::min(opt.gpus, p->levels); r++) {
+            mgcfd_solver *s = nullptr;
+            check(mgcfd_create_from_mesh(mesh, device_of_rank(opt, r), &s), "creating a rank's solver");
+            p->solvers.push_back(s);
+        }
+        p->stage.assign(static_cast<size_t>(p->levels), nullptr);
+    }
+    for (mgcfd_solver *s : p->solvers) {
+        mgcfd_set_option(s, MGCFD_OPT_EXACT, opt.fast_math ? 0 : 1);
+        mgcfd_set_option(s, MGCFD_OPT_TIMING, 0);                 // the fused path: per-loop times are not collected across devices
+    }
+}
+
+Run::~Run()
+{
+    if (p->group) mgcfd_group_destroy(p->group);
+    for (size_t l = 0; l < p->stage.size(); l++) if (p->stage[l]) (void)hipFree(p->stage[l]);
+    for (mgcfd_solver *s : p->solvers) mgcfd_destroy(s);
+    delete p;
+}
+
+int Run::ranks() const { return static_cast<int>(p->solvers.size()); }
+bool Run::partitioned() const { return p->partitioned; }
+
+// level-per-GPU: move a whole node array of `level` from the solver of rank `src` to the solver of rank `dst`
+static void hand_over(Run::Impl *p, int level, int which, int src, int dst, bool restricted)
+{
+    if (src == dst) return;
+    mgcfd_solver *a = p->solvers[static_cast<size_t>(src)], *b = p->solvers[static_cast<size_t>(dst)];
+    void *from = nullptr, *to = nullptr;
+    int64_t count = 0, count_b = 0;
+    check(mgcfd_array_devptr(a, level, which, &from, &count), "array address");
+    check(mgcfd_array_devptr(b, level, which, &to, &count_b), "array address");
+    check(mgcfd_synchronize(a), "synchronising the sender");     // (placement, not concurrency: the levels run one after another anyway)
+    const int da = device_of_rank(p->opt, src), db = device_of_rank(p->opt, dst);
+    if (restricted) {
+        // mg_restrict leaves a coarse node without children at ITS old value, which only the receiving rank has
+        if (!p->stage[static_cast<size_t>(level)]) {
+            if (hipSetDevice(db) != hipSuccess || hipMalloc(&p->stage[static_cast<size_t>(level)], sizeof(double) * static_cast<size_t>(count)) != hipSuccess)
+                throw std::runtime_error("allocating a staging array");
+        }
+        if (hipMemcpyPeer(p->stage[static_cast<size_t>(level)], db, from, da, sizeof(double) * static_cast<size_t>(count)) != hipSuccess)
+            throw std::runtime_error("device-to-device copy failed");
+        check(mgcfd_accept_restricted(b, level - 1, p->stage[static_cast<size_t>(level)]), "taking the restricted variables");
+    } else {
+        check(mgcfd_synchronize(b), "synchronising the receiver");
+        if (hipMemcpyPeer(to, db, from, da, sizeof(double) * static_cast<size_t>(count)) != hipSuccess)
+            throw std::runtime_error("device-to-device copy failed");
+        check(mgcfd_array_written(b, level, which), "marking the array written");
+    }
+}
+
+int Run::run_cycles(int cycles, double *rms_out)
+{
+    const int n = p->levels, w = ranks();
+    for (int c = 0; c < cycles; c++) {
+        if (p->partitioned) {
+            check(mgcfd_group_sweeps(p->group, 0, 1), "a partitioned sweep");
+            double rms = 0.0;
+            check(mgcfd_group_rms(p->group, 0, &rms), "the RMS");
+            if (rms_out) rms_out[c] = rms;
+        } else {
+            auto owner = [&](int l) { return l % w; };
+            for (int l = 0; l < n; l++) {
+                mgcfd_solver *s = p->solvers[static_cast<size_t>(owner(l))];
+                check(mgcfd_smooth(s, l, 1), "a sweep");
+                if (l == 0) { double rms = 0.0; check(mgcfd_calc_rms(s, 0, &rms), "the RMS"); if (rms_out) rms_out[c] = rms; }
+                if (l + 1 < n) {
+                    check(mgcfd_restrict(s, l), "restrict");                 // fills level l+1's variables on the FINE level's rank
+                    hand_over(p, l + 1, MGCFD_ARR_VARIABLES, owner(l), owner(l + 1), true);
+                }
+            }
+            for (int l = n - 2; l >= 0; l--) {
+                hand_over(p, l + 1, MGCFD_ARR_RESIDUALS, owner(l + 1), owner(l), false);
+                mgcfd_solver *s = p->solvers[static_cast<size_t>(owner(l))];
+                check(mgcfd_prolong(s, l), "prolong");
+                if (l > 0) check(mgcfd_smooth(s, l, 1), "a sweep");
+            }
+        }
+    }
+    // check_for_invalid_variables (src/Kernels/validation.cpp:107-138): every fused stage carried the check
+    for (int r = 0; r < w; r++)
+        for (int l = 0; l < (p->partitioned ? 1 : n); l++) {
+            if (!p->partitioned && l % w != r) continue;
+            int64_t bad = -1;
+            const int rc = mgcfd_check_for_invalid_variables(p->solvers[static_cast<size_t>(r)], l, &bad);
+            if (rc != MGCFD_OK) return rc;
+        }
+    return MGCFD_OK;
+}
+
+void Run::get_level0(int which, int ncols, double *out) const
+{
+    if (!p->partitioned) { check(mgcfd_get_array(p->solvers[0], 0, which, out), "reading back an array"); return; }
+    for (size_t r = 0; r < p->solvers.size(); r++) {
+        const Part &P = p->parts[r];
+        std::vector<double> a(P.gids.size() * static_cast<size_t>(ncols));
+        check(mgcfd_get_array(p->solvers[r], 0, which, a.data()), "reading back an array");
+        for (int64_t k = 0; k < P.n_owned; k++)
+            std::memcpy(out + P.gids[static_cast<size_t>(k)] * ncols, a.data() + static_cast<size_t>(k) * ncols, sizeof(double) * static_cast<size_t>(ncols));
+    }
+}
+
+void Run::loop_iters(int level, int cycles, int64_t out[MGCFD_NUM_LOOPS]) const
+{
+    // what the reference's counters would hold for the whole mesh (src/Monitoring/loop_stats.cpp:48-81): a rank's own
+    // counters include the edges cut by the partition once per side
+    std::memset(out, 0, sizeof(int64_t) * MGCFD_NUM_LOOPS);
+    if (p->partitioned) {
+        out[MGCFD_LOOP_FLUX] = int64_t(MGCFD_RK) * cycles * p->n_internal[0];
+        out[MGCFD_LOOP_COMPUTE_STEP] = int64_t(cycles) * p->nel[0];
+        out[MGCFD_LOOP_TIME_STEP] = int64_t(MGCFD_RK) * cycles * p->nel[0];
+        return;
+    }
+    check(mgcfd_get_loop_iters(p->solvers[static_cast<size_t>(level % ranks())], level, out), "loop counters");
+    if (level > 0) {                                             // restrict is counted on the coarse level, where it ran on the fine level's rank
+        int64_t fine[MGCFD_NUM_LOOPS];
+        check(mgcfd_get_loop_iters(p->solvers[static_cast<size_t>((level - 1) % ranks())], level, fine), "loop counters");
+        out[MGCFD_LOOP_RESTRICT] = fine[MGCFD_LOOP_RESTRICT];
+    }
+}
+
+} // namespace multi_gpu

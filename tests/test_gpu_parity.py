@@ -1395,3 +1395,36 @@ def test_tetrahedral_level_matches_oracle_on_one_sweep(big_tet, oracle):
     s.smooth(0, 1)
     assert np.array_equal(s.get(0, "variables").view(np.int64), var.view(np.int64))
 
+
+
+@pytest.mark.parametrize("case,gpus", [("fvcorr_1lvl", 3), ("m6_3lvl", 2), ("m6_3lvl", 3), ("m6_2lvl_dup2", 2)])
+def test_driver_on_several_gpus_reproduces_reference_binary(case, gpus, tmp_path):
+    """euler3d_gpu_double --gpus N (all ranks on this one GPU: --gpus-share-device): a single-level input partitioned
+    over the ranks with halo messages after every stage, a multigrid input with one level per rank — the variables
+    dump must still be the reference binary's byte for byte, the RMS lines and the loop counters the same."""
+    d, cycles, dup = _case(case)
+    exe = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
+    cmd = [exe, "-i", "input.dat", "-d", os.path.join(d, "input"), "-o", str(tmp_path) + "/", "-g", str(cycles),
+           "-m", str(dup), "--output-variables", "--gpus", str(gpus), "--gpus-share-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    dump = tmp_path / f"variables.size={dup}x.cycles={cycles}.level=0"
+    assert dump.read_bytes() == open(os.path.join(d, "variables.level0.txt"), "rb").read()
+    want_lines = [l.strip() for l in open(os.path.join(d, "stdout.txt")) if "RMS" in l]
+    got_lines = [l.strip() for l in r.stdout.splitlines() if "RMS" in l]
+    assert got_lines == want_lines
+    want, got = _csv_row(os.path.join(d, "LoopNumIters.csv")), _csv_row(tmp_path / "LoopNumIters.csv")
+    assert list(got.keys()) == list(want.keys())
+    for k in want:
+        if k[:-1] in ("flux", "update", "compute_step", "time_step", "restrict", "prolong") or k in ("Size", "Mesh", "MG cycles"):
+            assert got[k] == want[k], k
+    assert got["Num threads"] == str(min(gpus, 3 if case == "m6_3lvl" else (2 if case == "m6_2lvl_dup2" else gpus)))
+    assert f"{int(got['Num threads'])} ranks" in r.stderr
+
+
+def test_driver_refuses_more_gpus_than_there_are(tmp_path):
+    d, cycles, dup = _case("fvcorr_1lvl")
+    exe = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
+    r = subprocess.run([exe, "-i", "input.dat", "-d", os.path.join(d, "input"), "-o", str(tmp_path) + "/", "-g", "1", "--gpus", "64"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr

@@ -39,6 +39,7 @@ struct FusedStep {
     // fluxes and its divisor RK+1-0; the input state is then old_variables + (min_dt/volume/vin_div) * vin_flux
     const double *vin_flux = nullptr;
     double vin_div = 4.0;
+    int check_vin = 0;                        // ... and the check sequence number of that absorbed time_step (earlier than `check`)
     double *sumsq_partial = nullptr;          // != nullptr (last stage): per-tile sums of squares of the residuals (calc_rms, validation.cpp:91-105)
     // look-ahead for the NEXT sweep on this level, from the state this launch produces:
     double *next_partial_min = nullptr;       // first half of compute_step_factor: per-tile minima of 0.5*cbrt(vol)/(|v|+c)

@@ -635,13 +635,13 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         const double fo = (min_dt / vo) / fs.vin_div, fh = (min_dt / vh) / fs.vin_div;      // k_time_step: factor = sf / rk_div
         o0 = b0 + fo * f0; o1 = b1 + fo * f1; o2 = b2 + fo * f2; o3 = b3 + fo * f3; o4 = b4 + fo * f4;
         g0 = c0 + fh * h0; g1 = c1 + fh * h1; g2 = c2 + fh * h2; g3 = c3 + fh * h3; g4 = c4 + fh * h4;
-        if (fs.check && i < nel) {                                      // the first stage's check_for_invalid_variables
+        if (fs.check_vin && i < nel) {                                  // the first stage's check_for_invalid_variables (its own, earlier, sequence number)
             const bool finite = isfinite(o0) && isfinite(o1) && isfinite(o2) && isfinite(o3) && isfinite(o4);
             int code = 0;
             if (!finite) code = 1;
             else if (o0 < 0.0) code = 2;
             else if (o4 < 0.0) code = 3;
-            if (code) atomicMin(fs.err, err_key(fs.check, fs.old_of_new[i], code));
+            if (code) atomicMin(fs.err, err_key(fs.check_vin, fs.old_of_new[i], code));
         }
     } else {
         o0 = q[i]; o1 = q[stride + i]; o2 = q[2 * stride + i]; o3 = q[3 * stride + i]; o4 = q[4 * stride + i];

@@ -311,6 +311,7 @@ struct mgcfd_solver {
         fs.vin_div = double(MGCFD_RK + 1);
         fs.old_of_new = lv.dp.old_of_new;
         fs.err = err;
+        if (vin_flux) fs.check_vin = next_check();       // the absorbed first stage's check_for_invalid_variables comes first
         fs.check = force_check >= 0 ? force_check : next_check();
         Timed t(this, l, MGCFD_LOOP_FLUX, true);
         if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs);
@@ -908,7 +909,7 @@ int mgcfd_get_far_field(const mgcfd_solver *s, double *out17)
 }
 
 // ---- kernel-granular operations ----
-#define OP(body) REQUIRE(s); return guarded([&] { s->use_device(); body; })
+#define OP(body) REQUIRE(s); return guarded([&] { s->use_device(); body; HIP_CHECK(hipGetLastError()); })   /* (a launch that failed must not come back as MGCFD_OK) */
 int mgcfd_copy_old_variables(mgcfd_solver *s, int level) { OP(s->op_copy_old(level)); }
 int mgcfd_compute_step_factor(mgcfd_solver *s, int level) { OP(s->op_step_factor(level)); }
 int mgcfd_compute_flux_edge(mgcfd_solver *s, int level) { OP(s->op_flux(level, 1)); }
@@ -945,7 +946,7 @@ int mgcfd_calc_rms(mgcfd_solver *s, int level, double *rms)
         double sum = 0.0;
         HIP_CHECK(hipMemcpyAsync(&sum, lv.sumsq, sizeof(double), hipMemcpyDeviceToHost, s->stream));
         HIP_CHECK(hipStreamSynchronize(s->stream));
-        *rms = std::sqrt(sum / double(lv.info.nel));
+        *rms = std::sqrt(sum / double(lv.n_owned));          // (a partitioned level: its owned nodes; ghosts are counted by their owners)
     });
 }
 int mgcfd_invalid_state_location(const mgcfd_solver *s, int64_t *cell, int *cycle)
@@ -1340,7 +1341,7 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
             const double nan = std::numeric_limits<double>::quiet_NaN();
             for (int c = 0; c < cycles; c++)
                 rms_out[c] = (c < static_cast<int>(sums.size()) && (failed_cycle < 0 || c < failed_cycle))
-                                 ? std::sqrt(sums[static_cast<size_t>(c)] / double(s->L[0].info.nel)) : nan;
+                                 ? std::sqrt(sums[static_cast<size_t>(c)] / double(s->L[0].n_owned)) : nan;
         }
         HIP_CHECK(hipGetLastError());
     });

@@ -356,6 +356,7 @@ class Solver:
             raise ValueError("stream handle 0 is the legacy default stream; make a torch.cuda.Stream() current "
                              "(torch.cuda.set_stream) and pass its .cuda_stream, or pass None for the solver's own stream")
         self._c(self.lib.mgcfd_set_stream(self.handle, _vp(stream_handle) if stream_handle is not None else None))
+        self._stream_handle = int(stream_handle) if stream_handle is not None else None
 
     def synchronize(self):
         self._c(self.lib.mgcfd_synchronize(self.handle))

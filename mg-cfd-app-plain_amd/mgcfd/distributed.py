@@ -52,6 +52,10 @@ class HipSolverAdapter:
         self.device = device
         self._min = {}
 
+    @property
+    def stream_handle(self):
+        return getattr(self.s, "_stream_handle", None)
+
     def __getattr__(self, name):
         return getattr(self.s, name)
 
@@ -82,6 +86,17 @@ class HipSolverAdapter:
         return DevArrayView(ptr, count).tensor(self.device)
 
 
+def _check_current_stream(solver):
+    """Kernels and collectives are ordered only if torch's CURRENT stream is the one the solver launches on
+    (mgcfd_set_stream); a HIP solver that knows its stream is checked, stand-ins without one are not."""
+    h = getattr(solver, "stream_handle", None)
+    if h is None:
+        return
+    import torch
+    if torch.cuda.is_available() and int(torch.cuda.current_stream().cuda_stream) != int(h):
+        raise RuntimeError("torch's current stream is not the solver's stream: call torch.cuda.set_stream(st) and solver.set_stream(st.cuda_stream) first")
+
+
 class ShardedSweep:
     """Smoothing sweeps on per-rank mesh copies coupled through the global-min time step."""
 
@@ -94,6 +109,8 @@ class ShardedSweep:
         self._staged = os.environ.get("MGCFD_ALLREDUCE_STAGED") == "1"
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.global_time_step = global_time_step      # False for mesh_name = fvcorr (local time step)
+        if self.dist:
+            _check_current_stream(solver)
 
     @property
     def world(self) -> int:
@@ -127,7 +144,15 @@ class ShardedSweep:
                     stage = t.clone()
                     work = self.dist.all_reduce(stage, op=self.dist.ReduceOp.MIN, async_op=True)
                 s.sweep_flux0(level)
-                work.wait()          # stream-level wait: later kernels are ordered after the collective
+                try:
+                    work.wait()      # stream-level wait: later kernels are ordered after the collective
+                except RuntimeError:
+                    # RCCL reports most failures here, not at the call: fall back to a torch-owned copy for good
+                    if stage is not None:
+                        raise
+                    self._staged = True
+                    stage = t.clone()
+                    self.dist.all_reduce(stage, op=self.dist.ReduceOp.MIN)
                 if stage is not None:
                     t.copy_(stage)
             elif self.overlap_even_alone:
@@ -172,6 +197,8 @@ class PartitionedSweep:
         self.allreduce_min_fn = allreduce_min
         self.part = part
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        if self.dist:
+            _check_current_stream(solver)
         self.global_time_step = global_time_step
         self.exchange_fn = exchange or self._exchange_torch
         self.peers = sorted(set(part.send) | set(part.recv))

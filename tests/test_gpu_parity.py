@@ -981,7 +981,7 @@ def _partitioned_level_check(mg, variant, n_parts, partitioner, fused, sweeps=3,
         assert np.array_equal(s.get(0, "residuals")[:P.n_owned].view(np.int64), want_res[own].view(np.int64))
         # ghosts hold the owners' values after the last exchange
         assert np.array_equal(s.get(0, "variables")[P.n_owned:].view(np.int64), want_v[P.global_ids[P.n_owned:]].view(np.int64))
-        sumsq += s.calc_rms(0) ** 2 * s.nel(0)          # library RMS counts owned nodes only, over nel_local
+        sumsq += s.calc_rms(0) ** 2 * P.n_owned         # the library's RMS of a partitioned level is over its owned nodes
         s.close()
     assert abs(np.sqrt(sumsq / L["nel"]) - want_rms) <= 1e-12 * want_rms
 

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <numeric>
 #include <deque>
+#include <limits>
 #include <queue>
 #include <stdexcept>
 #include <string>
@@ -335,6 +336,20 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         // Third key: the number of edges the node evaluates in the half-row plan (decided above: it depends on which
         // nodes share a tile, not on their order inside it), so the lanes of a slice walk equally many half rows.
         const std::vector<int32_t> &cut_count = half_load;
+        // ... and before it: the OTHER tile a node faces (the smallest tile among its outside neighbours; none: last).
+        // A tile gathers its halo by id from the tiles around it, five scattered 8-byte loads per halo node; with a
+        // tile's nodes grouped by the neighbour they face, the ids one neighbour asks for are runs of consecutive
+        // ids — a few 128-byte lines per field instead of one line per node.
+        std::vector<int32_t> facing(static_cast<size_t>(nel), std::numeric_limits<int32_t>::max());
+        if (!std::getenv("MGCFD_NO_FACING_SORT")) {
+            std::vector<int32_t> tile_of(static_cast<size_t>(nel));
+            for (int64_t n = 0; n < nel; n++) tile_of[static_cast<size_t>(order[static_cast<size_t>(n)])] = static_cast<int32_t>(n / kTile);
+            for (int64_t v = 0; v < nel; v++)
+                for (int32_t k = g.ptr[static_cast<size_t>(v)]; k < g.ptr[static_cast<size_t>(v) + 1]; k++) {
+                    const int32_t tw = tile_of[static_cast<size_t>(g.idx[static_cast<size_t>(k)])];
+                    if (tw != tile_of[static_cast<size_t>(v)]) facing[static_cast<size_t>(v)] = std::min(facing[static_cast<size_t>(v)], tw);
+                }
+        }
         const int64_t W = kTile;
         for (int64_t s = 0; s < nel; s += W) {
             auto b = order.begin() + s, e = order.begin() + std::min(nel, s + W);
@@ -342,6 +357,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                 int dx = rows_of(x), dy = rows_of(y);
                 if (dx != dy) return dx > dy;
                 if (bnd_count[static_cast<size_t>(x)] != bnd_count[static_cast<size_t>(y)]) return bnd_count[static_cast<size_t>(x)] > bnd_count[static_cast<size_t>(y)];
+                if (facing[static_cast<size_t>(x)] != facing[static_cast<size_t>(y)]) return facing[static_cast<size_t>(x)] < facing[static_cast<size_t>(y)];
                 return cut_count[static_cast<size_t>(x)] > cut_count[static_cast<size_t>(y)];
             });
         }

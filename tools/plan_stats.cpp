@@ -20,6 +20,18 @@ int main(int argc, char **argv)
                 (long)P.halo_overflow_refs, int(P.has_tail), int(P.edge_once));
     std::printf("half %d evaluations %ld (%.2f per node) foreign %ld padding %ld (%.1f %%)\n", int(P.half), (long)P.hr_entries, double(P.hr_entries) / d.nel,
                 (long)P.hr_foreign, (long)P.hr_padding, P.hr_entries ? 100.0 * P.hr_padding / P.hr_entries : 0.0);
+    {   // how scattered the halo gathers are: distinct 128-byte blocks (16 consecutive ids) per tile, per field
+        int64_t blocks = 0, nodes = 0;
+        for (int32_t t = 0; t < P.n_tiles; t++) {
+            int32_t last = -1;
+            for (int32_t k = P.tile_halo_ptr[t]; k < P.tile_halo_ptr[t + 1]; k++) {
+                const int32_t b = P.tile_halo[k] / 16;
+                if (b != last) { blocks++; last = b; }
+                nodes++;
+            }
+        }
+        std::printf("halo gathers: %.1f nodes per tile in %.1f blocks of 16 ids (%.2f nodes per block)\n", double(nodes) / P.n_tiles, double(blocks) / P.n_tiles, double(nodes) / blocks);
+    }
     if (!P.hr_row0.empty()) {
         int hist[16] = {0};
         for (size_t s = 0; s + 1 < P.hr_row0.size(); s++) hist[std::min(15, P.hr_row0[s + 1] - P.hr_row0[s])]++;

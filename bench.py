@@ -257,6 +257,8 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="MGCFD_OPT_FLUX_VARIANT (see include/mgcfd.h)")
     ap.add_argument("--exchange", default="library", choices=["library", "torch"],
                     help="partitioned workload: who runs the sweep loop and the halo exchange (the library over RCCL, or torch.distributed from Python)")
+    ap.add_argument("--rank-graphs", action="store_true",
+                    help="partitioned workload, library exchange: replay every rank's sweep from a captured hipGraph (MGCFD_OPT_GRAPH)")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle leg (a rocprofv3 summary of the command then holds only the timed workload's launches)")
     ap.add_argument("--vcycle", action="store_true", help="(default now; kept so older command lines still parse)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (0 disables)")
@@ -377,6 +379,7 @@ def main():
                 dist.broadcast_object_list(uid, src=0)
                 solver.rank_attach_rccl(rank, world, uid[0])
                 solver.rank_set_halo(0, P)
+                solver.set_option("graph", 1 if args.rank_graphs else 0)
                 sw.sweep()
                 torch.cuda.synchronize()
                 want = solver.get(0, "variables")
@@ -392,7 +395,8 @@ def main():
                 step = lambda: solver.rank_sweeps(0, 1)
                 info = solver.rank_halo_info(0)
                 exchange = (f"libmgcfd_hip (mgcfd_rank_sweeps): RCCL ncclSend/ncclRecv grouped on a second stream under the interior tiles; "
-                            f"rank 0: {info['boundary_tiles']} boundary + {info['interior_tiles']} interior tiles; checked against the torch path at start-up")
+                            f"rank 0: {info['boundary_tiles']} boundary + {info['interior_tiles']} interior tiles; checked against the torch path at start-up"
+                            + ("; sweeps replayed from hipGraphs" if args.rank_graphs else ""))
             except Exception as e:                       # the torch path stands
                 if rank == 0:
                     print(f"bench.py: library exchange not used: {e}", file=sys.stderr)

@@ -1638,6 +1638,17 @@ k_accept_restricted(int64_t nel_coarse, int64_t stride_coarse, const int32_t *__
     for (int f = 0; f < 5; f++) coarse_q[f * stride_coarse + c] = src[f * stride_coarse + c];
 }
 
+// In-process groups (several solvers of one process, peer access between their devices): the all-reduce(MIN) of the
+// time step is every rank reading the others' scalars directly (8-byte loads over xGMI) behind their events.
+__global__ void k_min_over_peers(const double *const *__restrict__ scalars, int n, double *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double m = scalars[0][0];
+        for (int r = 1; r < n; r++) m = fmin(m, scalars[r][0]);
+        out[0] = m;
+    }
+}
+
 // rms history: append a device scalar to a ring (lets a whole multigrid cycle live in one hipGraph)
 __global__ void k_append_scalar(const double *__restrict__ src, double *__restrict__ ring, int *__restrict__ count, int cap)
 {
@@ -2045,6 +2056,9 @@ void launch_halo_unpack(hipStream_t st, int64_t n, int64_t stride, const int32_t
 
 void launch_accept_restricted(hipStream_t st, int64_t nel_coarse, int64_t stride_coarse, const int32_t *child_ptr, const double *src, double *coarse_q)
 { hipLaunchKernelGGL(k_accept_restricted, dim3(grid_for(nel_coarse)), dim3(kBlock), 0, st, nel_coarse, stride_coarse, child_ptr, src, coarse_q); }
+
+void launch_min_over_peers(hipStream_t st, const double *const *scalars, int n, double *out)
+{ hipLaunchKernelGGL(k_min_over_peers, dim3(1), dim3(64), 0, st, scalars, n, out); }
 
 void launch_sum_partials_append(hipStream_t st, int n, const double *partial, double *out, double *ring, int *count, int cap)
 { hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, SumTask{partial, n, out, ring, count, cap}); }

@@ -31,6 +31,7 @@
     void launch_halo_unpack(hipStream_t, int64_t n, int64_t stride, const int32_t *idx, const double *msg,           \
                             double *field);                                                                          \
     void launch_append_scalar(hipStream_t, const double *src, double *ring, int *count, int cap);                    \
+    void launch_min_over_peers(hipStream_t, const double *const *scalars, int n, double *out);                       \
     void launch_accept_restricted(hipStream_t, int64_t nel_coarse, int64_t stride_coarse, const int32_t *child_ptr,  \
                                   const double *src, double *coarse_q);                                              \
     void launch_sum_partials_append(hipStream_t, int n, const double *partial, double *out, double *ring,            \

@@ -56,21 +56,27 @@ template <typename T> static T *dev_upload(const std::vector<T> &v)
 struct EventPair { hipEvent_t start, stop; int level, loop; bool is_flux_internal; int launches; };
 
 // The halo exchange of one partitioned level as the C++ host runs it (mgcfd_rank_* / mgcfd_group_*): ONE packed message
-// per exchange holding every peer's segment (one pack and one unpack launch whatever the number of peers), double
-// buffered by exchange parity, and the level's tiles split into those next to ghost nodes ("boundary": they read ghosts,
-// and every node a peer needs lies in one of them) and the rest ("interior"), which run while the message travels.
+// per exchange holding every peer's segment (one pack and one unpack launch whatever the number of peers), one buffer
+// set per Runge-Kutta stage (a set is reused a whole sweep later), and the level's tiles split into those next to ghost
+// nodes ("boundary": they read ghosts, and every node a peer needs lies in one of them) and the rest ("interior"),
+// which run while the message travels.
 struct HaloExchange {
+    static constexpr int kSets = 3;
     std::vector<int> peer;                               // neighbouring ranks, ascending
     std::vector<int64_t> send_off, recv_off;             // [n_peers+1] node offsets of the peers' segments
     int32_t *send_idx = nullptr, *recv_idx = nullptr;    // device: library node ids, all peers concatenated
-    double *send_buf[2] = {nullptr, nullptr}, *recv_buf[2] = {nullptr, nullptr};   // device: [nodes][5]
+    double *send_buf[kSets] = {nullptr, nullptr, nullptr}, *recv_buf[kSets] = {nullptr, nullptr, nullptr};   // device: [nodes][5]
     int32_t *tiles_boundary = nullptr, *tiles_interior = nullptr;
     int32_t n_boundary = 0, n_interior = 0;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t packed[2] = {nullptr, nullptr}, arrived[2] = {nullptr, nullptr};
-    int parity = 0;                                      // buffer set of the NEXT exchange
-    bool in_flight = false;                              // an exchange has been started and not yet unpacked
-    double *gmin = nullptr;                              // device [world]: every rank's minimum time step (in-process groups)
+    hipEvent_t packed[kSets] = {nullptr, nullptr, nullptr}, arrived[kSets] = {nullptr, nullptr, nullptr};
+    hipEvent_t reduced = nullptr, gathered = nullptr, joined = nullptr;   // the in-process all-reduce of the time step; graph capture joins
+    double *gmin = nullptr;                              // device [world]: [0] = the group's minimum time step (in-process groups)
+    const double **peer_scalars = nullptr;               // device [world]: where every rank of the group keeps its minimum
+    // the sweep as a captured graph per buffer rotation (one host call per sweep instead of ~25): RCCL ranks
+    hipGraphExec_t sweep_graph[3] = {nullptr, nullptr, nullptr};
+    int64_t graph_iters[3][MGCFD_NUM_LOOPS] = {{0}};
+    bool graph_failed = false;
     int64_t total_send() const { return send_off.empty() ? 0 : send_off.back(); }
     int64_t total_recv() const { return recv_off.empty() ? 0 : recv_off.back(); }
 };
@@ -450,9 +456,16 @@ mgcfd_solver::~mgcfd_solver()
         for (auto &hp : lv.halo_plans) if (hp.first) (void)hipFree(hp.first);
         if (lv.hx) {
             HaloExchange &hx = *lv.hx;
-            void *hp[] = {hx.send_idx, hx.recv_idx, hx.send_buf[0], hx.send_buf[1], hx.recv_buf[0], hx.recv_buf[1], hx.tiles_boundary, hx.tiles_interior, hx.gmin};
+            void *hp[] = {hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.gmin, hx.peer_scalars};
             for (void *p : hp) if (p) (void)hipFree(p);
-            for (int b = 0; b < 2; b++) { if (hx.packed[b]) (void)hipEventDestroy(hx.packed[b]); if (hx.arrived[b]) (void)hipEventDestroy(hx.arrived[b]); }
+            for (int b = 0; b < HaloExchange::kSets; b++) {
+                if (hx.send_buf[b]) (void)hipFree(hx.send_buf[b]);
+                if (hx.recv_buf[b]) (void)hipFree(hx.recv_buf[b]);
+                if (hx.packed[b]) (void)hipEventDestroy(hx.packed[b]);
+                if (hx.arrived[b]) (void)hipEventDestroy(hx.arrived[b]);
+                if (hx.sweep_graph[b]) (void)hipGraphExecDestroy(hx.sweep_graph[b]);
+            }
+            for (hipEvent_t e : {hx.reduced, hx.gathered, hx.joined}) if (e) (void)hipEventDestroy(e);
             if (hx.comm_stream) (void)hipStreamDestroy(hx.comm_stream);
         }
     }
@@ -1701,12 +1714,15 @@ static void build_halo(mgcfd_solver *s, int level, int n_peers, const int *peers
     }
     hx->send_idx = dev_upload(sidx);
     hx->recv_idx = dev_upload(ridx);
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < HaloExchange::kSets; b++) {
         hx->send_buf[b] = dev_alloc<double>(sidx.size() * 5);
         hx->recv_buf[b] = dev_alloc<double>(ridx.size() * 5);
         HIP_CHECK(hipEventCreateWithFlags(&hx->packed[b], hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&hx->arrived[b], hipEventDisableTiming));
     }
+    HIP_CHECK(hipEventCreateWithFlags(&hx->reduced, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&hx->gathered, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&hx->joined, hipEventDisableTiming));
     HIP_CHECK(hipStreamCreateWithFlags(&hx->comm_stream, hipStreamNonBlocking));
     hx->gmin = dev_alloc<double>(static_cast<size_t>(std::max(world, 1)));
     // tiles next to ghosts: a tile that holds a ghost node, or an owned node with an edge to one
@@ -1726,13 +1742,12 @@ static void build_halo(mgcfd_solver *s, int level, int n_peers, const int *peers
     lv.hx = std::move(hx);
 }
 
-// the message of the state `field` (the buffer a stage just wrote, or `variables`): pack, start the transfer
-static void halo_start(mgcfd_solver *s, int level, const double *field)
+// the message of the state `field` (the buffer a stage just wrote, or `variables`) in buffer set b: pack, start the transfer
+static void halo_start(mgcfd_solver *s, int level, const double *field, int b)
 {
     DeviceLevel &lv = s->level(level);
     HaloExchange &hx = *lv.hx;
     mgcfd_comm &c = comm_of(s);
-    const int b = hx.parity;
     if (hx.total_send() > 0)
         exact::launch_halo_pack(s->stream, hx.total_send(), lv.dp.stride, hx.send_idx, field, hx.send_buf[b]);
     HIP_CHECK(hipEventRecord(hx.packed[b], s->stream));
@@ -1748,19 +1763,18 @@ static void halo_start(mgcfd_solver *s, int level, const double *field)
         HIP_CHECK(hipEventRecord(hx.arrived[b], hx.comm_stream));
     }
     // (in-process group: the copies are issued by group_deliver once every rank has packed)
-    hx.in_flight = true;
 }
 
 // in-process group: every rank's segments copied into its peers' receive buffers (device to device, over xGMI between
 // devices), each destination's copies on its own comm stream behind the sources' pack events
-static void group_deliver(mgcfd_group *g, int level)
+static void group_deliver(mgcfd_group *g, int level, int b)
 {
     for (mgcfd_solver *dst : g->ranks) {
         dst->use_device();
         DeviceLevel &ld = dst->level(level);
         HaloExchange &hd = *ld.hx;
-        const int b = hd.parity;
         const int me = comm_of(dst).rank;
+        bool any = false;
         for (size_t k = 0; k < hd.peer.size(); k++) {
             mgcfd_solver *src = g->ranks[static_cast<size_t>(hd.peer[k])];
             HaloExchange &hs = *src->level(level).hx;
@@ -1771,29 +1785,29 @@ static void group_deliver(mgcfd_group *g, int level)
             if (n != hs.send_off[ks + 1] - hs.send_off[ks]) throw std::logic_error("halo message lengths of two ranks do not match");
             if (n == 0) continue;
             HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, hs.packed[b], 0));
-            HIP_CHECK(hipMemcpyPeerAsync(hd.recv_buf[b] + hd.recv_off[k] * 5, dst->device, hs.send_buf[b] + hs.send_off[ks] * 5, src->device,
-                                         sizeof(double) * 5 * static_cast<size_t>(n), hd.comm_stream));
+            // (unified addressing + peer access: a plain device-to-device copy crosses xGMI; unlike hipMemcpyPeerAsync it can be captured)
+            HIP_CHECK(hipMemcpyAsync(hd.recv_buf[b] + hd.recv_off[k] * 5, hs.send_buf[b] + hs.send_off[ks] * 5,
+                                     sizeof(double) * 5 * static_cast<size_t>(n), hipMemcpyDeviceToDevice, hd.comm_stream));
+            any = true;
         }
+        if (!any) HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, hd.packed[b], 0));     // (keeps the comm stream behind the rank's own stream)
         HIP_CHECK(hipEventRecord(hd.arrived[b], hd.comm_stream));
     }
 }
 
-// wait for the message in flight and write it into the ghosts of `field`
-static void halo_finish(mgcfd_solver *s, int level, double *field)
+// wait for the message of buffer set b and write it into the ghosts of `field`
+static void halo_finish(mgcfd_solver *s, int level, double *field, int b)
 {
     DeviceLevel &lv = s->level(level);
     HaloExchange &hx = *lv.hx;
-    if (!hx.in_flight) return;
-    const int b = hx.parity;
     HIP_CHECK(hipStreamWaitEvent(s->stream, hx.arrived[b], 0));
     if (hx.total_recv() > 0)
         exact::launch_halo_unpack(s->stream, hx.total_recv(), lv.dp.stride, hx.recv_idx, hx.recv_buf[b], field);
-    hx.parity ^= 1;
-    hx.in_flight = false;
 }
 
-// One stage of a partitioned sweep on one rank, part 1: the ghosts of the stage's input arrive, the boundary tiles run,
-// their results are packed and sent.  Part 2 (stage_interior) runs the other tiles while the message travels.
+// One stage of a partitioned sweep on one rank, part 1: the ghosts of the stage's input arrive (the previous stage's
+// message), the boundary tiles run, their results are packed and sent.  Part 2 (stage_interior) runs the other tiles
+// while the message travels.
 static void stage_boundary(mgcfd_solver *s, int level, int j, int apply_min, const double *min_list, int n_min)
 {
     DeviceLevel &lv = s->level(level);
@@ -1801,7 +1815,7 @@ static void stage_boundary(mgcfd_solver *s, int level, int j, int apply_min, con
     double *const start = lv.q, *const b1 = lv.q_alt, *const b2 = lv.old_variables;
     double *in = j == 0 ? start : (j == 1 ? b1 : b2);
     double *out = j == 0 ? b1 : (j == 1 ? b2 : b1);
-    halo_finish(s, level, in);                              // (stage 0: the previous sweep's last message, into `variables`)
+    if (j > 0) halo_finish(s, level, in, j - 1);
     if (j == 0) {
         if (!lv.fluxes_zero) throw std::invalid_argument("a partitioned sweep needs zero fluxes (as after time_step)");
         s->settle_fluxes(lv);
@@ -1809,7 +1823,7 @@ static void stage_boundary(mgcfd_solver *s, int level, int j, int apply_min, con
     s->force_check = s->next_check();                       // both parts of the stage are one time_step for check_for_invalid_variables
     s->op_fused_stage(level, j, in, out, j == 0 ? apply_min : 0, j == 2, start, false, false, nullptr, hx.tiles_boundary, hx.n_boundary, true, min_list, n_min);
     lv.stage_out = out;
-    halo_start(s, level, out);
+    halo_start(s, level, out, j);
 }
 static void stage_interior(mgcfd_solver *s, int level, int j, int apply_min, const double *min_list, int n_min)
 {
@@ -1833,11 +1847,84 @@ static void sweep_first_half(mgcfd_solver *s, int level)
     DeviceLevel &lv = s->level(level);
     if (!lv.hx) throw std::invalid_argument("the level has no halo lists: call mgcfd_rank_set_halo first");
     if (lv.stage_next != 0) throw std::invalid_argument("a sweep is under way (mgcfd_sweep_stage)");
-    // the previous sweep's last message must be in the ghosts before compute_step_factor reads `variables`
-    halo_finish(s, level, lv.q);
     const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
     s->op_step_factor(level, true, false);                  // first half of compute_step_factor (owned and ghost nodes alike: the ghosts' values are the owners')
     if (global_dt) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
+}
+
+// one sweep of an RCCL rank, as issued (and as captured): every exchange it starts it also finishes
+static void rank_sweep_once(mgcfd_solver *s, int level)
+{
+    mgcfd_comm &c = comm_of(s);
+    DeviceLevel &lv = s->level(level);
+    const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
+    sweep_first_half(s, level);
+    if (global_dt) RCCL_CHECK(g_rccl.AllReduce(lv.min_dt, lv.min_dt, 1, Rccl::kDouble, Rccl::kMin, c.rccl, s->stream));
+    for (int j = 0; j < MGCFD_RK; j++) {
+        stage_boundary(s, level, j, global_dt ? 2 : 0, nullptr, 0);
+        stage_interior(s, level, j, global_dt ? 2 : 0, nullptr, 0);
+    }
+    halo_finish(s, level, lv.q, MGCFD_RK - 1);              // the ghosts of `variables` are current when the sweep ends
+}
+
+// one sweep of every rank of an in-process group
+#define TRACE(msg) do { if (std::getenv("MGCFD_TRACE")) { std::fprintf(stderr, "[trace] %s\n", msg); std::fflush(stderr); } } while (0)
+static void group_sweep_once(mgcfd_group *g, int level)
+{
+    const int n = static_cast<int>(g->ranks.size());
+    TRACE("sweep: first halves");
+    const bool global_dt = g->ranks[0]->mesh_variant != MGCFD_MESH_FVCORR;
+    for (mgcfd_solver *s : g->ranks) { s->use_device(); sweep_first_half(s, level); }
+    if (global_dt) {
+        // all-reduce(MIN) of one fp64 over the group: behind every rank's reduction event each rank reads the others'
+        // scalars itself (k_min_over_peers: 8-byte loads over xGMI) — no message, no second stream
+        for (mgcfd_solver *src : g->ranks) { src->use_device(); HIP_CHECK(hipEventRecord(src->level(level).hx->reduced, src->stream)); }
+        for (mgcfd_solver *dst : g->ranks) {
+            dst->use_device();
+            HaloExchange &hd = *dst->level(level).hx;
+            for (mgcfd_solver *src : g->ranks) if (src != dst) HIP_CHECK(hipStreamWaitEvent(dst->stream, src->level(level).hx->reduced, 0));
+            exact::launch_min_over_peers(dst->stream, hd.peer_scalars, n, hd.gmin);
+        }
+    }
+    for (int j = 0; j < MGCFD_RK; j++) {
+        TRACE("sweep: stage boundary");
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); stage_boundary(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1); }
+        TRACE("sweep: deliver");
+        group_deliver(g, level, j);
+        TRACE("sweep: interior");
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); stage_interior(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1); }
+    }
+    TRACE("sweep: last unpack");
+    for (mgcfd_solver *s : g->ranks) { s->use_device(); halo_finish(s, level, s->level(level).q, MGCFD_RK - 1); }
+    TRACE("sweep: issued");
+}
+
+// The sweep as a hipGraph: the ~25 host calls a rank's sweep takes (launches, event records and waits, copies or RCCL
+// calls) cost more host time than the kernels take on the GPU; captured once per buffer rotation (the launch arguments
+// repeat with period 3) a sweep is ONE host call.  `body` issues the sweep; `streams` beyond the first are forked
+// from and joined to the capturing stream.  Returns false (and leaves everything eager) when capture is not possible.
+template <typename Body>
+static bool capture_sweep(hipStream_t origin, const std::vector<std::pair<hipStream_t, hipEvent_t>> &others, hipEvent_t fork, Body &&body,
+                          hipGraphExec_t *exec)
+{
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(origin, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return false; }
+    bool ok = true;
+    try {
+        HIP_CHECK(hipEventRecord(fork, origin));
+        for (auto &o : others) HIP_CHECK(hipStreamWaitEvent(o.first, fork, 0));
+        body();
+        for (auto &o : others) { HIP_CHECK(hipEventRecord(o.second, o.first)); HIP_CHECK(hipStreamWaitEvent(origin, o.second, 0)); }
+    } catch (...) {
+        ok = false;
+    }
+    TRACE("capture: end");
+    if (hipStreamEndCapture(origin, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); ok = false; }
+    TRACE(ok ? "capture: instantiate" : "capture: FAILED");
+    if (ok && hipGraphInstantiate(exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); *exec = nullptr; ok = false; }
+    TRACE(ok ? "capture: ready" : "capture: not instantiated");
+    if (graph) (void)hipGraphDestroy(graph);
+    return ok;
 }
 
 extern "C" {
@@ -1883,6 +1970,25 @@ int mgcfd_rank_set_halo(mgcfd_solver *s, int level, int n_peers, const int *peer
     return guarded([&] { build_halo(s, level, n_peers, peers, send_counts, send_ids, recv_counts, recv_ids, comm_of(s).world); });
 }
 
+// what a replayed sweep leaves behind on the host side (the captured launches carry their arguments; the flags and
+// counters the eager path updates as it goes are advanced here)
+static void after_replayed_sweep(mgcfd_solver *s, int level, const int64_t *iters_delta)
+{
+    DeviceLevel &lv = s->level(level);
+    lv.rot = (lv.rot + 1) % 3;
+    lv.apply_rot();
+    lv.stage_out = lv.q;
+    lv.min_ahead = false;
+    for (int k = 0; k < MGCFD_NUM_LOOPS; k++) lv.iters[k] += iters_delta[k];
+}
+
+// (MGCFD_SWEEP_GRAPH=0 switches every captured partitioned sweep off, whatever the solvers' MGCFD_OPT_GRAPH says)
+static bool sweep_graphs_enabled()
+{
+    static const bool on = !(std::getenv("MGCFD_SWEEP_GRAPH") && std::atoi(std::getenv("MGCFD_SWEEP_GRAPH")) == 0);
+    return on;
+}
+
 // Bring the ghosts of `variables` up to date (after mgcfd_set_array, before the first sweep).  In an in-process group
 // call mgcfd_group_exchange instead.
 int mgcfd_rank_exchange(mgcfd_solver *s, int level)
@@ -1891,9 +1997,8 @@ int mgcfd_rank_exchange(mgcfd_solver *s, int level)
         if (!comm_of(s).rccl) throw std::invalid_argument("in-process ranks exchange through mgcfd_group_exchange");
         DeviceLevel &lv = s->level(level);
         if (!lv.hx) throw std::invalid_argument("the level has no halo lists");
-        halo_finish(s, level, lv.q);
-        halo_start(s, level, lv.q);
-        halo_finish(s, level, lv.q);
+        halo_start(s, level, lv.q, 0);
+        halo_finish(s, level, lv.q, 0);
         lv.min_ahead = false;
     });
 }
@@ -1904,16 +2009,37 @@ int mgcfd_rank_sweeps(mgcfd_solver *s, int level, int sweeps)
         mgcfd_comm &c = comm_of(s);
         if (!c.rccl) throw std::invalid_argument("in-process ranks sweep through mgcfd_group_sweeps");
         DeviceLevel &lv = s->level(level);
-        const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
+        if (!lv.hx) throw std::invalid_argument("the level has no halo lists: call mgcfd_rank_set_halo first");
+        HaloExchange &hx = *lv.hx;
+        s->settle_fluxes(lv);                               // (outside any capture: a lazy zero is not part of a sweep)
         for (int k = 0; k < sweeps; k++) {
-            sweep_first_half(s, level);
-            if (global_dt) RCCL_CHECK(g_rccl.AllReduce(lv.min_dt, lv.min_dt, 1, Rccl::kDouble, Rccl::kMin, c.rccl, s->stream));
-            for (int j = 0; j < MGCFD_RK; j++) {
-                stage_boundary(s, level, j, global_dt ? 2 : 0, nullptr, 0);
-                stage_interior(s, level, j, global_dt ? 2 : 0, nullptr, 0);
+            const int rot = lv.rot % 3;
+            // MGCFD_OPT_GRAPH = 1: the sweep replayed from a hipGraph (measured with the one rank a one-GPU box offers: 76 us
+            // per sweep against 129 us issued call by call; ncclSend/ncclRecv inside a capture could not be rehearsed
+            // there, hence opt-in)
+            if (s->opt_graph && sweep_graphs_enabled() && !hx.graph_failed && s->opt_timing == 0) {
+                if (!hx.sweep_graph[rot]) {
+                    int64_t before[MGCFD_NUM_LOOPS];
+                    std::memcpy(before, lv.iters, sizeof(before));
+                    const int rot_before = lv.rot;
+                    const bool ok = capture_sweep(s->stream, {}, hx.joined, [&] { rank_sweep_once(s, level); }, &hx.sweep_graph[rot]);
+                    s->force_check = -1;
+                    if (!ok) {                              // nothing ran: put the host state back and go on eagerly
+                        hx.graph_failed = true;
+                        lv.rot = rot_before; lv.apply_rot();
+                        std::memcpy(lv.iters, before, sizeof(before));
+                        rank_sweep_once(s, level);
+                        continue;
+                    }
+                    for (int q = 0; q < MGCFD_NUM_LOOPS; q++) { hx.graph_iters[rot][q] = lv.iters[q] - before[q]; lv.iters[q] = before[q]; }
+                    lv.rot = rot_before; lv.apply_rot();    // (the capture advanced the host state without running anything)
+                }
+                HIP_CHECK(hipGraphLaunch(hx.sweep_graph[rot], s->stream));
+                after_replayed_sweep(s, level, hx.graph_iters[rot]);
+            } else {
+                rank_sweep_once(s, level);
             }
         }
-        halo_finish(s, level, lv.q);                        // the ghosts of `variables` are current when the call returns
     });
 }
 
@@ -1973,10 +2099,9 @@ int mgcfd_group_exchange(mgcfd_group *g, int level)
 {
     REQUIRE(g);
     return guarded([&] {
-        for (mgcfd_solver *s : g->ranks) { s->use_device(); DeviceLevel &lv = s->level(level); if (!lv.hx) throw std::invalid_argument("a rank has no halo lists"); halo_finish(s, level, lv.q); }
-        for (mgcfd_solver *s : g->ranks) { s->use_device(); halo_start(s, level, s->level(level).q); }
-        group_deliver(g, level);
-        for (mgcfd_solver *s : g->ranks) { s->use_device(); DeviceLevel &lv = s->level(level); halo_finish(s, level, lv.q); lv.min_ahead = false; }
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); DeviceLevel &lv = s->level(level); if (!lv.hx) throw std::invalid_argument("a rank has no halo lists"); halo_start(s, level, lv.q, 0); }
+        group_deliver(g, level, 0);
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); DeviceLevel &lv = s->level(level); halo_finish(s, level, lv.q, 0); lv.min_ahead = false; }
     });
 }
 
@@ -1984,34 +2109,78 @@ int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps)
 {
     REQUIRE(g);
     return guarded([&] {
-        const int n = static_cast<int>(g->ranks.size());
-        const bool global_dt = g->ranks[0]->mesh_variant != MGCFD_MESH_FVCORR;
-        for (int k = 0; k < sweeps; k++) {
-            for (mgcfd_solver *s : g->ranks) { s->use_device(); sweep_first_half(s, level); }
-            if (global_dt) {
-                // all-reduce(MIN) of one fp64 over the group: every rank's minimum lands in slot r of every rank's list
-                // (8-byte peer copies on the destinations' comm streams); the first stage takes the minimum over the list
-                for (mgcfd_solver *src : g->ranks) { src->use_device(); HaloExchange &hs = *src->level(level).hx; HIP_CHECK(hipEventRecord(hs.packed[hs.parity], src->stream)); }
-                for (mgcfd_solver *dst : g->ranks) {
-                    dst->use_device();
-                    HaloExchange &hd = *dst->level(level).hx;
-                    for (int r = 0; r < n; r++) {
-                        mgcfd_solver *src = g->ranks[static_cast<size_t>(r)];
-                        HaloExchange &hs = *src->level(level).hx;
-                        HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, hs.packed[hs.parity], 0));
-                        HIP_CHECK(hipMemcpyPeerAsync(hd.gmin + r, dst->device, src->level(level).min_dt, src->device, sizeof(double), hd.comm_stream));
-                    }
-                    HIP_CHECK(hipEventRecord(hd.arrived[hd.parity], hd.comm_stream));
-                    HIP_CHECK(hipStreamWaitEvent(dst->stream, hd.arrived[hd.parity], 0));
-                }
-            }
-            for (int j = 0; j < MGCFD_RK; j++) {
-                for (mgcfd_solver *s : g->ranks) { s->use_device(); stage_boundary(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, n); }
-                group_deliver(g, level);
-                for (mgcfd_solver *s : g->ranks) { s->use_device(); stage_interior(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, n); }
+        mgcfd_solver *s0 = g->ranks[0];
+        for (mgcfd_solver *s : g->ranks) {
+            s->use_device();
+            DeviceLevel &lv = s->level(level);
+            if (!lv.hx) throw std::invalid_argument("a rank has no halo lists: call mgcfd_rank_set_halo first");
+            s->settle_fluxes(lv);
+        }
+        for (mgcfd_solver *s : g->ranks) {                  // (allocations and uploads: never inside a capture)
+            HaloExchange &hx = *s->level(level).hx;
+            if (hx.peer_scalars) continue;
+            s->use_device();
+            std::vector<const double *> ptrs;
+            for (mgcfd_solver *src : g->ranks) ptrs.push_back(src->level(level).min_dt);
+            hx.peer_scalars = dev_upload(ptrs);
+        }
+        HaloExchange &h0 = *s0->level(level).hx;
+        bool timing = false;
+        for (mgcfd_solver *s : g->ranks) timing = timing || s->opt_timing != 0;
+        // One graph over all ranks' streams replays SLOWER than the eager calls on ROCm 7.2 (2 ranks: 301 against 262 us per
+        // sweep; launching a graph of ~40 nodes on 4 streams costs the host 150 us), so groups capture only on request
+        // (MGCFD_GROUP_GRAPH=1); a single rank's two-stream sweep does gain (mgcfd_rank_sweeps: 76 against 129 us).
+        static const bool group_graphs = std::getenv("MGCFD_GROUP_GRAPH") && std::atoi(std::getenv("MGCFD_GROUP_GRAPH")) != 0;
+        const bool graphs = group_graphs && sweep_graphs_enabled() && !timing;
+        if (graphs) {
+            // a replayed graph is launched on rank 0's stream: it must start behind whatever the other ranks' streams hold
+            for (mgcfd_solver *s : g->ranks) {
+                if (s == s0) continue;
+                s->use_device();
+                HIP_CHECK(hipEventRecord(s->level(level).hx->joined, s->stream));
+                HIP_CHECK(hipStreamWaitEvent(s0->stream, s->level(level).hx->joined, 0));
             }
         }
-        for (mgcfd_solver *s : g->ranks) { s->use_device(); halo_finish(s, level, s->level(level).q); }
+        bool replayed = false;
+        for (int k = 0; k < sweeps; k++) {
+            const int rot = s0->level(level).rot % 3;
+            if (graphs && !h0.graph_failed) {
+                if (!h0.sweep_graph[rot]) {
+                    // every rank's sweep in ONE graph: the other ranks' streams fork from rank 0's and join it at the end
+                    std::vector<std::vector<int64_t>> before;
+                    std::vector<int> rot_before;
+                    std::vector<std::pair<hipStream_t, hipEvent_t>> others;
+                    for (mgcfd_solver *s : g->ranks) {
+                        DeviceLevel &lv = s->level(level);
+                        before.emplace_back(lv.iters, lv.iters + MGCFD_NUM_LOOPS);
+                        rot_before.push_back(lv.rot);
+                        if (s != s0) others.emplace_back(s->stream, lv.hx->joined);
+                    }
+                    s0->use_device();
+                    const bool ok = capture_sweep(s0->stream, others, h0.joined, [&] { group_sweep_once(g, level); }, &h0.sweep_graph[rot]);
+                    for (size_t r = 0; r < g->ranks.size(); r++) {
+                        mgcfd_solver *s = g->ranks[r];
+                        DeviceLevel &lv = s->level(level);
+                        s->force_check = -1;
+                        for (int q = 0; q < MGCFD_NUM_LOOPS; q++) { lv.hx->graph_iters[rot][q] = lv.iters[q] - before[r][static_cast<size_t>(q)]; lv.iters[q] = before[r][static_cast<size_t>(q)]; }
+                        lv.rot = rot_before[r]; lv.apply_rot();
+                    }
+                    if (!ok) { h0.graph_failed = true; group_sweep_once(g, level); continue; }
+                }
+                s0->use_device();
+                HIP_CHECK(hipGraphLaunch(h0.sweep_graph[rot], s0->stream));
+                replayed = true;
+                for (mgcfd_solver *s : g->ranks) after_replayed_sweep(s, level, s->level(level).hx->graph_iters[rot]);
+            } else {
+                group_sweep_once(g, level);
+            }
+        }
+        if (replayed) {
+            // ... and what the other ranks' streams are given next must wait for the graphs
+            s0->use_device();
+            HIP_CHECK(hipEventRecord(h0.joined, s0->stream));
+            for (mgcfd_solver *s : g->ranks) if (s != s0) { s->use_device(); HIP_CHECK(hipStreamWaitEvent(s->stream, h0.joined, 0)); }
+        }
     });
 }
 

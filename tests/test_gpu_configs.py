@@ -405,5 +405,16 @@ def test_rccl_loads_and_a_one_rank_communicator_sweeps():
     s.rank_sweeps(0, 3)
     _bits_equal(s.get(0, "variables"), want, "one-rank RCCL sweeps")
     assert s.rank_residual_sumsq(0) > 0
+    # ... and replayed from captured hipGraphs (MGCFD_OPT_GRAPH): seven sweeps pass through all three buffer rotations twice
+    ref = mgcfd.Solver.from_arrays([L], mg.mesh_variant)
+    ref.set(0, "variables", q0)
+    ref.smooth(0, 7)
+    s.set(0, "variables", q0[P.global_ids])
+    s.set_option("graph", 1)
+    s.rank_exchange(0)
+    s.rank_sweeps(0, 7)
+    _bits_equal(s.get(0, "variables"), ref.get(0, "variables"), "one-rank RCCL sweeps replayed from hipGraphs")
+    assert s.loop_iters(0)["flux"] == ref.loop_iters(0)["flux"] + 3 * 3 * L["n_internal"]
+    ref.close()
     s.rank_detach()
     s.close()

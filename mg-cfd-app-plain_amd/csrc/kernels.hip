@@ -1922,9 +1922,11 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     const dim3 grid(part ? fs.n_list : p.n_tiles);
     if (part && fs.n_list <= 0) return;
 
-    // 3 tiles of 52.5 KiB LDS fit a CU => at least 3 waves per SIMD wanted
+    // 3 tiles of 52.5 KiB LDS fit a CU => at least 3 waves per SIMD wanted (168 registers).  The two long-row instantiations that
+    // do not fit them — the kernel-granular '+=' launch and the split sweep's absorbed first stage, both off the sweep path —
+    // are built for 2 waves per SIMD instead of spilling 20-36 bytes per lane.
 #define MGCFD_TILE_LAUNCH_T(WMODE, FUSE, ACC, ROLE, TAIL)                                                      \
-    hipLaunchKernelGGL((k_flux_tile<3, WMODE, FUSE, ACC, ROLE, TAIL>), grid, block, 0, st, q, p.tile_halo,     \
+    hipLaunchKernelGGL((k_flux_tile<((TAIL) && ((ACC) || (ROLE) == 5)) ? 2 : 3, WMODE, FUSE, ACC, ROLE, TAIL>), grid, block, 0, st, q, p.tile_halo,     \
                        uint32_t(grid.x), p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.rows_bnd,  \
                        p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs, p.tail, p.gat16,     \
                        p.te_chunk_ptr, p.te_w3)

@@ -318,14 +318,14 @@ def test_bench_rehearsal_two_ranks_on_this_gpu():
         assert line["value"] > 0
 
 
-def _group_sweeps_check(mg, n_parts, sweeps, oracle_state=None):
+def _group_sweeps_check(mg, n_parts, sweeps, partitioner="rcb"):
     """Level 0 of `mg` split into n_parts solvers, the sweeps run by the LIBRARY's own loop (mgcfd_group_sweeps: boundary
     tiles, one pack, device-to-device messages, interior tiles meanwhile, one unpack) against the unpartitioned run."""
     import mgcfd
     from conftest import perturbed_state
-    from mgcfd.partition import partition_level, rcb_partition
+    from mgcfd.partition import partition_level, rcb_partition, slab_partition
     L = mgcfd.generated_to_levels(mg)[0]
-    parts = partition_level(L, rcb_partition(np.asarray(L["coords"]), n_parts))
+    parts = partition_level(L, (slab_partition if partitioner == "slab" else rcb_partition)(np.asarray(L["coords"]), n_parts))
     whole = mgcfd.Solver.from_arrays([L], mg.mesh_variant)
     q0 = perturbed_state(L["nel"], whole.far_field()[:5], seed=21)
     whole.set(0, "variables", q0)

@@ -206,7 +206,7 @@ def run_seed(seed, n_ops, verbose=False):
             v = m.L[l][a] * (1.0 + 1e-3 * rng.uniform(-1, 1, m.L[l][a].shape)) if a != "fluxes" else rng.normal(size=(m.L[l]["nel"], 5)) * 1e-9
             s.set(l, a, v); m.L[l][a][:] = v
         elif op == "option":
-            name_, val = [("fuse_update", int(rng.integers(2))), ("graph", int(rng.integers(2))), ("flux_variant", int(rng.choice([-1, 0, 1, 2, 3, 4]))),
+            name_, val = [("fuse_update", int(rng.integers(2))), ("graph", int(rng.integers(2))), ("flux_variant", int(rng.choice([-1, 0, 1, 2, 3, 4, 16, 32]))),
                           ("check_invalid", int(rng.integers(2))), ("indirect_rw", int(rng.integers(2))), ("timing", int(rng.integers(3)))][int(rng.integers(6))]
             if name_ == "indirect_rw": indirect[0] = val
             s.set_option(name_, val); op = f"option {name_}={val}"

@@ -62,7 +62,7 @@ def main():
         except AssertionError:
             print(f"seed {seed}: {kind} {name} {[l.nel for l in mg.levels]}: the oracle's state goes invalid, skipped", flush=True)
             continue
-        opts = {"fuse_update": int(rng.integers(0, 2)), "flux_variant": int(rng.choice([-1, 0, 1, 2, 3])), "graph": int(rng.integers(0, 2))}
+        opts = {"fuse_update": int(rng.integers(0, 2)), "flux_variant": int(rng.choice([-1, 0, 1, 2, 3, 16, 32, 33])), "graph": int(rng.integers(0, 2))}
         s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
         for k, v in opts.items():
             s.set_option(k, v)

@@ -33,7 +33,8 @@ value = internal edges pushed through compute_flux_edge by all ranks / wall time
 roofline: the kernel BASELINE's target names, compute_flux_edge (+ boundary + far-field faces) = k_flux_tile writing
 fluxes[], priced as SURVEY.md §8d prices it (40 B per edge + 80 B per node) against 8 TB/s, its duration measured
 here with hipEvents on the launch stream; `fused_stage` beside it is the launch the sweeps actually run (one whole
-Runge-Kutta stage = compute_flux_edge + time_step, 168 B per node more), timed inside the timed region.  `traffic` is
+Runge-Kutta stage = compute_flux_edge + time_step, 168 B per node more), timed by ONE hipEvent pair around the K
+timed steps (3 such launches per step, back to back; nothing else is enqueued inside the region).  `traffic` is
 not measurable from inside a process: it is the figure of the committed rocprofv3 --pmc profile of this command,
 labelled with the file and build it came from.
 cpu_baseline: the reference's own compute_flux_edge (oracle/_ref, built from the reference sources) — or the C oracle
@@ -60,6 +61,7 @@ LATTICE = 67                 # 67^3 = 300,763 nodes, 888,822 internal edges
 LATTICE_8X = 134             # the level tiled 8x (connected): 2,406,104 nodes / 7,164,444 internal edges
 HIERARCHY = (67, 55, 48, 43) # 300,763 / 166,375 / 110,592 / 79,507 nodes
 TRAFFIC_PROFILE = os.path.join("profiles", "r2_traffic.json")
+ROOFLINE_LAUNCHES = 1000     # back-to-back launches of the standalone flux kernel / of its data-movement probe per measurement
 
 
 def build_workload(lattice: int, seed: int = 0):
@@ -170,21 +172,21 @@ def cpu_baseline(levels, sample_seconds: float):
 def vcycle_wall(fast: bool, cycles: int = 25, device: int = 0):
     """Second half of BASELINE.json's metric: wall seconds per MG V-cycle on the 4-level M6-like hierarchy
     (67^3/55^3/48^3/43^3 lattices = 300,763/166,375/110,592/79,507 nodes, nearest-node maps,
-    mesh_name = m6wing), 25 cycles as the reference's default (src/Base/config.cpp:63), best of 3 — the reference's
+    mesh_name = m6wing), 25 cycles as the reference's default (src/Base/config.cpp:63), best of 5 — the reference's
     "Total" / cycles (src/Monitoring/timer.cpp:106-195) with everything resident."""
     import mgcfd
     mg, levels = build_hierarchy()
     s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant, device=device)
     s.set_option("exact", 0 if fast else 1)
-    s.run_cycles(2)
+    s.run_cycles(100)                       # ~30 ms of load: the clocks of an idle MI355X are up only after that (tools/exp/first_steps.py)
     best = float("inf")
-    for _ in range(3):
+    for _ in range(5):
         s.reset_monitoring()
         t0 = time.perf_counter()
         rms = s.run_cycles(cycles)
         best = min(best, time.perf_counter() - t0)
     edge_iters = sum(s.loop_iters(l)["flux"] for l in range(s.num_levels)) // cycles
-    out = {"workload": f"4-level M6-like synthetic hierarchy {[l.nel for l in mg.levels]} nodes, {cycles} cycles, best of 3",
+    out = {"workload": f"4-level M6-like synthetic hierarchy {[l.nel for l in mg.levels]} nodes, {cycles} cycles, best of 5 after 100 untimed cycles",
            "wall_s_per_cycle": round(best / cycles, 9), "flux_edge_iterations_per_cycle": edge_iters,
            "medges_per_s_whole_cycle": round(edge_iters * cycles / best / 1e6, 1), "rms_last": float(rms[-1])}
     s.close()
@@ -433,22 +435,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    flux_only = probe = None
+    if workload in ("level0", "copies"):
+        # the standalone compute_flux_edge kernel (writes fluxes[]), 50 back-to-back launches between one hipEvent pair
+        # on the same stream, and the data-movement probe on the same tiles (indirect_rw: same loads and stores, the
+        # reference's trivial arithmetic) = the empirical ceiling of this layout (src/Kernels/indirect_rw_loop.cpp:8-10).
+        # Measured BEFORE the timed region, 1000 launches each (~35 ms of GPU work together): they leave the state alone, and an
+        # MI355X that has been idle takes tens of milliseconds of load before its clocks are up — the first 20 sweeps after an
+        # idle period run at 66-72 us each, the same 20 sweeps after 30 ms of load at 61.5 (tools/exp/first_steps.py); the
+        # driver's default of 5 warm-up steps is 0.3 ms.  The line says so in "preheat".
+        solver.bench_flux(0, 2 * ROOFLINE_LAUNCHES)             # (untimed: the ramp itself)
+        flux_only = solver.bench_flux(0, ROOFLINE_LAUNCHES)
+        probe = solver.bench_indirect_rw(0, ROOFLINE_LAUNCHES) if hasattr(solver, "bench_indirect_rw") else None
+        solver.zero_fluxes(0)                                   # (the sweeps start from zero fluxes, as after any time_step)
     for _ in range(args.warmup):
         step()
     barrier()
     solver.reset_monitoring()
+    # ONE hipEvent pair around the whole timed region, on the stream the launches go to (no event inside the region:
+    # on ROCm an event record is a barrier packet between two launches).  A level0 step is exactly three fused-stage
+    # launches back to back, so (event time) / 3K is that kernel's launch-to-launch duration over the timed region.
     live_timing = os.environ.get("MGCFD_BENCH_NO_TIMING") != "1" and workload in ("level0", "copies")
-    if live_timing:
-        # hipEvent pairs around the three stage launches of sampled sweeps: every 8th sweep, every sweep when K is small
-        solver.set_option("timing", 3 if args.steps <= 400 else 2)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
+    ev0.record(stream)
     for _ in range(args.steps):
         step()
+    ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    flux_avg, flux_launches = solver.flux_kernel_time(timed_level) if live_timing else (0.0, 0)
-    solver.set_option("timing", 0)
+    gpu_seconds = ev0.elapsed_time(ev1) * 1e-3
+    flux_launches = 3 * args.steps if live_timing and workload == "level0" else 0
+    flux_avg = gpu_seconds / flux_launches if flux_launches else 0.0
     rc, bad = solver.check_for_invalid_variables(0)
     if rc != 0:
         raise SystemExit(f"state became invalid during the bench (code {rc}, cell {bad})")
@@ -478,11 +497,6 @@ def main():
         if workload == "level-per-gpu":
             out["vcycle"] = {"wall_s_per_cycle": round(elapsed / args.steps, 9), "flux_edge_iterations_per_cycle": edges_per_step_all_ranks}
     if workload in ("level0", "copies"):
-        # the standalone compute_flux_edge kernel (writes fluxes[]), 50 back-to-back launches between one hipEvent pair
-        # on the same stream, and the data-movement probe on the same tiles (indirect_rw: same loads and stores, the
-        # reference's trivial arithmetic) = the empirical ceiling of this layout (src/Kernels/indirect_rw_loop.cpp:8-10)
-        flux_only = solver.bench_flux(0, 50)
-        probe = solver.bench_indirect_rw(0, 50) if hasattr(solver, "bench_indirect_rw") else None
         if rank == 0:
             bytes_flux = 40 * n_int + 80 * nel                  # compute_flux_edge
             bytes_ts = 168 * nel                                # time_step
@@ -498,9 +512,11 @@ def main():
                     "traffic_source": (f"{TRAFFIC_PROFILE} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes; build {traffic.get('build')})"
                                        if traffic else None),
                     "kernel": "compute_flux_edge + boundary + far-field faces in one launch (writes fluxes[], no time_step): the kernel BASELINE's 60 % target names",
-                    "launches": 50, "avg_kernel_us": round(flux_only * 1e6, 3), "algorithmic_bytes_per_launch": bytes_flux,
+                    "launches": ROOFLINE_LAUNCHES, "avg_kernel_us": round(flux_only * 1e6, 3), "algorithmic_bytes_per_launch": bytes_flux,
                     "algorithmic_bytes": "40 B per internal edge + 80 B per node (SURVEY.md §8d)",
                     "medges_per_s": round(n_int / flux_only / 1e6, 1) if flux_only > 0 else None}
+            roof["preheat"] = (f"the {ROOFLINE_LAUNCHES} flux + {ROOFLINE_LAUNCHES} probe launches above ran BEFORE the warm-up and timed steps "
+                               "(an idle MI355X needs ~30 ms of load before its clocks are up: tools/exp/first_steps.py)")
             if probe:
                 roof["empirical_ceiling_us"] = round(probe * 1e6, 3)
                 roof["empirical_ceiling"] = "indirect_rw through the same tiles (same loads and stores, the reference's trivial arithmetic; src/Kernels/indirect_rw_loop.cpp:8-10)"
@@ -509,6 +525,7 @@ def main():
                 a2 = (bytes_flux + bytes_ts) / flux_avg / 1e9
                 roof["fused_stage"] = {"kernel": "one whole Runge-Kutta stage per launch = compute_flux_edge + boundary + far-field + time_step: what the timed sweeps run",
                                        "launches": flux_launches, "avg_kernel_us": round(flux_avg * 1e6, 3),
+                                       "timed_by": "one hipEvent pair around the K timed steps (3 launches each, back to back) on the launch stream",
                                        "algorithmic_bytes_per_launch": bytes_flux + bytes_ts,
                                        "algorithmic_bytes": {"compute_flux_edge (40E+80N)": bytes_flux, "time_step (168N)": bytes_ts},
                                        "achieved": round(a2, 1), "frac": round(a2 / HBM_PEAK_GBS, 4),

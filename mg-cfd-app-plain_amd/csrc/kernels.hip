@@ -468,10 +468,12 @@ __device__ __forceinline__ void finish_node(int64_t i, int64_t nel, int64_t stri
         // q_out may be the array old_variables points at (last stage, in place): this thread has read
         // its node's old values above and nobody else reads them
         store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
-        if (fs.residuals) {
+        if (fs.residuals || fs.sumsq_partial) {
             const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
-            fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
-            fs.residuals[3 * stride + i] = d3; fs.residuals[4 * stride + i] = d4;
+            if (fs.residuals) {                      // (null: the caller writes it on demand, solver.cpp settle_residuals)
+                fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
+                fs.residuals[3 * stride + i] = d3; fs.residuals[4 * stride + i] = d4;
+            }
             if (fs.sumsq_partial) ss = (((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3) + d4 * d4;
         }
         if (fs.check) {
@@ -889,8 +891,10 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
         if (ROLE >= 2 && ROLE <= 4) {               // last stage: residual (validation.cpp:77-89)
             const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
-            fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
-            fs.residuals[3 * stride + i] = d3; fs.residuals[4 * stride + i] = d4;
+            if (fs.residuals) {                      // (null: the caller writes it on demand, solver.cpp settle_residuals)
+                fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
+                fs.residuals[3 * stride + i] = d3; fs.residuals[4 * stride + i] = d4;
+            }
             if (fs.sumsq_partial) ss = (((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3) + d4 * d4;
         }
         if (fs.check) {

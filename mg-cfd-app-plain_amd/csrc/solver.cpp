@@ -112,6 +112,8 @@ struct DeviceLevel {
     int n_partials = 0;
     bool fluxes_zero = true;             // fluxes[] is logically zero (the flux launch need not read it)
     bool fluxes_stale = false;           // ... but its memory has not been zeroed (lazy zero after a fused time_step)
+    bool residuals_stale = false;        // residuals[] = variables - old_variables of the last sweep (validation.cpp:77-89), not written
+                                         // yet: a single-level run's sweeps overwrite it unread; settle_residuals writes it on demand
     bool sweep_flux0_done = false;       // mgcfd_sweep_flux0 ran since mgcfd_sweep_begin
     int stage_next = 0;                  // mgcfd_sweep_stage: the stage expected next (0 = a sweep may start)
     double *stage_out = nullptr;         // ... and the buffer the last one wrote (MGCFD_ARR_STAGE)
@@ -140,6 +142,8 @@ struct mgcfd_solver {
     double ff17[17] = {0};
     unsigned long long *err = nullptr;       // device: packed (cell << 8 | code), ~0 = clean
     int opt_exact = 1, opt_timing = 0, opt_indirect_rw = 0, opt_check = 1, opt_variant = -1, opt_fuse = 1, opt_graph = 0;
+    // (MGCFD_LAZY_RESIDUAL=0: every sweep's last stage writes residuals[] — for A/B measurements)
+    bool opt_lazy_residual = !(std::getenv("MGCFD_LAZY_RESIDUAL") && std::atoi(std::getenv("MGCFD_LAZY_RESIDUAL")) == 0);
     // check_for_invalid_variables: every checked launch carries its sequence number since the host last read the
     // error word, so the EARLIEST failing time_step wins, as in the reference (kernels.hip: err_key)
     int check_seq = 0;
@@ -149,7 +153,7 @@ struct mgcfd_solver {
     int timing_stride = 8;                  // OPT_TIMING == 2: bracket the flux launches of every Nth sweep
     int64_t sweep_counter = 0;
     bool in_timed_group = false;
-    struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; bool ahead_after = false; int rot_after = 0; int sf_par_after = 0; bool sumsq_after = false; };
+    struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; bool ahead_after = false; int rot_after = 0; int sf_par_after = 0; bool sumsq_after = false, res_stale_after = false; };
     std::map<uint64_t, SweepGraph> sweep_graphs;   // captured smoothing sweeps, keyed by (level, options)
     struct CycleGraph { hipGraphExec_t exec = nullptr; std::vector<std::vector<int64_t>> iters; std::vector<bool> ahead_after; std::vector<int> rot_after, sf_par_after; };
     std::map<uint64_t, CycleGraph> cycle_graphs;   // captured whole multigrid cycles, keyed by options
@@ -217,6 +221,7 @@ struct mgcfd_solver {
     void op_copy_old(int l)
     {
         DeviceLevel &lv = level(l);
+        settle_residuals(lv);
         HIP_CHECK(hipMemcpyAsync(lv.old_variables, lv.q, sizeof(double) * 5 * lv.dp.stride, hipMemcpyDeviceToDevice, stream));
     }
     // first half of compute_step_factor; reduce_to_scalar also folds the workgroups' partial
@@ -225,6 +230,7 @@ struct mgcfd_solver {
     {
         DeviceLevel &lv = level(l);
         lv.min_ahead = false;                       // partial_min is rewritten (same values if it was ahead)
+        if (fuse_copy_old) settle_residuals(lv);
         double *old = fuse_copy_old ? lv.old_variables : nullptr;
         if (opt_exact) exact::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.partial_min, old);
         else fast::launch_step_factor_local(stream, lv.info.nel, lv.dp.stride, lv.q, lv.cbrt_vol, lv.step_factors, lv.partial_min, old);
@@ -235,6 +241,17 @@ struct mgcfd_solver {
         DeviceLevel &lv = level(l);
         if (opt_exact) exact::launch_step_factor_apply(stream, lv.info.nel, lv.min_dt, lv.volumes, lv.step_factors);
         else fast::launch_step_factor_apply(stream, lv.info.nel, lv.min_dt, lv.volumes, lv.step_factors);
+    }
+    // Write the residual of the last sweep if its last stage left it out (single-level runs: the next sweep would only
+    // overwrite it).  Both operands are still in place — `variables` and the sweep's start state, which the buffer rotation
+    // made old_variables — and the subtraction is the one the stage would have done, so the bits are the same.  Called by
+    // everything that reads residuals[] and by everything that is about to change either operand.
+    void settle_residuals(DeviceLevel &lv)
+    {
+        if (!lv.residuals_stale) return;
+        lv.residuals_stale = false;
+        if (opt_exact) exact::launch_residual(stream, lv.dp.stride, lv.old_variables, lv.q, lv.residuals);
+        else fast::launch_residual(stream, lv.dp.stride, lv.old_variables, lv.q, lv.residuals);
     }
     // materialise a logically-zero flux array before anything reads its memory
     void settle_fluxes(DeviceLevel &lv)
@@ -252,6 +269,7 @@ struct mgcfd_solver {
         bool apply_pending = false;
         if (mesh_variant == MGCFD_MESH_FVCORR) {
             double *old = (fused && copy_old) ? lv.old_variables : nullptr;
+            if (old) settle_residuals(lv);
             if (opt_exact) exact::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors, old);
             else fast::launch_step_factor_legacy(stream, lv.info.nel, lv.dp.stride, lv.q, lv.volumes, lv.step_factors, old);
         } else {
@@ -294,9 +312,10 @@ struct mgcfd_solver {
     void op_fused_stage(int l, int j, const double *in, double *out, int apply_min, bool with_residual,
                         const double *old = nullptr, bool look_ahead = false, bool sumsq = false,
                         const double *vin_flux = nullptr, const int32_t *tile_list = nullptr, int32_t n_list = 0,
-                        bool count_iters = true, const double *min_list = nullptr, int n_min = 0)
+                        bool count_iters = true, const double *min_list = nullptr, int n_min = 0, bool lazy_residual = false)
     {
         DeviceLevel &lv = level(l);
+        settle_residuals(lv);                       // (a sweep that supersedes the residual has dropped the flag: smooth_once)
         FusedStep fs;
         fs.tile_list = tile_list;
         fs.n_list = n_list;
@@ -311,7 +330,7 @@ struct mgcfd_solver {
         fs.partial_min = apply_min == 1 ? lv.partial_min : (apply_min == 2 ? lv.min_dt : (apply_min == 3 ? min_list : nullptr));
         fs.n_partial = apply_min == 2 ? 1 : (apply_min == 3 ? n_min : static_cast<int>((lv.info.nel + 255) / 256));
         fs.volumes = lv.volumes;
-        fs.residuals = with_residual ? lv.residuals : nullptr;
+        fs.residuals = (with_residual && !lazy_residual) ? lv.residuals : nullptr;
         fs.sumsq_partial = (with_residual && sumsq) ? lv.tile_sumsq : nullptr;
         fs.vin_flux = vin_flux;                     // role 5: the input is the first stage's time_step of (old, vin_flux)
         fs.vin_div = double(MGCFD_RK + 1);
@@ -353,6 +372,7 @@ struct mgcfd_solver {
         if (j < 0 || j >= MGCFD_RK) throw std::invalid_argument("RK stage out of range");
         DeviceLevel &lv = level(l);
         settle_fluxes(lv);
+        settle_residuals(lv);
         if (!old) old = lv.old_variables;
         if (!out) out = lv.q;
         if (out == lv.q) lv.min_ahead = false;
@@ -370,12 +390,14 @@ struct mgcfd_solver {
     void op_residual(int l)
     {
         DeviceLevel &lv = level(l);
+        lv.residuals_stale = false;
         if (opt_exact) exact::launch_residual(stream, lv.dp.stride, lv.old_variables, lv.q, lv.residuals);
         else fast::launch_residual(stream, lv.dp.stride, lv.old_variables, lv.q, lv.residuals);
     }
     void op_sumsq(int l)
     {
         DeviceLevel &lv = level(l);
+        settle_residuals(lv);
         if (opt_exact) exact::launch_sumsq(stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
         else fast::launch_sumsq(stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
     }
@@ -385,6 +407,7 @@ struct mgcfd_solver {
         DeviceLevel &F = level(fine);
         DeviceLevel &C = level(fine + 1);
         if (!F.has_transfer) throw std::invalid_argument("level has no multigrid map");
+        settle_residuals(C);
         // Timer / iteration attribution quirk: the reference bumps `level` before the call,
         // so restriction is booked to the COARSE level.
         // the coarse sweep that follows starts with compute_step_factor on the restricted state: the
@@ -404,6 +427,8 @@ struct mgcfd_solver {
         DeviceLevel &F = level(fine);
         DeviceLevel &C = level(fine + 1);
         if (!F.has_transfer) throw std::invalid_argument("level has no multigrid map");
+        settle_residuals(C);
+        settle_residuals(F);
         const bool ahead = mesh_variant != MGCFD_MESH_FVCORR && F.n_owned == F.info.nel;   // as in op_restrict
         double *pm = ahead ? F.partial_min : nullptr;
         Timed t(this, fine, MGCFD_LOOP_PROLONG);
@@ -563,6 +588,9 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
             const double v = d.volumes[P.old_of_new[static_cast<size_t>(n)]];
             vol[static_cast<size_t>(n)] = v;
             cb[static_cast<size_t>(n)] = std::cbrt(v);        // cfd_loops.cpp:116, static => host libm once
+            // a ghost never holds the minimum of compute_step_factor (its owner counts it): a launch that looks ahead
+            // sees a ghost at the sweep's START state, which must not enter the next sweep's minimum
+            if (P.old_of_new[static_cast<size_t>(n)] >= lv.n_owned) cb[static_cast<size_t>(n)] = std::numeric_limits<double>::infinity();
         }
         lv.volumes = dev_upload(vol);
         lv.cbrt_vol = dev_upload(cb);
@@ -999,6 +1027,7 @@ static void smooth_once(mgcfd_solver *s, int level)
         // change roles at the end (DeviceLevel::rot).
         const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
         bool apply_pending = global_dt;
+        lv.residuals_stale = false;                // (an unwritten residual of the previous sweep: this sweep's replaces it)
         if (lv.min_ahead) {
             // the launch that produced `variables` already did compute_step_factor's work on them
             // (:388-395): the per-workgroup minima are in partial_min, or (fvcorr) the factors in sf_alt
@@ -1021,11 +1050,16 @@ static void smooth_once(mgcfd_solver *s, int level)
         s->op_fused_stage(level, 0, start, b1, apply, false, start);
         s->op_fused_stage(level, 1, b1, b2, 0, false, start);
         const bool sumsq = lv.want_sumsq && lv.n_owned == lv.info.nel;
-        s->op_fused_stage(level, 2, b2, b1, 0, true, start, look_ahead, sumsq);   // + :508
+        // residual (:508) = this stage's result - the sweep's start state.  On a single-level run nothing reads it before
+        // the next sweep overwrites it, so the stage leaves the 40 B per node unwritten (its squares still go into the
+        // RMS partials) and settle_residuals writes it if anybody asks: both operands stay where they are.
+        const bool lazy_res = s->L.size() == 1 && s->opt_lazy_residual;
+        s->op_fused_stage(level, 2, b2, b1, 0, true, start, look_ahead, sumsq, nullptr, nullptr, 0, true, nullptr, 0, lazy_res);
         lv.have_sumsq = sumsq;
         lv.rot = (lv.rot + 1) % 3;                 // variables = b1, q_alt = b2, old_variables = start
         lv.apply_rot();
         lv.min_ahead = look_ahead;
+        lv.residuals_stale = lazy_res;
         return;
     }
     const bool apply_pending = s->op_step_factor(level, true);     // :383 + :388-395
@@ -1088,6 +1122,7 @@ static void run_sweep(mgcfd_solver *s, int level)
         g.rot_after = lv.rot;
         g.sf_par_after = lv.sf_par;
         g.sumsq_after = lv.have_sumsq;
+        g.res_stale_after = lv.residuals_stale;
         it = s->sweep_graphs.emplace(key, g).first;
     }
     HIP_CHECK(hipGraphLaunch(it->second.exec, s->stream));
@@ -1097,6 +1132,7 @@ static void run_sweep(mgcfd_solver *s, int level)
     lv.sf_par = it->second.sf_par_after;
     lv.apply_sf();
     lv.have_sumsq = it->second.sumsq_after;
+    lv.residuals_stale = it->second.res_stale_after;
     for (int k = 0; k < MGCFD_NUM_LOOPS; k++) lv.iters[k] += it->second.iters[k];
 }
 
@@ -1393,7 +1429,7 @@ int mgcfd_get_array(mgcfd_solver *s, int level, int which, double *out)
         s->use_device();
         DeviceLevel &lv = s->level(level);
         int nc = 0;
-        double *src = array_ptr(lv, which, &nc);
+        double *src = (s->settle_residuals(lv), array_ptr(lv, which, &nc));
         if (which == MGCFD_ARR_FLUXES) s->settle_fluxes(lv);
         const int64_t stride = lv.dp.stride;
         std::vector<double> tmp(static_cast<size_t>(stride) * nc);
@@ -1412,7 +1448,7 @@ int mgcfd_set_array(mgcfd_solver *s, int level, int which, const double *in)
         s->use_device();
         DeviceLevel &lv = s->level(level);
         int nc = 0;
-        double *dst = array_ptr(lv, which, &nc);
+        double *dst = (s->settle_residuals(lv), array_ptr(lv, which, &nc));
         if (which == MGCFD_ARR_VOLUMES) throw std::invalid_argument("volumes are fixed at creation");
         const int64_t stride = lv.dp.stride;
         // keep the padded tail of every field as it is on the device (valid numbers)
@@ -1436,7 +1472,7 @@ int mgcfd_array_devptr(mgcfd_solver *s, int level, int which, void **devptr, int
         s->use_device();
         DeviceLevel &lv = s->level(level);
         int nc = 0;
-        double *p = array_ptr(lv, which, &nc);
+        double *p = (s->settle_residuals(lv), array_ptr(lv, which, &nc));
         if (which == MGCFD_ARR_FLUXES) s->settle_fluxes(lv);
         *devptr = p;
         *count = int64_t(nc) * lv.dp.stride;
@@ -1448,7 +1484,7 @@ int mgcfd_array_written(mgcfd_solver *s, int level, int which)
     return guarded([&] {
         DeviceLevel &lv = s->level(level);
         int nc = 0;
-        (void)array_ptr(lv, which, &nc);
+        (void)(s->settle_residuals(lv), array_ptr(lv, which, &nc));
         if (which == MGCFD_ARR_VOLUMES) throw std::invalid_argument("volumes are fixed at creation");
         if (which == MGCFD_ARR_FLUXES) { lv.fluxes_zero = false; lv.fluxes_stale = false; }
         if (which == MGCFD_ARR_VARIABLES) lv.min_ahead = false;
@@ -1500,7 +1536,7 @@ static void halo_move(mgcfd_solver *s, int level, int plan, int which, void *dev
     DeviceLevel &lv = s->level(level);
     if (plan < 0 || plan >= static_cast<int>(lv.halo_plans.size())) throw std::invalid_argument("unknown halo plan");
     int nc = 0;
-    double *field = array_ptr(lv, which, &nc);
+    double *field = (s->settle_residuals(lv), array_ptr(lv, which, &nc));
     if (nc != 5) throw std::invalid_argument("halo messages carry 5-component node arrays");
     if (which == MGCFD_ARR_FLUXES) { if (pack) s->settle_fluxes(lv); else { lv.fluxes_zero = false; lv.fluxes_stale = false; } }
     if (which == MGCFD_ARR_VARIABLES && !pack) lv.min_ahead = false;
@@ -1805,6 +1841,14 @@ static void halo_finish(mgcfd_solver *s, int level, double *field, int b)
         exact::launch_halo_unpack(s->stream, hx.total_recv(), lv.dp.stride, hx.recv_idx, hx.recv_buf[b], field);
 }
 
+// (MGCFD_PART_LOOK_AHEAD=0: the last stage of a partitioned sweep does not compute the next sweep's step-factor minima —
+//  every sweep then starts with its own k_step_factor_local launch; for A/B measurements)
+static bool part_look_ahead()
+{
+    static const bool on = !(std::getenv("MGCFD_PART_LOOK_AHEAD") && std::atoi(std::getenv("MGCFD_PART_LOOK_AHEAD")) == 0);
+    return on;
+}
+
 // One stage of a partitioned sweep on one rank, part 1: the ghosts of the stage's input arrive (the previous stage's
 // message), the boundary tiles run, their results are packed and sent.  Part 2 (stage_interior) runs the other tiles
 // while the message travels.
@@ -1821,7 +1865,7 @@ static void stage_boundary(mgcfd_solver *s, int level, int j, int apply_min, con
         s->settle_fluxes(lv);
     }
     s->force_check = s->next_check();                       // both parts of the stage are one time_step for check_for_invalid_variables
-    s->op_fused_stage(level, j, in, out, j == 0 ? apply_min : 0, j == 2, start, false, false, nullptr, hx.tiles_boundary, hx.n_boundary, true, min_list, n_min);
+    s->op_fused_stage(level, j, in, out, j == 0 ? apply_min : 0, j == 2, start, j == 2 && apply_min != 0 && part_look_ahead(), false, nullptr, hx.tiles_boundary, hx.n_boundary, true, min_list, n_min);
     lv.stage_out = out;
     halo_start(s, level, out, j);
 }
@@ -1832,13 +1876,15 @@ static void stage_interior(mgcfd_solver *s, int level, int j, int apply_min, con
     double *const start = lv.q, *const b1 = lv.q_alt, *const b2 = lv.old_variables;
     double *in = j == 0 ? start : (j == 1 ? b1 : b2);
     double *out = j == 0 ? b1 : (j == 1 ? b2 : b1);
-    s->op_fused_stage(level, j, in, out, j == 0 ? apply_min : 0, j == 2, start, false, false, nullptr, hx.tiles_interior, hx.n_interior, false, min_list, n_min);
+    s->op_fused_stage(level, j, in, out, j == 0 ? apply_min : 0, j == 2, start, j == 2 && apply_min != 0 && part_look_ahead(), false, nullptr, hx.tiles_interior, hx.n_interior, false, min_list, n_min);
     s->force_check = -1;
     if (j == 2) {
         lv.rot = (lv.rot + 1) % 3;                          // variables = b1, q_alt = b2, old_variables = start
         lv.apply_rot();
         lv.stage_out = lv.q;
-        lv.min_ahead = false;
+        // global time step: both launches of the last stage left the first half of the NEXT sweep's compute_step_factor
+        // in partial_min, every tile its own minimum over its OWNED nodes (cbrt_vol is +inf on ghosts)
+        lv.min_ahead = apply_min != 0 && part_look_ahead();
     }
 }
 
@@ -1848,7 +1894,8 @@ static void sweep_first_half(mgcfd_solver *s, int level)
     if (!lv.hx) throw std::invalid_argument("the level has no halo lists: call mgcfd_rank_set_halo first");
     if (lv.stage_next != 0) throw std::invalid_argument("a sweep is under way (mgcfd_sweep_stage)");
     const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
-    s->op_step_factor(level, true, false);                  // first half of compute_step_factor (owned and ghost nodes alike: the ghosts' values are the owners')
+    if (global_dt && lv.min_ahead) lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;      // the previous sweep's last stage looked ahead
+    else s->op_step_factor(level, true, false);             // first half of compute_step_factor (a ghost's factor is its owner's business)
     if (global_dt) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
 }
 
@@ -1978,7 +2025,7 @@ static void after_replayed_sweep(mgcfd_solver *s, int level, const int64_t *iter
     lv.rot = (lv.rot + 1) % 3;
     lv.apply_rot();
     lv.stage_out = lv.q;
-    lv.min_ahead = false;
+    lv.min_ahead = s->mesh_variant != MGCFD_MESH_FVCORR && part_look_ahead();    // (as stage_interior leaves it)
     for (int k = 0; k < MGCFD_NUM_LOOPS; k++) lv.iters[k] += iters_delta[k];
 }
 
@@ -2017,8 +2064,12 @@ int mgcfd_rank_sweeps(mgcfd_solver *s, int level, int sweeps)
             // MGCFD_OPT_GRAPH = 1: the sweep replayed from a hipGraph (measured with the one rank a one-GPU box offers: 76 us
             // per sweep against 129 us issued call by call; ncclSend/ncclRecv inside a capture could not be rehearsed
             // there, hence opt-in)
-            if (s->opt_graph && sweep_graphs_enabled() && !hx.graph_failed && s->opt_timing == 0) {
+            // (global time step: a sweep is captured / replayed only from a looked-ahead state — the steady state; the first
+            //  sweep after an exchange, which still runs k_step_factor_local, goes out eagerly)
+            const bool steady = s->mesh_variant == MGCFD_MESH_FVCORR || lv.min_ahead || !part_look_ahead();
+            if (s->opt_graph && sweep_graphs_enabled() && !hx.graph_failed && s->opt_timing == 0 && steady) {
                 if (!hx.sweep_graph[rot]) {
+                    const bool ahead_before = lv.min_ahead;
                     int64_t before[MGCFD_NUM_LOOPS];
                     std::memcpy(before, lv.iters, sizeof(before));
                     const int rot_before = lv.rot;
@@ -2027,12 +2078,14 @@ int mgcfd_rank_sweeps(mgcfd_solver *s, int level, int sweeps)
                     if (!ok) {                              // nothing ran: put the host state back and go on eagerly
                         hx.graph_failed = true;
                         lv.rot = rot_before; lv.apply_rot();
+                        lv.min_ahead = ahead_before;
                         std::memcpy(lv.iters, before, sizeof(before));
                         rank_sweep_once(s, level);
                         continue;
                     }
                     for (int q = 0; q < MGCFD_NUM_LOOPS; q++) { hx.graph_iters[rot][q] = lv.iters[q] - before[q]; lv.iters[q] = before[q]; }
                     lv.rot = rot_before; lv.apply_rot();    // (the capture advanced the host state without running anything)
+                    lv.min_ahead = ahead_before;
                 }
                 HIP_CHECK(hipGraphLaunch(hx.sweep_graph[rot], s->stream));
                 after_replayed_sweep(s, level, hx.graph_iters[rot]);
@@ -2144,8 +2197,10 @@ int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps)
         bool replayed = false;
         for (int k = 0; k < sweeps; k++) {
             const int rot = s0->level(level).rot % 3;
-            if (graphs && !h0.graph_failed) {
+            const bool steady = s0->mesh_variant == MGCFD_MESH_FVCORR || s0->level(level).min_ahead || !part_look_ahead();   // (as in mgcfd_rank_sweeps)
+            if (graphs && !h0.graph_failed && steady) {
                 if (!h0.sweep_graph[rot]) {
+                    const bool ahead_before = s0->level(level).min_ahead;
                     // every rank's sweep in ONE graph: the other ranks' streams fork from rank 0's and join it at the end
                     std::vector<std::vector<int64_t>> before;
                     std::vector<int> rot_before;
@@ -2164,6 +2219,7 @@ int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps)
                         s->force_check = -1;
                         for (int q = 0; q < MGCFD_NUM_LOOPS; q++) { lv.hx->graph_iters[rot][q] = lv.iters[q] - before[r][static_cast<size_t>(q)]; lv.iters[q] = before[r][static_cast<size_t>(q)]; }
                         lv.rot = rot_before[r]; lv.apply_rot();
+                        lv.min_ahead = ahead_before;
                     }
                     if (!ok) { h0.graph_failed = true; group_sweep_once(g, level); continue; }
                 }

@@ -583,6 +583,60 @@ def test_old_variables_hold_the_sweep_start_state(mesh3_dir, fvcorr_dir, fuse):
         s.close(); fresh.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("then", ["set_variables", "time_step", "copy_old", "unfused_sweep", "split_sweep", "cycles", "graph_sweep",
+                                  "written_from_outside", "bench_flux", "nothing"])
+def test_unwritten_residual_is_written_before_its_operands_change(fvcorr_dir, then, monkeypatch):
+    """On a single-level run the last stage of a fused sweep does not write residuals[] (the next sweep would overwrite it
+    unread); the library writes it on demand from `variables` and the sweep's start state.  Whatever changes either
+    operand first must therefore write it first: the same call sequence on a solver that writes every residual
+    (MGCFD_LAZY_RESIDUAL=0) must leave every array bit-identical, the residual included, read only at the very end."""
+    import mgcfd
+    from mgcfd import meshgen
+    cases = [lambda: mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", fvcorr_dir)),                 # local time step
+             lambda: mgcfd.Solver.from_generated(meshgen.make_multigrid((11,), "m6wing", seed=4, cavity_radius=0.2))]   # global time step
+    for make in cases:
+        solvers = []
+        for lazy in ("1", "0"):
+            monkeypatch.setenv("MGCFD_LAZY_RESIDUAL", lazy)
+            solvers.append(make())
+        monkeypatch.delenv("MGCFD_LAZY_RESIDUAL")
+        q = perturbed_state(solvers[0].nel(0), solvers[0].far_field()[:5], seed=31)
+        q2 = perturbed_state(solvers[0].nel(0), solvers[0].far_field()[:5], seed=32)
+        out = []
+        for s in solvers:
+            s.set(0, "variables", q)
+            s.smooth(0, 2)                                  # (nothing read in between: the second sweep's residual is unwritten)
+            if then == "set_variables":
+                s.set(0, "variables", q2)
+            elif then == "time_step":
+                s.compute_fluxes(0); s.time_step(0, 1)
+            elif then == "copy_old":
+                s.copy_old_variables(0)
+            elif then == "unfused_sweep":
+                s.copy_old_variables(0); s.compute_step_factor(0)
+                for j in range(3):
+                    s.compute_fluxes(0); s.time_step(0, j)
+            elif then == "split_sweep":
+                s.sweep_begin(0); s.sweep_stage(0, 0, partials=False); s.sweep_stage(0, 1, partials=False)     # (stops before the last stage)
+            elif then == "cycles":
+                s.run_cycles(2)
+            elif then == "graph_sweep":
+                s.set_option("graph", 1); s.smooth(0, 4)
+            elif then == "written_from_outside":
+                s.array_devptr(0, "variables"); s.array_written(0, "variables")
+            elif then == "bench_flux":
+                s.bench_flux(0, 2); s.zero_fluxes(0)
+            names = ["residuals", "variables", "old_variables", "step_factors"]
+            if then not in ("split_sweep",):
+                names.append("fluxes")
+            out.append({n: s.get(0, n) for n in names})
+            s.close()
+        for n in out[0]:
+            assert np.array_equal(out[0][n].view(np.int64), out[1][n].view(np.int64)), (then, n)
+        assert np.abs(out[0]["residuals"]).max() > 0.0
+
+
 def test_invalid_state_is_reported(setup, oracle):
     mgcfd, mesh, solver, case, lib = setup
     ff = oracle.farfield()

@@ -116,6 +116,7 @@ def run_seed(seed, n_ops, verbose=False):
         q = perturbed_state(m.L[l]["nel"], np.array(m.ff.var), seed=seed * 7 + l)
         s.set(l, "variables", q); m.L[l]["variables"][:] = q
     compare("set")
+    skip = np.random.default_rng(seed + 777)             # (its own stream: the operation sequences of the seeds stay as they were)
     for k in range(n_ops):
         l = int(rng.integers(nl))
         op = str(rng.choice(["sweep", "sweep", "cycle", "flux", "flux_parts", "time_step", "step_factor", "copy_old", "residual", "restrict",
@@ -223,7 +224,10 @@ def run_seed(seed, n_ops, verbose=False):
         if any(not np.isfinite(m.L[x]["variables"]).all() or (m.L[x]["variables"][:, 0] <= 0).any() or (m.L[x]["variables"][:, 4] <= 0).any() for x in range(nl)):
             log.append("state invalid: stop")
             break
-        compare(op)
+        # (any array read makes the library write a residual its last sweep left unwritten — single-level runs — so some calls
+        #  go unchecked: the next call then meets the unwritten residual and must write it before it changes an operand)
+        if skip.random() < 0.6 or k == n_ops - 1:
+            compare(op)
     s.close()
     return log
 

@@ -49,6 +49,9 @@ struct FusedStep {
     // results can travel while the others are computed): tile_list[k] = tile of workgroup k; nullptr = all tiles
     const int32_t *tile_list = nullptr;
     int32_t n_list = 0;
+    // > 0: the launch treats only nodes [0, nel_active) as present (a partitioned level whose ghosts are numbered last:
+    // the ghost slots are then written by halo messages only — a peer may be storing into them during this launch)
+    int64_t nel_active = 0;
 };
 
 // "Add up these partial sums" as an argument: k_sum_partials does only that; k_restrict can take it along.

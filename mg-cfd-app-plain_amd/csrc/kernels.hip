@@ -1923,6 +1923,7 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     FusedStep fs{};
     if (fused) fs = *fused;
     const bool part = fused && fs.tile_list;                        // part of the level's tiles (node gather only)
+    const int64_t nel_arg = (fused && fs.nel_active > 0) ? fs.nel_active : p.nel;
     const dim3 grid(part ? fs.n_list : p.n_tiles);
     if (part && fs.n_list <= 0) return;
 
@@ -1931,7 +1932,7 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     // are built for 2 waves per SIMD instead of spilling 20-36 bytes per lane.
 #define MGCFD_TILE_LAUNCH_T(WMODE, FUSE, ACC, ROLE, TAIL)                                                      \
     hipLaunchKernelGGL((k_flux_tile<((TAIL) && ((ACC) || (ROLE) == 5)) ? 2 : 3, WMODE, FUSE, ACC, ROLE, TAIL>), grid, block, 0, st, q, p.tile_halo,     \
-                       uint32_t(grid.x), p.pad_row, p.stride, p.nel, p.slice_row0, p.rows_int, p.rows_bnd,  \
+                       uint32_t(grid.x), p.pad_row, p.stride, nel_arg, p.slice_row0, p.rows_int, p.rows_bnd, \
                        p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs, p.tail, p.gat16,     \
                        p.te_chunk_ptr, p.te_w3)
     // levels with long rows (tetrahedral meshes, hubs) run the instantiation that hands them to the workgroup

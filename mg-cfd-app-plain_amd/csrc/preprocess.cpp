@@ -280,8 +280,33 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     };
 
     // ---- node order ----
+    // A partitioned level (n_owned < nel): the OWNED nodes are clustered among themselves and numbered first, the ghosts
+    // follow in their given order.  Tiles past the owned nodes hold only ghosts and are never launched, and a launch that
+    // is told nel = n_owned leaves every ghost slot alone: ghosts are written by halo messages only (solver.cpp: a peer
+    // may store into them while this rank's own kernels run).
     std::vector<int32_t> order;
-    if (opt.ordering == 2) {
+    if (opt.ordering == 2 && n_owned < nel) {
+        std::vector<mgcfd_edge> inner;
+        for (int64_t e = L.internal_start; e < L.internal_start + L.n_internal; e++)
+            if (owned(edges[static_cast<size_t>(e)].a) && owned(edges[static_cast<size_t>(e)].b)) inner.push_back(edges[static_cast<size_t>(e)]);
+        const Adjacency go = build_adjacency(n_owned, inner.data(), 0, static_cast<int64_t>(inner.size()));
+        order = cluster_order(go, n_owned);
+        auto with_ghosts = [&](std::vector<int32_t> v) {
+            for (int64_t v2 = n_owned; v2 < nel; v2++) v.push_back(static_cast<int32_t>(v2));
+            return v;
+        };
+        order = with_ghosts(order);
+        P.ghosts_last = true;
+        const std::pair<int64_t, int64_t> greedy = halo_cost(g, order, nel);
+        if (greedy.first > 0 && L.coords) {
+            std::vector<int32_t> boxes(static_cast<size_t>(n_owned));
+            std::iota(boxes.begin(), boxes.end(), 0);
+            rcb_split(L.coords, boxes.data(), n_owned);
+            boxes = with_ghosts(boxes);
+            if (halo_cost(g, boxes, nel) < greedy) { order.swap(boxes); P.ordered_by_boxes = true; }
+        }
+    }
+    else if (opt.ordering == 2) {
         order = cluster_order(g, nel);
         // greedy balls have the smallest halos on hexahedral-like meshes; where they overflow the LDS tile
         // (high-degree meshes) try coordinate boxes and keep whichever leaves fewer halo nodes outside
@@ -354,6 +379,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         for (int64_t s = 0; s < nel; s += W) {
             auto b = order.begin() + s, e = order.begin() + std::min(nel, s + W);
             std::stable_sort(b, e, [&](int32_t x, int32_t y) {
+                if (owned(x) != owned(y)) return owned(x);                    // (the tile where the ghosts begin: owned nodes first)
                 int dx = rows_of(x), dy = rows_of(y);
                 if (dx != dy) return dx > dy;
                 if (bnd_count[static_cast<size_t>(x)] != bnd_count[static_cast<size_t>(y)]) return bnd_count[static_cast<size_t>(x)] > bnd_count[static_cast<size_t>(y)];

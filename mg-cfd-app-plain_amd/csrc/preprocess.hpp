@@ -76,6 +76,7 @@ struct LevelPlan {
     std::vector<uint16_t> nbr16;          // [rows*64] 16-bit tile-local codes (see kT16*)
     double halo_mean = 0.0; int32_t halo_max = 0; int64_t halo_overflow_refs = 0, halo_total = 0;
     bool ordered_by_boxes = false;        // node order from rcb_split (coordinate boxes) instead of cluster_order
+    bool ghosts_last = false;             // partitioned level: new ids [0, n_owned) are the owned nodes, the ghosts follow
     std::vector<EdgeW> w;              // [rows*64]
     //   internal, this node = a:  (x,y,z) = -0.5*e   k = -|e|*smoothing*0.5   (flux_kernel.elemfunc.c:130-140)
     //   internal, this node = b:  (x,y,z) = +0.5*e   k = same

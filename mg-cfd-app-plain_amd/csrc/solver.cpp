@@ -319,6 +319,8 @@ struct mgcfd_solver {
         FusedStep fs;
         fs.tile_list = tile_list;
         fs.n_list = n_list;
+        // the C++ partitioned sweeps (tile lists): ghosts numbered last are left to the halo messages
+        if (tile_list && lv.plan.ghosts_last && lv.n_owned < lv.info.nel) fs.nel_active = lv.n_owned;
         fs.rk_div = double(MGCFD_RK + 1 - j);
         fs.step_factors = lv.step_factors;
         fs.old_variables = old ? old : lv.old_variables;
@@ -604,7 +606,8 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.sf_alt = dev_alloc<double>(static_cast<size_t>(stride));
         lv.sfb[0] = lv.step_factors; lv.sfb[1] = lv.sf_alt;
         lv.min_dt = dev_alloc<double>(1);
-        lv.partial_min = dev_alloc<double>(static_cast<size_t>((nel + 255) / 256));
+        // (+inf: a tile that is never launched — the ghost-only tiles of a partitioned level — holds no minimum)
+        lv.partial_min = dev_upload(std::vector<double>(static_cast<size_t>((nel + 255) / 256), std::numeric_limits<double>::infinity()));
         lv.tile_sumsq = dev_alloc<double>(static_cast<size_t>((nel + 255) / 256));
         lv.sumsq = dev_alloc<double>(1);
         lv.n_partials = static_cast<int>(std::min<int64_t>(1024, (nel * 5 + 255) / 256));
@@ -1770,7 +1773,10 @@ static void build_halo(mgcfd_solver *s, int level, int n_peers, const int *peers
         if (E.a >= lv.n_owned || E.b >= lv.n_owned) { boundary[static_cast<size_t>(tile_of(E.a))] = 1; boundary[static_cast<size_t>(tile_of(E.b))] = 1; }
     }
     std::vector<int32_t> tb, ti;
-    for (int32_t t = 0; t < lv.plan.n_tiles; t++) (boundary[static_cast<size_t>(t)] ? tb : ti).push_back(t);
+    for (int32_t t = 0; t < lv.plan.n_tiles; t++) {
+        if (lv.plan.ghosts_last && int64_t(t) * kTile >= lv.n_owned) break;      // ghost-only tiles are never launched
+        (boundary[static_cast<size_t>(t)] ? tb : ti).push_back(t);
+    }
     hx->n_boundary = static_cast<int32_t>(tb.size());
     hx->n_interior = static_cast<int32_t>(ti.size());
     hx->tiles_boundary = dev_upload(tb);

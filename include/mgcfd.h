@@ -342,7 +342,10 @@ int mgcfd_residual_sumsq(mgcfd_solver *s, int level, void **devptr);
  * peer's segment with ONE launch, sends (RCCL ncclSend/ncclRecv grouped on a second stream; between the
  * solvers of one process hipMemcpyPeerAsync over xGMI), runs the interior tiles while the message travels,
  * and unpacks with ONE launch before the next stage's boundary tiles.  Results equal the unpartitioned
- * level's bit for bit on owned nodes.
+ * level's bit for bit on owned nodes.  The solvers of one process skip the message buffers altogether: behind its
+ * boundary tiles a rank stores the nodes its peers need straight into their ghost slots (one launch, peer access
+ * over xGMI) and a peer's next stage waits for that launch's event (MGCFD_GROUP_DIRECT=0 in the environment keeps
+ * the buffered form).
  *
  * Two ways to be a rank:
  *   one rank per PROCESS (RCCL):  mgcfd_rccl_unique_id on rank 0, the 128 bytes handed to every rank by the

@@ -21,6 +21,16 @@ struct FarField {
     double fc_mx[3], fc_my[3], fc_mz[3], fc_de[3];
 };
 
+// Where a halo "push" stores (kernels.hip: k_halo_push): the state buffers of up to kMaxPushPeers neighbouring ranks
+// (peer access over xGMI, or the same device), the peers' segments of the message being consecutive slot ranges.
+constexpr int kMaxPushPeers = 8;
+struct PushPeers {
+    double *base[kMaxPushPeers] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // peer p's state buffer [5][stride[p]]
+    int64_t stride[kMaxPushPeers] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t first[kMaxPushPeers + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // slots [first[p], first[p+1]) go to peer p
+    int n = 0;
+};
+
 // Arguments of the time_step half of a fused flux + time_step launch (kernels.hip: k_flux_tile<FUSE>).
 struct FusedStep {
     double rk_div = 1.0;                      // double(RK+1-j)

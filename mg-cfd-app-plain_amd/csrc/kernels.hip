@@ -1630,6 +1630,24 @@ k_halo_unpack(int64_t n, int64_t stride, const int32_t *__restrict__ idx, const 
     for (int f = 0; f < 5; f++) field[f * stride + i] = msg[k * 5 + f];
 }
 
+// The message of a partitioned level stored straight into the neighbours' ghost slots: slot k of the message is node idx[k]
+// here and node target[k] in the numbering of the peer whose segment k lies in.  One launch replaces pack, the copies (or
+// send/receive) and the peers' unpack launches; the stores cross xGMI (peer access) or stay on the device.
+__global__ void __launch_bounds__(kBlock)
+k_halo_push(int64_t n, int64_t stride, const int32_t *__restrict__ idx, const int32_t *__restrict__ target,
+            const double *__restrict__ field, PushPeers peers)
+{
+    const int64_t k = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    if (k >= n) return;
+    double *dst = peers.base[0];
+    int64_t ps = peers.stride[0];
+#pragma unroll
+    for (int p = 1; p < kMaxPushPeers; p++)                          // (selects, no indexed access to the argument block)
+        if (p < peers.n && k >= peers.first[p]) { dst = peers.base[p]; ps = peers.stride[p]; }
+    const int64_t i = idx[k], g = target[k];
+    for (int f = 0; f < 5; f++) dst[f * ps + g] = field[f * stride + i];
+}
+
 // One multigrid level per rank: the restricted variables arrive from the rank that holds the finer level as a whole
 // [5][stride] array.  mg_restrict leaves a coarse node WITHOUT children at its old value (mg_loops.cpp:63-78,174-189),
 // and only the rank that sweeps the coarse level has that value: take the message for nodes with children only.
@@ -2057,6 +2075,9 @@ void launch_sumsq(hipStream_t st, int64_t nel, int64_t stride, const double *x, 
 
 void launch_halo_pack(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const double *field, double *msg)
 { if (n > 0) hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, field, msg); }
+
+void launch_halo_push(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const int32_t *target, const double *field, const PushPeers &peers)
+{ if (n > 0) hipLaunchKernelGGL(k_halo_push, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, target, field, peers); }
 
 void launch_halo_unpack(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const double *msg, double *field)
 { if (n > 0) hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, msg, field); }

@@ -77,6 +77,13 @@ struct HaloExchange {
     hipGraphExec_t sweep_graph[3] = {nullptr, nullptr, nullptr};
     int64_t graph_iters[3][MGCFD_NUM_LOOPS] = {{0}};
     bool graph_failed = false;
+    // in-process groups, direct mode: a rank's message is stored by ONE launch straight into its peers' ghost slots
+    // (k_halo_push) — no message buffers, no second stream, no unpack; a stage's boundary tiles wait for the peers'
+    // previous-stage events instead
+    std::vector<int32_t> recv_idx_host;                  // recv_idx on the host (a peer builds its push targets from it)
+    int32_t *push_target = nullptr;                      // device [total_send]: slot k's node in the numbering of the peer it goes to
+    hipEvent_t bdone[3] = {nullptr, nullptr, nullptr};   // [stage] this rank's boundary tiles and push of that stage are enqueued up to here
+    bool direct = false;
     int64_t total_send() const { return send_off.empty() ? 0 : send_off.back(); }
     int64_t total_recv() const { return recv_off.empty() ? 0 : recv_off.back(); }
 };
@@ -483,7 +490,8 @@ mgcfd_solver::~mgcfd_solver()
         for (auto &hp : lv.halo_plans) if (hp.first) (void)hipFree(hp.first);
         if (lv.hx) {
             HaloExchange &hx = *lv.hx;
-            void *hp[] = {hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.gmin, hx.peer_scalars};
+            void *hp[] = {hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.gmin, hx.peer_scalars, hx.push_target};
+            for (hipEvent_t e : hx.bdone) if (e) (void)hipEventDestroy(e);
             for (void *p : hp) if (p) (void)hipFree(p);
             for (int b = 0; b < HaloExchange::kSets; b++) {
                 if (hx.send_buf[b]) (void)hipFree(hx.send_buf[b]);
@@ -1753,6 +1761,8 @@ static void build_halo(mgcfd_solver *s, int level, int n_peers, const int *peers
     }
     hx->send_idx = dev_upload(sidx);
     hx->recv_idx = dev_upload(ridx);
+    hx->recv_idx_host = ridx;
+    for (int j = 0; j < 3; j++) HIP_CHECK(hipEventCreateWithFlags(&hx->bdone[j], hipEventDisableTiming));
     for (int b = 0; b < HaloExchange::kSets; b++) {
         hx->send_buf[b] = dev_alloc<double>(sidx.size() * 5);
         hx->recv_buf[b] = dev_alloc<double>(ridx.size() * 5);
@@ -1920,6 +1930,108 @@ static void rank_sweep_once(mgcfd_solver *s, int level)
     halo_finish(s, level, lv.q, MGCFD_RK - 1);              // the ghosts of `variables` are current when the sweep ends
 }
 
+// ---- in-process groups, direct mode -------------------------------------------------------------------------------------
+// Every rank of a group can store into every other rank's memory (one process: unified addressing, peer access over xGMI),
+// so a message needs no buffers: behind its boundary tiles a rank runs ONE k_halo_push that writes the nodes its peers need
+// straight into their ghost slots of the buffer the stage writes, and records bdone[stage].  A peer's next stage waits
+// for that event before its boundary tiles (the only ones that read ghosts) start.  Ghost slots are written by pushes
+// only (the stage launches are told nel = n_owned: the plan numbers ghosts last), so a push may land while the
+// receiver's own kernels of that stage still run.  Why nothing is overwritten while somebody may still read it: rank A's
+// push of stage j goes into the buffer B's stage j writes, whose ghost slots B last read in the stage before (as that
+// stage's input) — and A's boundary tiles of stage j start only behind B's bdone of that earlier stage.
+// Per stage and rank: [P event waits] boundary launch, push launch, event record, interior launch — against
+// unpack, boundary, pack, record, wait, P copies, record, interior, wait of the buffered form.
+// (MGCFD_GROUP_DIRECT=0 keeps the buffered form.)
+static bool group_direct_wanted()
+{
+    // (not together with group graphs, MGCFD_GROUP_GRAPH=1: the capture code joins the buffered form's streams)
+    static const bool on = !(std::getenv("MGCFD_GROUP_DIRECT") && std::atoi(std::getenv("MGCFD_GROUP_DIRECT")) == 0) &&
+                           !(std::getenv("MGCFD_GROUP_GRAPH") && std::atoi(std::getenv("MGCFD_GROUP_GRAPH")) != 0);
+    return on;
+}
+
+// build the push targets of every rank (once; allocations and uploads never happen inside a sweep)
+static void group_prepare_direct(mgcfd_group *g, int level)
+{
+    bool possible = group_direct_wanted();
+    for (mgcfd_solver *s : g->ranks) {
+        DeviceLevel &lv = s->level(level);
+        if (!lv.hx) throw std::invalid_argument("a rank has no halo lists");
+        if (lv.hx->direct) return;                          // (done before)
+        if (static_cast<int>(lv.hx->peer.size()) > kMaxPushPeers) possible = false;
+        if (lv.n_owned < lv.info.nel && !lv.plan.ghosts_last) possible = false;     // (a plan that mixes ghosts into the tiles: its stages write them)
+    }
+    if (!possible) return;
+    for (mgcfd_solver *src : g->ranks) {
+        src->use_device();
+        HaloExchange &hs = *src->level(level).hx;
+        const int me = comm_of(src).rank;
+        std::vector<int32_t> target(static_cast<size_t>(hs.total_send()), 0);
+        for (size_t k = 0; k < hs.peer.size(); k++) {
+            mgcfd_solver *dst = g->ranks[static_cast<size_t>(hs.peer[k])];
+            HaloExchange &hd = *dst->level(level).hx;
+            const auto it = std::find(hd.peer.begin(), hd.peer.end(), me);
+            if (it == hd.peer.end()) throw std::logic_error("halo lists of two ranks do not match");
+            const size_t kd = static_cast<size_t>(it - hd.peer.begin());
+            const int64_t n = hs.send_off[k + 1] - hs.send_off[k];
+            if (n != hd.recv_off[kd + 1] - hd.recv_off[kd]) throw std::logic_error("halo message lengths of two ranks do not match");
+            for (int64_t i = 0; i < n; i++)
+                target[static_cast<size_t>(hs.send_off[k] + i)] = hd.recv_idx_host[static_cast<size_t>(hd.recv_off[kd] + i)];
+        }
+        hs.push_target = dev_upload(target);
+    }
+    for (mgcfd_solver *s : g->ranks) s->level(level).hx->direct = true;
+}
+
+// which of a rank's three state buffers a stage writes (as stage_boundary / stage_interior name them)
+static double *stage_out_buffer(DeviceLevel &lv, int j) { return j == 1 ? lv.old_variables : lv.q_alt; }
+
+// the nodes the peers need of `field` (this rank's buffer) into the peers' buffers `peer_field(peer level)`, then the event
+template <typename PeerField>
+static void push_and_record(mgcfd_group *g, mgcfd_solver *s, int level, const double *field, PeerField &&peer_field, int ev)
+{
+    DeviceLevel &lv = s->level(level);
+    HaloExchange &hx = *lv.hx;
+    if (hx.total_send() > 0) {
+        PushPeers pp;
+        pp.n = static_cast<int>(hx.peer.size());
+        for (int k = 0; k < pp.n; k++) {
+            DeviceLevel &pl = g->ranks[static_cast<size_t>(hx.peer[static_cast<size_t>(k)])]->level(level);
+            pp.base[k] = peer_field(pl);
+            pp.stride[k] = pl.dp.stride;
+            pp.first[k] = hx.send_off[static_cast<size_t>(k)];
+        }
+        pp.first[pp.n] = hx.total_send();
+        exact::launch_halo_push(s->stream, hx.total_send(), lv.dp.stride, hx.send_idx, hx.push_target, field, pp);
+    }
+    HIP_CHECK(hipEventRecord(hx.bdone[ev], s->stream));
+}
+
+static void wait_for_peers(mgcfd_group *g, mgcfd_solver *s, int level, int ev)
+{
+    HaloExchange &hx = *s->level(level).hx;
+    for (int p : hx.peer) HIP_CHECK(hipStreamWaitEvent(s->stream, g->ranks[static_cast<size_t>(p)]->level(level).hx->bdone[ev], 0));
+}
+
+// part 1 of a stage in direct mode (part 2 is stage_interior as it is)
+static void stage_boundary_direct(mgcfd_group *g, mgcfd_solver *s, int level, int j, int apply_min, const double *min_list, int n_min)
+{
+    DeviceLevel &lv = s->level(level);
+    HaloExchange &hx = *lv.hx;
+    double *const start = lv.q, *const b1 = lv.q_alt, *const b2 = lv.old_variables;
+    double *in = j == 0 ? start : (j == 1 ? b1 : b2);
+    double *out = j == 0 ? b1 : (j == 1 ? b2 : b1);
+    wait_for_peers(g, s, level, (j + 2) % 3);               // the ghosts of `in`: the peers' pushes of the stage before (stage 0: of the last sweep, or of the exchange)
+    if (j == 0) {
+        if (!lv.fluxes_zero) throw std::invalid_argument("a partitioned sweep needs zero fluxes (as after time_step)");
+        s->settle_fluxes(lv);
+    }
+    s->force_check = s->next_check();
+    s->op_fused_stage(level, j, in, out, j == 0 ? apply_min : 0, j == 2, start, j == 2 && apply_min != 0 && part_look_ahead(), false, nullptr, hx.tiles_boundary, hx.n_boundary, true, min_list, n_min);
+    lv.stage_out = out;
+    push_and_record(g, s, level, out, [&](DeviceLevel &pl) { return stage_out_buffer(pl, j); }, j);
+}
+
 // one sweep of every rank of an in-process group
 #define TRACE(msg) do { if (std::getenv("MGCFD_TRACE")) { std::fprintf(stderr, "[trace] %s\n", msg); std::fflush(stderr); } } while (0)
 static void group_sweep_once(mgcfd_group *g, int level)
@@ -1939,16 +2051,20 @@ static void group_sweep_once(mgcfd_group *g, int level)
             exact::launch_min_over_peers(dst->stream, hd.peer_scalars, n, hd.gmin);
         }
     }
+    const bool direct = g->ranks[0]->level(level).hx->direct;
     for (int j = 0; j < MGCFD_RK; j++) {
         TRACE("sweep: stage boundary");
-        for (mgcfd_solver *s : g->ranks) { s->use_device(); stage_boundary(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1); }
-        TRACE("sweep: deliver");
-        group_deliver(g, level, j);
+        for (mgcfd_solver *s : g->ranks) {
+            s->use_device();
+            if (direct) stage_boundary_direct(g, s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1);
+            else stage_boundary(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1);
+        }
+        if (!direct) { TRACE("sweep: deliver"); group_deliver(g, level, j); }
         TRACE("sweep: interior");
         for (mgcfd_solver *s : g->ranks) { s->use_device(); stage_interior(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1); }
     }
-    TRACE("sweep: last unpack");
-    for (mgcfd_solver *s : g->ranks) { s->use_device(); halo_finish(s, level, s->level(level).q, MGCFD_RK - 1); }
+    // (direct mode: the last stage's pushes went into the buffer that is `variables` now; whoever reads ghosts next waits for bdone[2])
+    if (!direct) { TRACE("sweep: last unpack"); for (mgcfd_solver *s : g->ranks) { s->use_device(); halo_finish(s, level, s->level(level).q, MGCFD_RK - 1); } }
     TRACE("sweep: issued");
 }
 
@@ -2158,7 +2274,22 @@ int mgcfd_group_exchange(mgcfd_group *g, int level)
 {
     REQUIRE(g);
     return guarded([&] {
-        for (mgcfd_solver *s : g->ranks) { s->use_device(); DeviceLevel &lv = s->level(level); if (!lv.hx) throw std::invalid_argument("a rank has no halo lists"); halo_start(s, level, lv.q, 0); }
+        for (mgcfd_solver *s : g->ranks) if (!s->level(level).hx) throw std::invalid_argument("a rank has no halo lists");
+        group_prepare_direct(g, level);
+        if (g->ranks[0]->level(level).hx->direct) {
+            // every rank's owned `variables` into its peers' ghost slots; a peer's stream continues behind the pushes into it
+            for (mgcfd_solver *s : g->ranks) {
+                s->use_device();
+                DeviceLevel &lv = s->level(level);
+                s->settle_residuals(lv);
+                wait_for_peers(g, s, level, 2);             // (nobody still reads the ghosts a peer is about to overwrite: their last sweep's last stage is behind this)
+                push_and_record(g, s, level, lv.q, [](DeviceLevel &pl) { return pl.q; }, 2);
+                lv.min_ahead = false;
+            }
+            for (mgcfd_solver *s : g->ranks) { s->use_device(); wait_for_peers(g, s, level, 2); }
+            return;
+        }
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); DeviceLevel &lv = s->level(level); halo_start(s, level, lv.q, 0); }
         group_deliver(g, level, 0);
         for (mgcfd_solver *s : g->ranks) { s->use_device(); DeviceLevel &lv = s->level(level); halo_finish(s, level, lv.q, 0); lv.min_ahead = false; }
     });
@@ -2183,6 +2314,7 @@ int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps)
             for (mgcfd_solver *src : g->ranks) ptrs.push_back(src->level(level).min_dt);
             hx.peer_scalars = dev_upload(ptrs);
         }
+        group_prepare_direct(g, level);
         HaloExchange &h0 = *s0->level(level).hx;
         bool timing = false;
         for (mgcfd_solver *s : g->ranks) timing = timing || s->opt_timing != 0;
@@ -2237,6 +2369,8 @@ int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps)
                 group_sweep_once(g, level);
             }
         }
+        // direct mode: the last stage's pushes land in the peers' `variables`; a rank's stream goes on only behind the pushes into it
+        if (h0.direct) for (mgcfd_solver *s : g->ranks) { s->use_device(); wait_for_peers(g, s, level, 2); }
         if (replayed) {
             // ... and what the other ranks' streams are given next must wait for the graphs
             s0->use_device();

@@ -370,7 +370,11 @@ int mgcfd_rank_residual_sumsq(mgcfd_solver *s, int level, double *sum_all_ranks)
 int mgcfd_group_create(int n, mgcfd_solver *const *solvers, mgcfd_group **out);   /* solvers[r] becomes rank r of n */
 void mgcfd_group_destroy(mgcfd_group *g);
 int mgcfd_group_exchange(mgcfd_group *g, int level);
-int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps);
+int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps);   /* asynchronous; a host thread per rank issues that rank's launches */
+/* The same with calc_rms (src/Kernels/validation.cpp:91-105) after every sweep — the reference's cycle loop prints it per
+ * cycle, src/euler3d_cpu_double.cpp:383-508 — gathered on the devices and read back ONCE: rms_of_each[k] = RMS after
+ * sweep k.  At most 4096 sweeps per call.  Synchronises. */
+int mgcfd_group_sweeps_rms(mgcfd_group *g, int level, int sweeps, double *rms_of_each);
 int mgcfd_group_rms(mgcfd_group *g, int level, double *rms);
 int mgcfd_group_synchronize(mgcfd_group *g);
 

@@ -249,13 +249,17 @@ static void hand_over(Run::Impl *p, int level, int which, int src, int dst, bool
 int Run::run_cycles(int cycles, double *rms_out)
 {
     const int n = p->levels, w = ranks();
-    for (int c = 0; c < cycles; c++) {
-        if (p->partitioned) {
-            check(mgcfd_group_sweeps(p->group, 0, 1), "a partitioned sweep");
-            double rms = 0.0;
-            check(mgcfd_group_rms(p->group, 0, &rms), "the RMS");
-            if (rms_out) rms_out[c] = rms;
-        } else {
+    if (p->partitioned) {
+        // the whole batch inside the library: a host thread per rank, the RMS of every cycle read back once
+        std::vector<double> rms(static_cast<size_t>(std::max(cycles, 1)));
+        for (int c = 0; c < cycles; c += 4096) {
+            const int n_now = std::min(4096, cycles - c);
+            check(mgcfd_group_sweeps_rms(p->group, 0, n_now, rms.data() + c), "the partitioned sweeps");
+        }
+        if (rms_out) std::copy(rms.begin(), rms.begin() + cycles, rms_out);
+    }
+    for (int c = 0; c < cycles && !p->partitioned; c++) {
+        {
             auto owner = [&](int l) { return l % w; };
             for (int l = 0; l < n; l++) {
                 mgcfd_solver *s = p->solvers[static_cast<size_t>(owner(l))];

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,8 +16,10 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -1986,24 +1989,29 @@ static void group_prepare_direct(mgcfd_group *g, int level)
 // which of a rank's three state buffers a stage writes (as stage_boundary / stage_interior name them)
 static double *stage_out_buffer(DeviceLevel &lv, int j) { return j == 1 ? lv.old_variables : lv.q_alt; }
 
-// the nodes the peers need of `field` (this rank's buffer) into the peers' buffers `peer_field(peer level)`, then the event
+// where a rank's push goes: the buffer `peer_field(peer's level)` of every peer, the peers' segments of the message
 template <typename PeerField>
-static void push_and_record(mgcfd_group *g, mgcfd_solver *s, int level, const double *field, PeerField &&peer_field, int ev)
+static PushPeers make_push_peers(mgcfd_group *g, mgcfd_solver *s, int level, PeerField &&peer_field)
+{
+    HaloExchange &hx = *s->level(level).hx;
+    PushPeers pp;
+    pp.n = static_cast<int>(hx.peer.size());
+    for (int k = 0; k < pp.n; k++) {
+        DeviceLevel &pl = g->ranks[static_cast<size_t>(hx.peer[static_cast<size_t>(k)])]->level(level);
+        pp.base[k] = peer_field(pl);
+        pp.stride[k] = pl.dp.stride;
+        pp.first[k] = hx.send_off[static_cast<size_t>(k)];
+    }
+    pp.first[pp.n] = hx.total_send();
+    return pp;
+}
+
+// the nodes the peers need of `field` (this rank's buffer) into the peers' buffers, then the event
+static void push_and_record(mgcfd_solver *s, int level, const double *field, const PushPeers &pp, int ev)
 {
     DeviceLevel &lv = s->level(level);
     HaloExchange &hx = *lv.hx;
-    if (hx.total_send() > 0) {
-        PushPeers pp;
-        pp.n = static_cast<int>(hx.peer.size());
-        for (int k = 0; k < pp.n; k++) {
-            DeviceLevel &pl = g->ranks[static_cast<size_t>(hx.peer[static_cast<size_t>(k)])]->level(level);
-            pp.base[k] = peer_field(pl);
-            pp.stride[k] = pl.dp.stride;
-            pp.first[k] = hx.send_off[static_cast<size_t>(k)];
-        }
-        pp.first[pp.n] = hx.total_send();
-        exact::launch_halo_push(s->stream, hx.total_send(), lv.dp.stride, hx.send_idx, hx.push_target, field, pp);
-    }
+    if (hx.total_send() > 0) exact::launch_halo_push(s->stream, hx.total_send(), lv.dp.stride, hx.send_idx, hx.push_target, field, pp);
     HIP_CHECK(hipEventRecord(hx.bdone[ev], s->stream));
 }
 
@@ -2013,8 +2021,10 @@ static void wait_for_peers(mgcfd_group *g, mgcfd_solver *s, int level, int ev)
     for (int p : hx.peer) HIP_CHECK(hipStreamWaitEvent(s->stream, g->ranks[static_cast<size_t>(p)]->level(level).hx->bdone[ev], 0));
 }
 
-// part 1 of a stage in direct mode (part 2 is stage_interior as it is)
-static void stage_boundary_direct(mgcfd_group *g, mgcfd_solver *s, int level, int j, int apply_min, const double *min_list, int n_min)
+// part 1 of a stage in direct mode (part 2 is stage_interior as it is); `to` = where the push goes (nullptr: the peers'
+// buffers as they are named now — one host thread drives the group, nobody has rotated since the stage began)
+static void stage_boundary_direct(mgcfd_group *g, mgcfd_solver *s, int level, int j, int apply_min, const double *min_list, int n_min,
+                                  const PushPeers *to = nullptr)
 {
     DeviceLevel &lv = s->level(level);
     HaloExchange &hx = *lv.hx;
@@ -2029,8 +2039,93 @@ static void stage_boundary_direct(mgcfd_group *g, mgcfd_solver *s, int level, in
     s->force_check = s->next_check();
     s->op_fused_stage(level, j, in, out, j == 0 ? apply_min : 0, j == 2, start, j == 2 && apply_min != 0 && part_look_ahead(), false, nullptr, hx.tiles_boundary, hx.n_boundary, true, min_list, n_min);
     lv.stage_out = out;
-    push_and_record(g, s, level, out, [&](DeviceLevel &pl) { return stage_out_buffer(pl, j); }, j);
+    push_and_record(s, level, out, to ? *to : make_push_peers(g, s, level, [&](DeviceLevel &pl) { return stage_out_buffer(pl, j); }), j);
 }
+
+// ---- a host thread per rank ---------------------------------------------------------------------------------------------
+// One thread issuing every rank's calls costs the host N x ~67 us per sweep (launches 3.5 us, event records and waits 4-5 us
+// each on ROCm) — more than the kernels of a rank take.  In direct mode every rank's calls touch only its own stream, its
+// own events and its own solver, so each rank gets a thread of its own.  What the threads must agree on is the ORDER of
+// event records and waits (a wait refers to the event's most recent record at the time of the call): a barrier after the
+// first half of compute_step_factor and after every stage puts each record ahead of the waits for it.
+namespace {
+struct SpinBarrier {
+    explicit SpinBarrier(int n) : n_(n) {}
+    void wait()
+    {
+        const unsigned gen = gen_.load(std::memory_order_acquire);
+        if (count_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
+            count_.store(0, std::memory_order_relaxed);
+            gen_.fetch_add(1, std::memory_order_release);
+        } else {
+            for (int spins = 0; gen_.load(std::memory_order_acquire) == gen; spins++)
+                if (spins > 4000) std::this_thread::yield();
+        }
+    }
+    std::atomic<int> count_{0};
+    std::atomic<unsigned> gen_{0};
+    const int n_;
+};
+}
+
+// `sweeps` sweeps of every rank, a thread per rank (the calling thread takes rank 0).  with_rms: after every sweep each rank
+// appends the sum of its owned nodes' squared residuals to its ring (mgcfd_solver::rms_ring) for one read-back at the end.
+static void group_sweeps_threaded(mgcfd_group *g, int level, int sweeps, bool with_rms)
+{
+    const int n = static_cast<int>(g->ranks.size());
+    SpinBarrier bar(n);
+    std::atomic<bool> failed{false};
+    std::mutex mu;
+    std::exception_ptr first_error;
+    const bool global_dt = g->ranks[0]->mesh_variant != MGCFD_MESH_FVCORR;
+    auto run = [&](int r) {
+        mgcfd_solver *s = g->ranks[static_cast<size_t>(r)];
+        // (a rank that failed keeps arriving at the barriers, doing nothing, so that the others are not left waiting)
+        auto step = [&](auto &&body) {
+            if (failed.load(std::memory_order_acquire)) return;
+            try { body(); }
+            catch (...) { std::lock_guard<std::mutex> lock(mu); if (!first_error) first_error = std::current_exception(); failed.store(true, std::memory_order_release); }
+        };
+        step([&] { s->use_device(); });
+        DeviceLevel &lv = s->level(level);
+        HaloExchange &hx = *lv.hx;
+        for (int k = 0; k < sweeps; k++) {
+            step([&] {
+                sweep_first_half(s, level);
+                if (global_dt) HIP_CHECK(hipEventRecord(hx.reduced, s->stream));
+            });
+            bar.wait();
+            PushPeers to[MGCFD_RK];
+            step([&] {
+                if (global_dt) {
+                    for (mgcfd_solver *src : g->ranks) if (src != s) HIP_CHECK(hipStreamWaitEvent(s->stream, src->level(level).hx->reduced, 0));
+                    exact::launch_min_over_peers(s->stream, hx.peer_scalars, n, hx.gmin);
+                }
+                // the peers' buffers of this sweep's three stages, read while nobody rotates (a rank rotates in its last stage's
+                // second part, two barriers from here; its previous rotation lies before the barrier just passed)
+                for (int j = 0; j < MGCFD_RK; j++) to[j] = make_push_peers(g, s, level, [&](DeviceLevel &pl) { return stage_out_buffer(pl, j); });
+            });
+            for (int j = 0; j < MGCFD_RK; j++) {
+                step([&] {
+                    stage_boundary_direct(g, s, level, j, global_dt ? 3 : 0, hx.gmin, 1, &to[j]);
+                    stage_interior(s, level, j, global_dt ? 3 : 0, hx.gmin, 1);
+                });
+                bar.wait();
+            }
+            if (with_rms) step([&] {
+                exact::launch_sumsq(s->stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
+                exact::launch_append_scalar(s->stream, lv.sumsq, s->rms_ring, s->rms_count, mgcfd_solver::kRmsRing);
+            });
+        }
+        step([&] { wait_for_peers(g, s, level, 2); HIP_CHECK(hipGetLastError()); });
+    };
+    std::vector<std::thread> threads;
+    for (int r = 1; r < n; r++) threads.emplace_back(run, r);
+    run(0);
+    for (std::thread &t : threads) t.join();
+    if (first_error) std::rethrow_exception(first_error);
+}
+
 
 // one sweep of every rank of an in-process group
 #define TRACE(msg) do { if (std::getenv("MGCFD_TRACE")) { std::fprintf(stderr, "[trace] %s\n", msg); std::fflush(stderr); } } while (0)
@@ -2283,7 +2378,7 @@ int mgcfd_group_exchange(mgcfd_group *g, int level)
                 DeviceLevel &lv = s->level(level);
                 s->settle_residuals(lv);
                 wait_for_peers(g, s, level, 2);             // (nobody still reads the ghosts a peer is about to overwrite: their last sweep's last stage is behind this)
-                push_and_record(g, s, level, lv.q, [](DeviceLevel &pl) { return pl.q; }, 2);
+                push_and_record(s, level, lv.q, make_push_peers(g, s, level, [](DeviceLevel &pl) { return pl.q; }), 2);
                 lv.min_ahead = false;
             }
             for (mgcfd_solver *s : g->ranks) { s->use_device(); wait_for_peers(g, s, level, 2); }
@@ -2295,10 +2390,12 @@ int mgcfd_group_exchange(mgcfd_group *g, int level)
     });
 }
 
-int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps)
+// rms_out (may be null): the RMS after each of the `sweeps` sweeps, read back once at the end (direct mode only)
+static int group_sweeps_impl(mgcfd_group *g, int level, int sweeps, double *rms_out)
 {
     REQUIRE(g);
     return guarded([&] {
+        if (rms_out && sweeps > mgcfd_solver::kRmsRing) throw std::invalid_argument("at most 4096 sweeps per call with the RMS of each");
         mgcfd_solver *s0 = g->ranks[0];
         for (mgcfd_solver *s : g->ranks) {
             s->use_device();
@@ -2318,6 +2415,66 @@ int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps)
         HaloExchange &h0 = *s0->level(level).hx;
         bool timing = false;
         for (mgcfd_solver *s : g->ranks) timing = timing || s->opt_timing != 0;
+        // direct mode: a host thread per rank (MGCFD_GROUP_THREADS=0: one thread issues everything, for A/B)
+        static const bool threads_wanted = !(std::getenv("MGCFD_GROUP_THREADS") && std::atoi(std::getenv("MGCFD_GROUP_THREADS")) == 0);
+        if (rms_out && !h0.direct) {
+            // the buffered form: the RMS read back after every sweep (as mgcfd_group_rms does it)
+            for (int k = 0; k < sweeps; k++) {
+                group_sweep_once(g, level);
+                double sum = 0.0;
+                int64_t nodes = 0;
+                for (mgcfd_solver *s : g->ranks) {
+                    s->use_device();
+                    DeviceLevel &lv = s->level(level);
+                    exact::launch_sumsq(s->stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
+                    double part = 0.0;
+                    HIP_CHECK(hipMemcpyAsync(&part, lv.sumsq, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+                    HIP_CHECK(hipStreamSynchronize(s->stream));
+                    sum += part;
+                    nodes += lv.n_owned;
+                }
+                rms_out[k] = std::sqrt(sum / double(nodes));
+            }
+            return;
+        }
+        // (the threads are started per call — ~50 us — so a call of one or two sweeps is issued by the caller's thread alone)
+        const bool threaded = threads_wanted && g->ranks.size() > 1 && sweeps >= 4;
+        if (h0.direct && (rms_out || threaded)) {
+            if (rms_out)
+                for (mgcfd_solver *s : g->ranks) {
+                    s->use_device();
+                    if (!s->rms_ring) { s->rms_ring = dev_alloc<double>(mgcfd_solver::kRmsRing); s->rms_count = dev_alloc<int>(1); }
+                    HIP_CHECK(hipMemsetAsync(s->rms_count, 0, sizeof(int), s->stream));
+                }
+            if (threaded) group_sweeps_threaded(g, level, sweeps, rms_out != nullptr);
+            else {
+                for (int k = 0; k < sweeps; k++) {
+                    group_sweep_once(g, level);
+                    if (rms_out)
+                        for (mgcfd_solver *s : g->ranks) {
+                            s->use_device();
+                            DeviceLevel &lv = s->level(level);
+                            exact::launch_sumsq(s->stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
+                            exact::launch_append_scalar(s->stream, lv.sumsq, s->rms_ring, s->rms_count, mgcfd_solver::kRmsRing);
+                        }
+                }
+                for (mgcfd_solver *s : g->ranks) { s->use_device(); wait_for_peers(g, s, level, 2); }
+            }
+            if (rms_out) {
+                // one read-back: the ranks' sums of every sweep, added in rank order as mgcfd_group_rms adds them
+                std::vector<double> sums(static_cast<size_t>(sweeps), 0.0), part(static_cast<size_t>(sweeps));
+                int64_t nodes = 0;
+                for (mgcfd_solver *s : g->ranks) {
+                    s->use_device();
+                    HIP_CHECK(hipMemcpyAsync(part.data(), s->rms_ring, sizeof(double) * static_cast<size_t>(sweeps), hipMemcpyDeviceToHost, s->stream));
+                    HIP_CHECK(hipStreamSynchronize(s->stream));
+                    for (int k = 0; k < sweeps; k++) sums[static_cast<size_t>(k)] += part[static_cast<size_t>(k)];
+                    nodes += s->level(level).n_owned;
+                }
+                for (int k = 0; k < sweeps; k++) rms_out[k] = std::sqrt(sums[static_cast<size_t>(k)] / double(nodes));
+            }
+            return;
+        }
         // One graph over all ranks' streams replays SLOWER than the eager calls on ROCm 7.2 (2 ranks: 301 against 262 us per
         // sweep; launching a graph of ~40 nodes on 4 streams costs the host 150 us), so groups capture only on request
         // (MGCFD_GROUP_GRAPH=1); a single rank's two-stream sweep does gain (mgcfd_rank_sweeps: 76 against 129 us).
@@ -2378,6 +2535,13 @@ int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps)
             for (mgcfd_solver *s : g->ranks) if (s != s0) { s->use_device(); HIP_CHECK(hipStreamWaitEvent(s->stream, h0.joined, 0)); }
         }
     });
+}
+
+int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps) { return group_sweeps_impl(g, level, sweeps, nullptr); }
+int mgcfd_group_sweeps_rms(mgcfd_group *g, int level, int sweeps, double *rms_of_each)
+{
+    REQUIRE(rms_of_each);
+    return group_sweeps_impl(g, level, sweeps, rms_of_each);
 }
 
 // calc_rms over the whole level: sqrt(sum over the ranks' owned nodes of residual^2 / owned nodes of all ranks).  Synchronises.

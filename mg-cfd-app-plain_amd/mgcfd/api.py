@@ -129,6 +129,7 @@ _SIGNATURES = [
     ("mgcfd_group_destroy", None, [_vp]),
     ("mgcfd_group_exchange", C.c_int, [_vp, C.c_int]),
     ("mgcfd_group_sweeps", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("mgcfd_group_sweeps_rms", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_group_rms", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_group_synchronize", C.c_int, [_vp]),
 ]
@@ -560,6 +561,12 @@ class Group:
 
     def exchange(self, l: int = 0): _check(self.lib, self.lib.mgcfd_group_exchange(self.handle, l))
     def sweeps(self, l: int = 0, n: int = 1): _check(self.lib, self.lib.mgcfd_group_sweeps(self.handle, l, n))
+
+    def sweeps_rms(self, l: int = 0, n: int = 1) -> np.ndarray:
+        """n sweeps, the RMS after each (read back once at the end)."""
+        out = np.zeros(max(n, 1), dtype=np.float64)
+        _check(self.lib, self.lib.mgcfd_group_sweeps_rms(self.handle, l, n, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out[:n]
     def synchronize(self): _check(self.lib, self.lib.mgcfd_group_synchronize(self.handle))
 
     def rms(self, l: int = 0) -> float:

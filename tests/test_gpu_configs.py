@@ -353,16 +353,35 @@ def _group_sweeps_check(mg, n_parts, sweeps, partitioner="rcb"):
         _bits_equal(s.get(0, "residuals")[:P.n_owned], want_res[own], f"part {P.rank}: residuals")
         _bits_equal(s.get(0, "step_factors")[:P.n_owned], want_sf[own], f"part {P.rank}: step factors")
     assert abs(g.rms(0) - want_rms) <= 1e-12 * want_rms
+    # ... and again from the start with the RMS of every sweep gathered on the devices (mgcfd_group_sweeps_rms: what the
+    # drop-in's --gpus N loop calls), against calc_rms of the whole level after each sweep
+    whole = mgcfd.Solver.from_arrays([L], mg.mesh_variant)
+    whole.set(0, "variables", q0)
+    want_each = []
+    for _ in range(sweeps):
+        whole.smooth(0, 1)
+        want_each.append(whole.calc_rms(0))
+    whole.close()
+    for P, s in zip(parts, solvers):
+        s.set(0, "variables", q0[P.global_ids])
+    g.exchange(0)
+    got_each = g.sweeps_rms(0, sweeps)
+    assert np.allclose(got_each, want_each, rtol=1e-12, atol=0.0), (got_each, want_each)
+    for P, s in zip(parts, solvers):
+        _bits_equal(s.get(0, "variables")[:P.n_owned], want_v[P.global_ids[:P.n_owned]], f"part {P.rank}: owned variables (second run)")
+        _bits_equal(s.get(0, "variables")[P.n_owned:], want_v[P.global_ids[P.n_owned:]], f"part {P.rank}: ghosts (second run)")
     g.close()
     for s in solvers:
         s.close()
 
 
-@pytest.mark.parametrize("kind,n_parts", [("lattice", 2), ("lattice", 5), ("fvcorr", 3), ("tet", 4)])
-def test_library_runs_the_partitioned_sweeps_itself(kind, n_parts):
+@pytest.mark.parametrize("kind,n_parts,sweeps", [("lattice", 2, 3), ("lattice", 5, 3), ("fvcorr", 3, 3), ("tet", 4, 3),
+                                                 ("lattice", 5, 7), ("fvcorr", 3, 6), ("tet", 4, 5)])
+def test_library_runs_the_partitioned_sweeps_itself(kind, n_parts, sweeps):
     """mgcfd_group_sweeps (the C++ host's own loop over the ranks of one process) on small levels: a lattice, a
-    local-time-step (fvcorr) level, a tetrahedral level with long rows — three sweeps, owned nodes and ghosts bit for
-    bit against mgcfd_smooth on the whole level, RMS over the owned nodes of all parts."""
+    local-time-step (fvcorr) level, a tetrahedral level with long rows — owned nodes and ghosts bit for bit against
+    mgcfd_smooth on the whole level, RMS over the owned nodes of all parts.  Calls of four sweeps or more are issued by
+    a host thread per rank (a barrier per stage between them), shorter ones by the calling thread alone."""
     from mgcfd import meshgen
     if kind == "tet":
         mg = meshgen.make_tet_multigrid((5000,), "m6wing", seed=6)
@@ -370,15 +389,15 @@ def test_library_runs_the_partitioned_sweeps_itself(kind, n_parts):
         mg = meshgen.make_multigrid((14,), "fvcorr", seed=4, cavity_radius=0.01, volume_noise=0.02)
     else:
         mg = meshgen.make_multigrid((20,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
-    _group_sweeps_check(mg, n_parts, 3)
+    _group_sweeps_check(mg, n_parts, sweeps)
 
 
 def test_cfg5_eight_parts_library_loop():
     """BASELINE configs[4] at size with the sweep loop in the library: the 134^3 level in 8 parts as an in-process group
-    (all on this GPU), two sweeps, against mgcfd_smooth on the whole 2.4 M-node level."""
+    (all on this GPU), four sweeps — a host thread per rank —, against mgcfd_smooth on the whole 2.4 M-node level."""
     import bench
     mg, _ = bench.build_workload(bench.LATTICE_8X)
-    _group_sweeps_check(mg, 8, 2)
+    _group_sweeps_check(mg, 8, 4)
 
 
 def test_rccl_loads_and_a_one_rank_communicator_sweeps():

@@ -43,7 +43,7 @@ def main():
             T._partitioned_level_check(mg, variant, n_parts, partitioner, fused, sweeps=int(rng.integers(1, 4)), seed=seed)
             # ... and the same level by the library's own loop over an in-process group (mgcfd_group_sweeps)
             import test_gpu_configs as TC
-            TC._group_sweeps_check(mg, n_parts, int(rng.integers(1, 4)), partitioner=partitioner)
+            TC._group_sweeps_check(mg, n_parts, int(rng.integers(1, 7)), partitioner=partitioner)     # (4 and more: a host thread per rank)
             print(tag + (f" + hierarchy {[l.nel for l in hier.levels]}" if hier is not None else "") + ": ok", flush=True)
         except AssertionError as e:
             print(tag + ": MISMATCH " + str(e)[:200], flush=True)

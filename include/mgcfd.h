@@ -63,8 +63,8 @@ enum {
                                   3: as 2 for every sweep (reads back as 2) */
     MGCFD_OPT_INDIRECT_RW = 2, /* 1: also run the indirect_rw probe each RK stage, as the reference's main() does */
     MGCFD_OPT_CHECK_INVALID = 3, /* 1 (default): NaN / negativity check every RK stage (validation.cpp:107-138) */
-    MGCFD_OPT_FLUX_VARIANT = 4, /* -1 (default): automatic — 0 while a level's incidence rows fit the Infinity Cache,
-                                   1 beyond (about 1 M nodes).  Otherwise a bit set:
+    MGCFD_OPT_FLUX_VARIANT = 4, /* -1 (default): automatic — 1 (the edge-length factor recomputed: never slower on an
+                                   MI355X, faster once a level's rows outgrow the Infinity Cache).  Otherwise a bit set:
                                    bit 0: 0 edge-length factor streamed, 1 recomputed from the weights;
                                    bit 1: 0 (default) node gather (every edge evaluated from both ends),
                                    2 edge-once tiles (every edge evaluated once per tile; levels whose tiles

@@ -107,7 +107,7 @@ struct DeviceLevel {
     double *tile_sumsq = nullptr;        // [n_tiles] per-tile sums of squares of the residuals, written by a last stage on request
     bool want_sumsq = false;             // the next fused sweep's last stage also fills tile_sumsq (cycle driver, level 0)
     bool have_sumsq = false;             // ... and did
-    int64_t row_bytes = 0;               // bytes of the incidence rows (ids + weights): decides the automatic flux variant
+    int64_t row_bytes = 0;               // bytes of the incidence rows (ids + weights)
     bool min_ahead = false;              // the launch that produced the CURRENT variables looked ahead: partial_min holds the
                                          // first half of compute_step_factor for them (global time step), or sf_alt holds
                                          // their step factors (mesh_name = fvcorr, local time step)
@@ -290,13 +290,14 @@ struct mgcfd_solver {
         lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;
         return apply_pending;
     }
-    // MGCFD_OPT_FLUX_VARIANT = -1 (auto): stream the edge-length factor while a level's incidence rows fit the
-    // Infinity Cache, recompute it from the weights (8 of 34 bytes per entry less) once they do not — measured
-    // cross-over at about 1 M nodes / 3 M edges (equal at 0.3-1.0 M nodes, +13 % at 1.5 M, +17 % at 2.4 M)
-    int variant_for(const DeviceLevel &lv) const
+    // MGCFD_OPT_FLUX_VARIANT = -1 (auto): the edge-length factor is recomputed from the weights (8 of 34 bytes per entry
+    // less to stream, one sqrt more per entry).  The fused stages run equally fast either way while a level's rows fit the
+    // Infinity Cache (bench level: 20.15 against 20.2 us) and 13-17 % faster without the stream beyond it (1.5-2.4 M
+    // nodes); the standalone flux launch gains at every size (bench level: 16.0-16.15 against 16.8-16.9 us).
+    int variant_for(const DeviceLevel &) const
     {
         if (opt_variant >= 0) return opt_variant;
-        return lv.row_bytes > (int64_t(192) << 20) ? 1 : 0;
+        return 1;
     }
     // classes: bit0 internal, bit1 solid wall (-1), bit2 far field (-2)
     void op_flux(int l, int classes)

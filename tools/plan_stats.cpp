@@ -18,6 +18,7 @@ int main(int argc, char **argv)
     mgcfd::build_level_plan(d, edges, opt, P);
     std::printf("nel %ld tiles %d halo mean %.1f max %d overflow refs %ld tail %d edge_once %d\n", (long)d.nel, P.n_tiles, P.halo_mean, P.halo_max,
                 (long)P.halo_overflow_refs, int(P.has_tail), int(P.edge_once));
+    std::printf("edges listed per tile: mean %.1f max %d (24 B each: %.1f KB at most)\n", P.te_mean, P.te_max, P.te_max * 24 / 1024.0);
     std::printf("half %d evaluations %ld (%.2f per node) foreign %ld padding %ld (%.1f %%)\n", int(P.half), (long)P.hr_entries, double(P.hr_entries) / d.nel,
                 (long)P.hr_foreign, (long)P.hr_padding, P.hr_entries ? 100.0 * P.hr_padding / P.hr_entries : 0.0);
     {   // how scattered the halo gathers are: distinct 128-byte blocks (16 consecutive ids) per tile, per field

@@ -13,6 +13,7 @@ ap.add_argument("--sizes", default="67,55,48,43")
 ap.add_argument("--cycles", type=int, default=25)
 ap.add_argument("--repeats", type=int, default=3)
 ap.add_argument("--fast", action="store_true")
+ap.add_argument("--variant", type=int, default=-1, help="MGCFD_OPT_FLUX_VARIANT")
 ap.add_argument("--timers", action="store_true", help="per-loop hipEvent timing (unfused, as the driver's default)")
 a = ap.parse_args()
 sizes = tuple(int(x) for x in a.sizes.split(","))
@@ -24,6 +25,7 @@ s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
 t2 = time.time()
 s.set_option("exact", 0 if a.fast else 1)
 s.set_option("timing", 1 if a.timers else 0)
+s.set_option("flux_variant", a.variant)
 s.run_cycles(2)
 best = 1e9
 for _ in range(a.repeats):

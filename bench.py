@@ -57,6 +57,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_COPY_GBS = 6290.0        # ... and what a device-to-device copy measures there ("report both")
 LATTICE = 67                 # 67^3 = 300,763 nodes, 888,822 internal edges
 LATTICE_8X = 134             # the level tiled 8x (connected): 2,406,104 nodes / 7,164,444 internal edges
 HIERARCHY = (67, 55, 48, 43) # 300,763 / 166,375 / 110,592 / 79,507 nodes
@@ -511,6 +512,7 @@ def main():
                     "traffic": traffic.get("flux_only", {}).get("bytes"),
                     "traffic_source": (f"{TRAFFIC_PROFILE} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes; build {traffic.get('build')})"
                                        if traffic else None),
+                    "frac_of_measured_copy_rate": round(ach / HBM_COPY_GBS, 4), "measured_copy_rate": HBM_COPY_GBS,
                     "kernel": "compute_flux_edge + boundary + far-field faces in one launch (writes fluxes[], no time_step): the kernel BASELINE's 60 % target names",
                     "launches": ROOFLINE_LAUNCHES, "avg_kernel_us": round(flux_only * 1e6, 3), "algorithmic_bytes_per_launch": bytes_flux,
                     "algorithmic_bytes": "40 B per internal edge + 80 B per node (SURVEY.md §8d)",

@@ -1693,7 +1693,8 @@ k_restrict(int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine, const
            SumTask rms /* .partial != nullptr: the last workgroup also adds up the fine level's per-tile sums of squares
                           (calc_rms of the sweep just finished) — the launch that would do only that is saved */)
 {
-    const int64_t c = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    // (coarse tiles next to each other read children next to each other: one XCD's L2 per contiguous range of them)
+    const int64_t c = xcd_contiguous_block(blockIdx.x, gridDim.x) * int64_t(kBlock) + threadIdx.x;
     double sf = __longlong_as_double(0x7FF0000000000000LL);          // +inf
     if (c < nel_coarse) {
         // The first four children come from a fixed-stride table (-1 padded): their ids need no
@@ -1827,7 +1828,7 @@ k_prolong_tile(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t
                double *__restrict__ fine_q, const double *__restrict__ cbrt_vol, double *__restrict__ partial_min)
 {
     __shared__ double cr[kProCap * 5];
-    const unsigned t = blockIdx.x;
+    const unsigned t = xcd_contiguous_block(blockIdx.x, gridDim.x);   // neighbouring tiles (they share coarse parents) on one XCD's L2
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int64_t i = int64_t(t) * kTile + tid;
@@ -1855,6 +1856,11 @@ k_prolong_tile(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t
     const double f0 = fine_residuals[ii], f1 = fine_residuals[stride + ii], f2 = fine_residuals[2 * stride + ii],
                  f3 = fine_residuals[3 * stride + ii], f4 = fine_residuals[4 * stride + ii];
     const double ws = pro_wsum[ii];
+    // the first row pair's entries go out before the staging barrier too (they do not depend on the staged residuals)
+    const double *wr = pro_w + (int64_t(row0) << 7) + lane;
+    const uint16_t *sr = pro_s16 + (int64_t(row0) << 6) + lane;
+    double wa0 = wr[0], wb0 = wr[64], wa1 = wr[128], wb1 = wr[192];
+    uint32_t sl0 = sr[0], sl1 = sr[64];
     __syncthreads();
 
     const double *od = cr + own_slot * 5;
@@ -1866,10 +1872,6 @@ k_prolong_tile(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t
         r0 = r1 = r2 = r3 = r4 = 0.0;
         // entries two rows ahead of their use (the arrays end in padding rows, so the reads past a
         // slice's last row are in bounds and nothing is conditional)
-        const double *wr = pro_w + (int64_t(row0) << 7) + lane;
-        const uint16_t *sr = pro_s16 + (int64_t(row0) << 6) + lane;
-        double wa0 = wr[0], wb0 = wr[64], wa1 = wr[128], wb1 = wr[192];
-        uint32_t sl0 = sr[0], sl1 = sr[64];
 #define MGCFD_PRO_PAIR(R)                                                                                      \
         do {                                                                                                   \
             const bool v0 = wa0 != 0.0 || wb0 != 0.0;                                                          \

@@ -299,6 +299,39 @@ def test_cfg4_one_level_per_solver_at_full_size(oracle):
     torch.cuda.set_stream(torch.cuda.default_stream())
 
 
+def test_bench_line_at_the_drivers_arguments():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` — what the driver runs — prints ONE JSON line with the contract's
+    fields: BASELINE's metric and unit, whole-job value, steps / warmup echoed, the roofline object of the flux kernel
+    (HBM bound, achieved / peak / frac consistent, traffic named with the profile it came from), the V-cycle leg and the
+    CPU baseline of the same level (bounded sample)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("Medges/s (compute_flux_edge)") and d["unit"] == "Medges/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert 30000 < d["value"] < 80000 and abs(d["value"] - 3 * 888822 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_kernel_us"] * 1e-6) / 1e9) < 1.0
+    assert roof["algorithmic_bytes_per_launch"] == 40 * 888822 + 80 * 300763
+    assert 0.3 < roof["frac"] < 0.8 and 10.0 < roof["empirical_ceiling_us"] < roof["avg_kernel_us"]
+    assert roof["traffic"] is None or (roof["traffic"] >= roof["algorithmic_bytes_per_launch"] and "profiles/" in roof["traffic_source"])
+    assert roof["fused_stage"]["launches"] == 60
+    assert 0.0002 < d["vcycle"]["wall_s_per_cycle"] < 0.001
+    cpu = d["cpu_baseline"]
+    assert cpu["unit"] == "Medges/s" and cpu["cores"] == 1 and cpu["kind"] in ("reference", "port") and cpu["value"] > 1 and cpu["sample"] and cpu["cpu_model"]
+
+
 def test_bench_rehearsal_two_ranks_on_this_gpu():
     """`python bench.py --gpus 2` from a plain invocation starts two ranks itself (here both on device 0 with gloo
     collectives: MGCFD_BENCH_REHEARSAL=1, a functional rehearsal of the N > 1 path, not a measurement) and reports

@@ -165,7 +165,7 @@ struct mgcfd_solver {
     bool in_timed_group = false;
     struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; bool ahead_after = false; int rot_after = 0; int sf_par_after = 0; bool sumsq_after = false, res_stale_after = false; };
     std::map<uint64_t, SweepGraph> sweep_graphs;   // captured smoothing sweeps, keyed by (level, options)
-    struct CycleGraph { hipGraphExec_t exec = nullptr; std::vector<std::vector<int64_t>> iters; std::vector<bool> ahead_after; std::vector<int> rot_after, sf_par_after; };
+    struct CycleGraph { hipGraphExec_t exec = nullptr; std::vector<std::vector<int64_t>> iters; std::vector<bool> ahead_after, res_stale_after; std::vector<int> rot_after, sf_par_after; };
     std::map<uint64_t, CycleGraph> cycle_graphs;   // captured whole multigrid cycles, keyed by options
     static constexpr int kRmsRing = 4096;
     double *rms_ring = nullptr;                    // level-0 sum of squares of the cycles run since the last read-back
@@ -1332,11 +1332,12 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
                     if (it == s->cycle_graphs.end()) {
                         mgcfd_solver::CycleGraph g;
                         std::vector<std::vector<int64_t>> before(nl);
-                        std::vector<bool> ahead_before;
+                        std::vector<bool> ahead_before, stale_before;
                         std::vector<int> rot_before, sf_before;
                         for (size_t l = 0; l < nl; l++) {
                             before[l].assign(s->L[l].iters, s->L[l].iters + MGCFD_NUM_LOOPS);
                             ahead_before.push_back(s->L[l].min_ahead);
+                            stale_before.push_back(s->L[l].residuals_stale);
                             rot_before.push_back(s->L[l].rot);
                             sf_before.push_back(s->L[l].sf_par);
                         }
@@ -1361,6 +1362,8 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
                             g.ahead_after.push_back(s->L[l].min_ahead);
                             g.rot_after.push_back(s->L[l].rot);
                             g.sf_par_after.push_back(s->L[l].sf_par);
+                            g.res_stale_after.push_back(s->L[l].residuals_stale);
+                            s->L[l].residuals_stale = stale_before[l];
                             s->L[l].min_ahead = ahead_before[l];          // nothing ran yet: capture only recorded
                             s->L[l].rot = rot_before[l];
                             s->L[l].apply_rot();
@@ -1373,6 +1376,7 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
                     for (size_t l = 0; l < nl; l++) {
                         for (int k = 0; k < MGCFD_NUM_LOOPS; k++) s->L[l].iters[k] += it->second.iters[l][static_cast<size_t>(k)];
                         s->L[l].min_ahead = it->second.ahead_after[l];
+                        s->L[l].residuals_stale = it->second.res_stale_after[l];   // (a single level's cycle leaves its residual unwritten)
                         s->L[l].rot = it->second.rot_after[l];
                         s->L[l].apply_rot();
                         s->L[l].sf_par = it->second.sf_par_after[l];

@@ -585,7 +585,7 @@ def test_old_variables_hold_the_sweep_start_state(mesh3_dir, fvcorr_dir, fuse):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("then", ["set_variables", "time_step", "copy_old", "unfused_sweep", "split_sweep", "cycles", "graph_sweep",
-                                  "written_from_outside", "bench_flux", "nothing"])
+                                  "written_from_outside", "bench_flux", "cycle_graph_replay", "nothing"])
 def test_unwritten_residual_is_written_before_its_operands_change(fvcorr_dir, then, monkeypatch):
     """On a single-level run the last stage of a fused sweep does not write residuals[] (the next sweep would overwrite it
     unread); the library writes it on demand from `variables` and the sweep's start state.  Whatever changes either
@@ -627,6 +627,14 @@ def test_unwritten_residual_is_written_before_its_operands_change(fvcorr_dir, th
                 s.array_devptr(0, "variables"); s.array_written(0, "variables")
             elif then == "bench_flux":
                 s.bench_flux(0, 2); s.zero_fluxes(0)
+            elif then == "cycle_graph_replay":
+                # cycles captured into graphs (their last stage leaves the residual unwritten), a sweep that WRITES its residual,
+                # then the same graphs replayed: the replay must mark the residual unwritten again (tools/fuzz_ops.py seed 1082)
+                s.set_option("graph", 1); s.run_cycles(3)
+                s.sweep_begin(0)
+                for j in range(3):
+                    s.sweep_stage(0, j, partials=False)
+                s.run_cycles(3)
             names = ["residuals", "variables", "old_variables", "step_factors"]
             if then not in ("split_sweep",):
                 names.append("fluxes")

@@ -621,7 +621,9 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                 int32_t rows_h[kTile / kSlice] = {0};
                 int32_t cap_total = 0;
                 for (int32_t sl = 0; sl < kTile / kSlice; sl++) {
-                    rows_h[sl] = lanes[sl] ? own_slice[sl] / lanes[sl] : 0;                 // floor of the slice's mean
+                    // floor of the slice's mean — never more than a lane keeps in registers (k_flux_half walks kHalfMaxRows half
+                    // rows at most: what a slice cannot hold goes to the other slices' lanes, or the level runs the node gather)
+                    rows_h[sl] = lanes[sl] ? std::min<int32_t>(kHalfMaxRows, own_slice[sl] / lanes[sl]) : 0;
                     cap_total += rows_h[sl] * lanes[sl];
                 }
                 while (cap_total < n_eval) {

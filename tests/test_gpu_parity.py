@@ -503,6 +503,46 @@ def test_randomised_operation_sequences(seed):
     assert len(log) >= 2
 
 
+@pytest.mark.gpu
+def test_half_rows_never_exceed_what_a_lane_keeps():
+    """tools/fuzz_partitioned.py seed 2070: a part of a small tetrahedral level — 87 owned nodes of degree up to 17 in one
+    tile, no long rows — whose first slice owns eleven evaluations per lane.  The half-row plan used to give that slice
+    eleven half rows although k_flux_half keeps five per lane (the rest were never evaluated: garbage fluxes); now the
+    surplus goes to the other slices' lanes or the level runs the node gather.  Half rows (variant 32) must write the node
+    gather's bits on every part."""
+    import os
+    import sys
+    import mgcfd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity
+    from mgcfd.partition import partition_level, rcb_partition
+    rng = np.random.default_rng(5000 + 2070)
+    while True:
+        kind, name, mg, _ = fuzz_parity.make_case(rng)
+        if name != "fvcorr" and 20 <= mg.levels[0].nel <= 5000:
+            break
+    assert kind == "tet" and mg.levels[0].nel == 260
+    L = mgcfd.generated_to_levels(mg)[0]
+    parts = partition_level(L, rcb_partition(np.asarray(L["coords"]), 3))
+    ff = None
+    with_half = 0
+    for P in parts:
+        out = {}
+        for v in (0, 32):
+            s = mgcfd.Solver.from_arrays([P.level], mg.mesh_variant, n_owned=[P.n_owned])
+            ff = s.far_field()[:5]
+            s.set_option("flux_variant", v)
+            s.set(0, "variables", perturbed_state(L["nel"], ff, seed=2070)[P.global_ids])
+            with_half += int(v == 32 and s.has_half_rows(0))
+            s.compute_fluxes(0)
+            out[v] = s.get(0, "fluxes")[:P.n_owned]
+            s.close()
+        assert np.array_equal(out[0].view(np.int64), out[32].view(np.int64)), P.rank
+    # (with the cap in place none of these three parts has room for its evaluations in five half rows per lane, so all
+    #  of them decline and run the node gather: with_half == 0; before the fix part 2 claimed half rows and wrote garbage)
+    assert with_half <= len(parts)
+
+
 def test_graph_replay_never_covers_unfused_sweeps(mesh3_dir):
     """MGCFD_OPT_GRAPH=1 with the two-phase flux variant (whose sweeps run unfused): a replayed sweep used to leave the
     host-side "fluxes are stale" flag unset, so mgcfd_get_array(fluxes) returned the last stage's fluxes instead of

@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd")); sys.path.insert(
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 
+ALWAYS_COMPARE = False
 ARRAYS = ("variables", "old_variables", "fluxes", "residuals", "step_factors")
 
 
@@ -34,6 +35,8 @@ class Mirror:
                                ni=lv["n_internal"], nb=lv["n_boundary"], nw=lv["n_wall"],
                                map=None if lv.get("mg_map") is None else np.ascontiguousarray(lv["mg_map"], dtype=np.int64), **st))
 
+    went_invalid = False                                    # some time_step left an invalid state: the reference would have exited
+
     def p(self, a):
         return self.o.ptr(a)
 
@@ -51,6 +54,12 @@ class Mirror:
     def time_step(self, l, j):
         L = self.L[l]
         self.lib.ora_time_step(j, L["nel"], self.p(L["step_factors"]), self.p(L["fluxes"]), self.p(L["old_variables"]), self.p(L["variables"]))
+        # check_for_invalid_variables runs after EVERY time_step (validation.cpp:107-138) and the reference exits there: an
+        # intermediate Runge-Kutta state may be invalid although the sweep's final state is fine again (every stage restarts
+        # from old_variables) — e.g. the first sweep after indirect_rw left its sums in fluxes[]
+        bad = C.c_int64(-1)
+        if self.lib.ora_check_for_invalid_variables(self.p(L["variables"]), L["nel"], C.byref(bad)) != 0:
+            self.went_invalid = True
 
     def copy_old(self, l):
         self.L[l]["old_variables"][:] = self.L[l]["variables"]
@@ -101,6 +110,7 @@ def run_seed(seed, n_ops, verbose=False):
     s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
     nl = len(levels)
     indirect = [0]
+    checking = [1]
     log = [f"{kind} {name} {[l.nel for l in mg.levels]}"]
 
     def compare(tag):
@@ -135,12 +145,13 @@ def run_seed(seed, n_ops, verbose=False):
                 if e.code not in (4, 5, 6):
                     raise
                 m.cycle()
-                bad = C.c_int64(-1)
-                if all(m.lib.ora_check_for_invalid_variables(m.p(x["variables"]), x["nel"], C.byref(bad)) == 0 for x in m.L):
-                    raise AssertionError(f"seed {seed}: the library reported {e} but the oracle's state is valid\n  " + "\n  ".join(log))
+                if not m.went_invalid:
+                    raise AssertionError(f"seed {seed}: the library reported {e} but no time_step of the oracle's cycle left an invalid state\n  " + "\n  ".join(log))
                 log.append(f"{k}: cycle went invalid on both sides: stop")
                 break
             m.cycle()
+            if m.went_invalid and checking[0]:
+                raise AssertionError(f"seed {seed}: a time_step of the oracle's cycle left an invalid state, mgcfd_run_cycles returned OK\n  " + "\n  ".join(log))
         elif op == "indirect_rw":
             L = m.L[l]
             s.indirect_rw(l); m.lib.ora_indirect_rw(0, L["ni"], m.p(L["edges"]), m.p(L["variables"]), m.p(L["fluxes"]))
@@ -164,9 +175,14 @@ def run_seed(seed, n_ops, verbose=False):
                 s.run_cycles(2)
             except mgcfd.MgcfdError as e:
                 if e.code not in (4, 5, 6): raise
-                log.append(f"{k}: cycles went invalid: stop")
+                m.cycle(); m.cycle()
+                if not m.went_invalid:
+                    raise AssertionError(f"seed {seed}: the library reported {e} but no time_step of the oracle's two cycles left an invalid state\n  " + "\n  ".join(log))
+                log.append(f"{k}: cycles went invalid on both sides: stop")
                 break
             m.cycle(); m.cycle()
+            if m.went_invalid and checking[0]:
+                raise AssertionError(f"seed {seed}: a time_step of the oracle's cycles left an invalid state, mgcfd_run_cycles returned OK\n  " + "\n  ".join(log))
         elif op == "staged_sweep":
             # the sweep one Runge-Kutta stage per call (mgcfd_sweep_stage, the form a partitioned level uses): after every
             # stage MGCFD_ARR_STAGE must hold what the reference's variables hold at that point
@@ -210,6 +226,7 @@ def run_seed(seed, n_ops, verbose=False):
             name_, val = [("fuse_update", int(rng.integers(2))), ("graph", int(rng.integers(2))), ("flux_variant", int(rng.choice([-1, 0, 1, 2, 3, 4, 16, 32]))),
                           ("check_invalid", int(rng.integers(2))), ("indirect_rw", int(rng.integers(2))), ("timing", int(rng.integers(3)))][int(rng.integers(6))]
             if name_ == "indirect_rw": indirect[0] = val
+            if name_ == "check_invalid": checking[0] = val
             s.set_option(name_, val); op = f"option {name_}={val}"
         elif op == "split_sweep":
             if not np.all(m.L[l]["fluxes"] == 0.0): continue        # (sweep_begin wants zero fluxes, as after time_step)
@@ -220,13 +237,17 @@ def run_seed(seed, n_ops, verbose=False):
             m.sweep(l)
         log.append(f"{k}: {op} level {l}")
         if verbose: print(log[-1], flush=True)
-        # a state that went invalid ends the sequence (the reference would have exited)
-        if any(not np.isfinite(m.L[x]["variables"]).all() or (m.L[x]["variables"][:, 0] <= 0).any() or (m.L[x]["variables"][:, 4] <= 0).any() for x in range(nl)):
+        # a state that went invalid — after any time_step inside the call — ends the sequence (the reference would have exited)
+        if m.went_invalid and checking[0] and op not in ("cycle", "cycles2"):
+            # ... and the library's launches carried the same check: its flag must be up (the calls above are asynchronous)
+            if s.check_for_invalid_variables(l)[0] == 0:
+                raise AssertionError(f"seed {seed}: a time_step of the oracle left an invalid state during {op}, the library reports none\n  " + "\n  ".join(log))
+        if m.went_invalid or any(not np.isfinite(m.L[x]["variables"]).all() or (m.L[x]["variables"][:, 0] <= 0).any() or (m.L[x]["variables"][:, 4] <= 0).any() for x in range(nl)):
             log.append("state invalid: stop")
             break
         # (any array read makes the library write a residual its last sweep left unwritten — single-level runs — so some calls
         #  go unchecked: the next call then meets the unwritten residual and must write it before it changes an operand)
-        if skip.random() < 0.6 or k == n_ops - 1:
+        if ALWAYS_COMPARE or skip.random() < 0.6 or k == n_ops - 1:
             compare(op)
     s.close()
     return log
@@ -238,7 +259,10 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--ops", type=int, default=40)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--always-compare", action="store_true", help="read every array back after every call (nothing stays unwritten between calls)")
     args = ap.parse_args()
+    global ALWAYS_COMPARE
+    ALWAYS_COMPARE = args.always_compare
     bad = 0
     for seed in range(args.first, args.first + args.seeds):
         try:

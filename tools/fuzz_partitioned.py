@@ -46,6 +46,7 @@ def main():
             TC._group_sweeps_check(mg, n_parts, int(rng.integers(1, 7)), partitioner=partitioner)     # (4 and more: a host thread per rank)
             print(tag + (f" + hierarchy {[l.nel for l in hier.levels]}" if hier is not None else "") + ": ok", flush=True)
         except AssertionError as e:
+            if os.environ.get("FUZZ_RAISE"): raise                  # (the traceback says which comparison it was)
             print(tag + ": MISMATCH " + str(e)[:200], flush=True)
             bad += 1
         except Exception as e:                              # (a random mesh whose state goes invalid: the reference would exit too)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised runs of the drop-in binary (GPU box): a random hierarchy written in the reference's file formats,
-euler3d_gpu_double with random flags (-g, -m, --no-timers, --legacy-ordering, --no-indirect-rw), its variables dump,
+euler3d_gpu_double with random flags (-g, -m, --no-timers, --legacy-ordering, --no-indirect-rw, --gpus N), its variables dump,
 RMS lines and LoopNumIters counts against the oracle reading the same files.
     python tools/fuzz_driver.py [--seeds 40] [--first 0]"""
 import argparse, os, shutil, subprocess, sys, tempfile
@@ -13,6 +13,7 @@ EXE = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
 def _one(seed, np, meshgen, oracle, fuzz_parity, read_loop_iters):
     bad = 0
     rng = np.random.default_rng(9000 + seed)
+    gpu_rng = np.random.default_rng(19000 + seed)           # (its own stream: the cases of the seeds stay as they were)
     while True:
         kind, name, mg, _ = fuzz_parity.make_case(rng)
         # the file format lists a level's coarser neighbour by index: keep hierarchies the reference itself accepts
@@ -25,6 +26,10 @@ def _one(seed, np, meshgen, oracle, fuzz_parity, read_loop_iters):
         dup = int(rng.choice([1, 1, 2, 3]))
         legacy = bool(rng.integers(2)) and dup == 1
         flags = [f for f, on in (("--no-timers", rng.integers(2)), ("--no-indirect-rw", rng.integers(2))) if on]
+        # several ranks (all on this one GPU): a single level is partitioned over them (halo stores after every stage, a host
+        # thread per rank), a hierarchy runs one level per rank
+        gpus = int(gpu_rng.choice([1, 1, 2, 3, 4]))
+        if gpus > 1: flags += ["--gpus", str(gpus), "--gpus-share-device"]
         cmd = [EXE, "-i", "input.dat", "-d", d, "-o", d + "/", "-g", str(cycles), "-m", str(dup), "--output-variables"] + flags + (["--legacy-ordering"] if legacy else [])
         tag = f"seed {seed}: {kind} {name} {[l.nel for l in mg.levels]} -g {cycles} -m {dup} {' '.join(flags)}{' --legacy-ordering' if legacy else ''}"
         oc = oracle.OracleCase.from_input_dat(os.path.join(d, "input.dat"), dup, legacy_ordering=legacy)

@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mg-cfd-app-plain_amd")); sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 EXE = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
+# the REFERENCE's own main() linked against libmgcfd_hip.so through the reference-side binding (oracle/build_ref_gpu_backend.sh;
+# built in the build container, travels with the repository): run on the same input where it exists
+EXE_BINDING = os.path.join(ROOT, "oracle", "_ref", "euler3d_ref_main_gpu_backend.b")
 
 
 def _one(seed, np, meshgen, oracle, fuzz_parity, read_loop_iters):
@@ -57,6 +60,25 @@ def _one(seed, np, meshgen, oracle, fuzz_parity, read_loop_iters):
                            "restrict": iters[l].restrict_, "prolong": iters[l].prolong}
                 if {k: got_it[l][k] for k in want_it} != want_it:
                     problems.append(f"LoopNumIters level {l}: {got_it[l]} vs {want_it}")
+        # (a single-level input that is not fvcorr: the reference never reads its .coords and aborts in adjust_ewt, SURVEY.md §7 —
+        #  the library and the oracle read them; nothing to compare there)
+        if os.path.exists(EXE_BINDING) and not legacy and not problems and (len(mg.levels) > 1 or name == "fvcorr"):
+            d2 = tempfile.mkdtemp(prefix="mgcfd_fuzz_b_")
+            try:
+                rb = subprocess.run([EXE_BINDING, "-i", "input.dat", "-d", d, "-o", d2 + "/", "-g", str(cycles), "-m", str(dup), "--output-variables"],
+                                    capture_output=True, text=True, cwd=d2, env=dict(os.environ, OMP_NUM_THREADS="1"))
+                if rb.returncode != 0:
+                    problems.append(f"reference main on the library: rc {rb.returncode}: {rb.stdout[-200:]}")
+                else:
+                    got_b = np.loadtxt(os.path.join(d2, f"variables.size={dup}x.cycles={cycles}.level=0")).reshape(-1, 5)
+                    if not np.array_equal(got_b.view(np.int64), np.ascontiguousarray(want).view(np.int64)):
+                        problems.append("reference main on the library: variables dump differs")
+                    lines_b = [l for l in rb.stdout.splitlines() if "RMS" in l]
+                    if len(lines_b) != cycles or any(f"(RMS = {rms[c]:.3e})" not in lines_b[c] for c in range(cycles)):
+                        problems.append("reference main on the library: RMS lines differ")
+                tag += " + reference main on the library"
+            finally:
+                shutil.rmtree(d2, ignore_errors=True)
         print(tag + (": ok" if not problems else ": MISMATCH " + "; ".join(problems)), flush=True)
         bad += 1 if problems else 0
     finally:

@@ -1134,7 +1134,7 @@ k_flux_half(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
             const uint16_t *__restrict__ nbr16, const double *__restrict__ w, FarField ff, double *__restrict__ fluxes,
             int classes, FusedStep fs)
 {
-    __shared__ double2 tile[kTileCap * kLdsRecD2];
+    __shared__ double2 tile[kTileCap * kLdsRecD2 > kHalfLdsD2 ? kTileCap * kLdsRecD2 : kHalfLdsD2];   // (the flux terms need a little more than the records)
 
     PH_BEGIN();
     double min_dt = 0.0;
@@ -1947,7 +1947,7 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     const dim3 grid(part ? fs.n_list : p.n_tiles);
     if (part && fs.n_list <= 0) return;
 
-    // 3 tiles of 52.5 KiB LDS fit a CU => at least 3 waves per SIMD wanted (168 registers).  The two long-row instantiations that
+    // 3 tiles of 52.4 KiB LDS fit a CU (preprocess.hpp: kTileCap) => at least 3 waves per SIMD wanted (168 registers).  The two long-row instantiations that
     // do not fit them — the kernel-granular '+=' launch and the split sweep's absorbed first stage, both off the sweep path —
     // are built for 2 waves per SIMD instead of spilling 20-36 bytes per lane.
 #define MGCFD_TILE_LAUNCH_T(WMODE, FUSE, ACC, ROLE, TAIL)                                                      \

@@ -20,7 +20,11 @@ namespace mgcfd {
 
 constexpr int kSlice = 64;   // wavefront width
 constexpr int kTile = 256;   // nodes per tile = one 256-thread workgroup = 4 slices
-constexpr int kTileCap = 560;   // node records a tile can stage in LDS (560 * 96 B = 52.5 KiB => 3 tiles per CU)
+// node records a tile can stage in LDS.  A CU's 160 KiB of LDS is handed out in granules (1,280 B as measured: a kernel that asks
+// for 53,760 B runs three workgroups per CU, one that asks for 53,792 runs TWO), and the stage kernels keep a few words beside
+// the records (per-wave minima and sums): 559 * 96 B = 53,664 B leaves them 96 B inside the 42nd granule.  With 560 records the
+// first and the last stage of every sweep ran at two workgroups per CU: 20.6 / 21.1 us against 18.3 / 19.1 (profiles/README.md).
+constexpr int kTileCap = 559;
 // edge-once tiles: a tile's internal edges are evaluated in chunks of one edge per thread; the
 // fluxes of up to kMaxEdgeChunks chunks wait in registers, then replace the node records in LDS
 // (kMaxEdgeChunks * 256 * 40 B must fit kTileCap * 96 B)
@@ -35,8 +39,8 @@ constexpr uint32_t kHalfForeign = 1u << 24;
 constexpr uint32_t kHalfPad = 0x00007FFFu;   // (low 15 bits = kT16Pad)
 constexpr int kHalfMaxRows = 5;            // half rows (edges a node evaluates) a thread keeps the results of in registers
 constexpr int kHalfTileRows = 21;          // half rows of a tile's four slices together (21 * 64 * 40 B = the whole LDS tile)
-constexpr int kHalfSlots = kHalfTileRows * kSlice;   // flux-term slots of a tile in LDS: 5 fields x 1344 x 8 B = 52.5 KiB
-static_assert(kHalfSlots * 40 <= kTileCap * 96, "the edge fluxes replace the node records in LDS");
+constexpr int kHalfSlots = kHalfTileRows * kSlice;   // flux-term slots of a tile in LDS: 5 fields x 1344 x 8 B = 52.5 KiB (its own array in k_flux_half)
+constexpr int kHalfLdsD2 = (5 * kHalfSlots + 1) / 2;   // double2 the half-row kernel's flux terms take in LDS (they replace the node records)
 static_assert(kMaxEdgeChunks * kEdgeChunk * 40 <= kTileCap * 96, "edge fluxes must fit the LDS tile");
 
 // neighbour codes in Sell::nbr

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
+#include <stdexcept>
 #include <stdint.h>
 
 #include "device_plan.hpp"
@@ -758,8 +759,14 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         // The last pair has nothing left to prefetch: in the fused stages the registers its prefetch would
         // have used take the time_step operands instead, which arrive while the pair is being summed.
         if (FUSE) {
-            r0 = fs.old_variables[i]; r1 = fs.old_variables[stride + i]; r2 = fs.old_variables[2 * stride + i];
-            r3 = fs.old_variables[3 * stride + i]; r4 = fs.old_variables[4 * stride + i];
+            if (ROLE == 0) {
+                // the first stage's input IS the sweep's start state (the launcher checks q == old_variables): the node's own
+                // record, live in registers for every edge anyway, holds the five values
+                r0 = me.rho; r1 = me.mx; r2 = me.my; r3 = me.mz; r4 = me.en;
+            } else {
+                r0 = fs.old_variables[i]; r1 = fs.old_variables[stride + i]; r2 = fs.old_variables[2 * stride + i];
+                r3 = fs.old_variables[3 * stride + i]; r4 = fs.old_variables[4 * stride + i];
+            }
             sfv = ((ROLE == 0 || ROLE == 5) ? fs.volumes : fs.step_factors)[i];
         }
         if (r < n_int) MGCFD_ROW_PAIR();
@@ -1967,6 +1974,8 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     } while (0)
     // fused stages: the role decides which optional paths exist in the launched kernel
     const int role = !fused ? 1 : (fs.vin_flux ? 5 : fs.partial_min ? 0 : (fs.next_partial_min ? 3 : (fs.next_legacy_sf ? 4 : (fs.residuals ? 2 : 1))));
+    // (role 0 takes the sweep's start state from its own record instead of loading old_variables)
+    if (role == 0 && q != fs.old_variables) throw std::logic_error("a first stage whose input is not the sweep's start state");
 #define MGCFD_TILE_LAUNCH(LOADK, FUSE, ACC)                                                                    \
     do {                                                                                                       \
         if (role == 0) MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, 0);                                               \

@@ -1966,7 +1966,7 @@ static void rank_sweep_once(mgcfd_solver *s, int level)
 static bool group_direct_wanted()
 {
     // (not together with group graphs, MGCFD_GROUP_GRAPH=1: the capture code joins the buffered form's streams)
-    static const bool on = !(std::getenv("MGCFD_GROUP_DIRECT") && std::atoi(std::getenv("MGCFD_GROUP_DIRECT")) == 0) &&
+    const bool on = !(std::getenv("MGCFD_GROUP_DIRECT") && std::atoi(std::getenv("MGCFD_GROUP_DIRECT")) == 0) &&
                            !(std::getenv("MGCFD_GROUP_GRAPH") && std::atoi(std::getenv("MGCFD_GROUP_GRAPH")) != 0);
     return on;
 }
@@ -2434,7 +2434,7 @@ static int group_sweeps_impl(mgcfd_group *g, int level, int sweeps, double *rms_
         bool timing = false;
         for (mgcfd_solver *s : g->ranks) timing = timing || s->opt_timing != 0;
         // direct mode: a host thread per rank (MGCFD_GROUP_THREADS=0: one thread issues everything, for A/B)
-        static const bool threads_wanted = !(std::getenv("MGCFD_GROUP_THREADS") && std::atoi(std::getenv("MGCFD_GROUP_THREADS")) == 0);
+        const bool threads_wanted = !(std::getenv("MGCFD_GROUP_THREADS") && std::atoi(std::getenv("MGCFD_GROUP_THREADS")) == 0);
         if (rms_out && !h0.direct) {
             // the buffered form: the RMS read back after every sweep (as mgcfd_group_rms does it)
             for (int k = 0; k < sweeps; k++) {

@@ -425,6 +425,19 @@ def test_library_runs_the_partitioned_sweeps_itself(kind, n_parts, sweeps):
     _group_sweeps_check(mg, n_parts, sweeps)
 
 
+@pytest.mark.parametrize("form", ["buffered", "one_thread"])
+def test_library_loop_in_its_other_forms(form, monkeypatch):
+    """The forms the group loop falls back to or can be switched to: messages through buffers, a second stream and
+    pack / copy / unpack (MGCFD_GROUP_DIRECT=0: more than eight peers, or a plan that mixes ghosts into the tiles), and one
+    host thread issuing every rank's launches (MGCFD_GROUP_THREADS=0) — same results, bit for bit."""
+    from mgcfd import meshgen
+    monkeypatch.setenv("MGCFD_GROUP_DIRECT" if form == "buffered" else "MGCFD_GROUP_THREADS", "0")
+    mg = meshgen.make_multigrid((20,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    _group_sweeps_check(mg, 4, 6)
+    mg = meshgen.make_multigrid((14,), "fvcorr", seed=4, cavity_radius=0.01, volume_noise=0.02)
+    _group_sweeps_check(mg, 3, 5)
+
+
 def test_cfg5_eight_parts_library_loop():
     """BASELINE configs[4] at size with the sweep loop in the library: the 134^3 level in 8 parts as an in-process group
     (all on this GPU), four sweeps — a host thread per rank —, against mgcfd_smooth on the whole 2.4 M-node level."""

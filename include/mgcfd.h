@@ -221,6 +221,11 @@ int mgcfd_calc_rms(mgcfd_solver *s, int level, double *rms);
 /* check_for_invalid_variables(); synchronises; returns MGCFD_OK or MGCFD_ERR_NAN/NEG_*;
  * *bad_cell = first offending cell in original numbering          validation.cpp:107-138 */
 int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_cell);
+/* What the checks INSIDE the launches issued so far have found (every time_step / fused stage carries the reference's
+ * check_for_invalid_variables; the calls themselves are asynchronous): MGCFD_OK or the first failing launch's class and
+ * cell.  Unlike mgcfd_check_for_invalid_variables it does not look at the current state — the reference checks after a
+ * time_step only, so a value a prolongation spoils after the last sweep goes unnoticed there too.  Synchronises; clears the flag. */
+int mgcfd_pending_invalid_state(mgcfd_solver *s, int64_t *bad_cell);
 /* mg_restrict(variables[fine] -> variables[fine+1])                 mg_loops.cpp:30-202 */
 int mgcfd_restrict(mgcfd_solver *s, int fine_level);
 /* prolong_residuals_interpolate_proper(residuals[fine+1] -> variables[fine])   mg_loops.cpp:678-864 */

@@ -1040,6 +1040,16 @@ int mgcfd_check_for_invalid_variables(mgcfd_solver *s, int level, int64_t *bad_c
     return code;
 }
 
+int mgcfd_pending_invalid_state(mgcfd_solver *s, int64_t *bad_cell)
+{
+    REQUIRE(s);
+    int code = MGCFD_OK;
+    int rc = guarded([&] { s->use_device(); code = s->read_error(bad_cell); });
+    if (rc != MGCFD_OK) return rc;
+    if (code != MGCFD_OK) g_last_error = "invalid variables detected";
+    return code;
+}
+
 // One smoothing sweep = the per-level body of the reference's cycle loop
 // (src/euler3d_cpu_double.cpp:383-508): copy, step factor, RK x (fluxes, time_step), residual.
 // Same operations, fewer passes over memory: the copy rides on the step-factor kernel, the

@@ -69,6 +69,7 @@ _SIGNATURES = [
     ("mgcfd_set_option", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mgcfd_level_has_edge_once", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_level_has_half_rows", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    ("mgcfd_pending_invalid_state", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("mgcfd_level_tiling", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
     ("mgcfd_invalid_state_location", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     ("mgcfd_get_option", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
@@ -399,6 +400,12 @@ class Solver:
     def check_for_invalid_variables(self, l):
         bad = _i64(-1)
         rc = self.lib.mgcfd_check_for_invalid_variables(self.handle, l, C.byref(bad))
+        return rc, bad.value
+
+    def pending_invalid_state(self):
+        """(code, cell) of what the checks inside the launches issued so far found; does not look at the current state."""
+        bad = _i64(-1)
+        rc = self.lib.mgcfd_pending_invalid_state(self.handle, C.byref(bad))
         return rc, bad.value
 
     def smooth(self, l: int, sweeps: int = 1):

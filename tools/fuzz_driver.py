@@ -13,6 +13,14 @@ EXE = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
 EXE_BINDING = os.path.join(ROOT, "oracle", "_ref", "euler3d_ref_main_gpu_backend.b")
 
 
+def same_bits_or_both_nan(np, got, want):
+    """Bit for bit — except that a NaN equals a NaN.  A run can END with a NaN the reference never reports (it checks after a
+    time_step only, and the last operation of a cycle is a prolongation: seed 10105); an x86 core then holds the negative
+    default NaN where a GPU holds the positive one ("-nan" against "nan" in the dump), which no arithmetic rule fixes."""
+    got, want = np.ascontiguousarray(got), np.ascontiguousarray(want)
+    return got.shape == want.shape and bool(np.all((got.view(np.int64) == want.view(np.int64)) | (np.isnan(got) & np.isnan(want))))
+
+
 def _one(seed, np, meshgen, oracle, fuzz_parity, read_loop_iters):
     bad = 0
     rng = np.random.default_rng(9000 + seed)
@@ -45,11 +53,11 @@ def _one(seed, np, meshgen, oracle, fuzz_parity, read_loop_iters):
             return bad
         problems = []
         if r.returncode != 0:
-            problems.append(f"driver rc {r.returncode}: {r.stdout[-200:]}")
+            problems.append(f"driver rc {r.returncode}: {r.stdout[-200:]} | {r.stderr[-400:]}")
         else:
             got = np.loadtxt(os.path.join(d, f"variables.size={dup}x.cycles={cycles}.level=0")).reshape(-1, 5)
             want = oc.array(0, "variables").reshape(-1, 5)
-            if not np.array_equal(got.view(np.int64), np.ascontiguousarray(want).view(np.int64)):
+            if not same_bits_or_both_nan(np, got, want):
                 problems.append("variables dump differs")
             lines = [l for l in r.stdout.splitlines() if "RMS" in l]
             if len(lines) != cycles or any(f"(RMS = {rms[c]:.3e})" not in lines[c] for c in range(cycles)):
@@ -71,7 +79,7 @@ def _one(seed, np, meshgen, oracle, fuzz_parity, read_loop_iters):
                     problems.append(f"reference main on the library: rc {rb.returncode}: {rb.stdout[-200:]}")
                 else:
                     got_b = np.loadtxt(os.path.join(d2, f"variables.size={dup}x.cycles={cycles}.level=0")).reshape(-1, 5)
-                    if not np.array_equal(got_b.view(np.int64), np.ascontiguousarray(want).view(np.int64)):
+                    if not same_bits_or_both_nan(np, got_b, want):
                         problems.append("reference main on the library: variables dump differs")
                     lines_b = [l for l in rb.stdout.splitlines() if "RMS" in l]
                     if len(lines_b) != cycles or any(f"(RMS = {rms[c]:.3e})" not in lines_b[c] for c in range(cycles)):

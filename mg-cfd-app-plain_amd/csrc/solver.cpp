@@ -1755,7 +1755,10 @@ struct mgcfd_comm {
     void *rccl = nullptr;                         // ncclComm_t (one rank per process)
     struct mgcfd_group *group = nullptr;          // or: the in-process group this solver is rank `rank` of
 };
-struct mgcfd_group { std::vector<mgcfd_solver *> ranks; };
+struct mgcfd_group {
+    std::vector<mgcfd_solver *> ranks;
+    bool peer_ok = true;                          // every device of the group can address every other one's memory (direct mode stores into it)
+};
 
 static std::map<mgcfd_solver *, mgcfd_comm> g_comms;     // (one host thread per solver; groups are driven by one thread)
 
@@ -1984,7 +1987,7 @@ static bool group_direct_wanted()
 // build the push targets of every rank (once; allocations and uploads never happen inside a sweep)
 static void group_prepare_direct(mgcfd_group *g, int level)
 {
-    bool possible = group_direct_wanted();
+    bool possible = group_direct_wanted() && g->peer_ok;   // (a kernel must never store into memory its device cannot address)
     for (mgcfd_solver *s : g->ranks) {
         DeviceLevel &lv = s->level(level);
         if (!lv.hx) throw std::invalid_argument("a rank has no halo lists");
@@ -2376,6 +2379,7 @@ int mgcfd_group_create(int n, mgcfd_solver *const *solvers, mgcfd_group **out)
                 int can = 0;
                 HIP_CHECK(hipDeviceCanAccessPeer(&can, solvers[a]->device, solvers[b]->device));
                 if (can) { solvers[a]->use_device(); const hipError_t e = hipDeviceEnablePeerAccess(solvers[b]->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_CHECK(e); (void)hipGetLastError(); }
+                else g->peer_ok = false;          // (messages then go through the buffered form: the runtime stages such a copy itself)
             }
         for (int r = 0; r < n; r++) {
             mgcfd_comm c;

@@ -2379,8 +2379,11 @@ int mgcfd_group_create(int n, mgcfd_solver *const *solvers, mgcfd_group **out)
                 int can = 0;
                 HIP_CHECK(hipDeviceCanAccessPeer(&can, solvers[a]->device, solvers[b]->device));
                 if (can) { solvers[a]->use_device(); const hipError_t e = hipDeviceEnablePeerAccess(solvers[b]->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_CHECK(e); (void)hipGetLastError(); }
-                else g->peer_ok = false;          // (messages then go through the buffered form: the runtime stages such a copy itself)
+                else g->peer_ok = false;
             }
+        // the group's all-reduce reads the other ranks' scalars in place and its messages are stores into the peers' memory:
+        // a kernel must never touch memory its device cannot address, so such a set of devices is refused here
+        if (!g->peer_ok) throw std::invalid_argument("the devices of an in-process group must have peer access to each other (use one rank per process over RCCL instead)");
         for (int r = 0; r < n; r++) {
             mgcfd_comm c;
             c.rank = r; c.world = n; c.group = g.get();

@@ -2159,11 +2159,9 @@ static void group_sweeps_threaded(mgcfd_group *g, int level, int sweeps, bool wi
 
 
 // one sweep of every rank of an in-process group
-#define TRACE(msg) do { if (std::getenv("MGCFD_TRACE")) { std::fprintf(stderr, "[trace] %s\n", msg); std::fflush(stderr); } } while (0)
 static void group_sweep_once(mgcfd_group *g, int level)
 {
     const int n = static_cast<int>(g->ranks.size());
-    TRACE("sweep: first halves");
     const bool global_dt = g->ranks[0]->mesh_variant != MGCFD_MESH_FVCORR;
     for (mgcfd_solver *s : g->ranks) { s->use_device(); sweep_first_half(s, level); }
     if (global_dt) {
@@ -2179,19 +2177,16 @@ static void group_sweep_once(mgcfd_group *g, int level)
     }
     const bool direct = g->ranks[0]->level(level).hx->direct;
     for (int j = 0; j < MGCFD_RK; j++) {
-        TRACE("sweep: stage boundary");
         for (mgcfd_solver *s : g->ranks) {
             s->use_device();
             if (direct) stage_boundary_direct(g, s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1);
             else stage_boundary(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1);
         }
-        if (!direct) { TRACE("sweep: deliver"); group_deliver(g, level, j); }
-        TRACE("sweep: interior");
+        if (!direct) group_deliver(g, level, j);
         for (mgcfd_solver *s : g->ranks) { s->use_device(); stage_interior(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1); }
     }
     // (direct mode: the last stage's pushes went into the buffer that is `variables` now; whoever reads ghosts next waits for bdone[2])
-    if (!direct) { TRACE("sweep: last unpack"); for (mgcfd_solver *s : g->ranks) { s->use_device(); halo_finish(s, level, s->level(level).q, MGCFD_RK - 1); } }
-    TRACE("sweep: issued");
+    if (!direct) for (mgcfd_solver *s : g->ranks) { s->use_device(); halo_finish(s, level, s->level(level).q, MGCFD_RK - 1); }
 }
 
 // The sweep as a hipGraph: the ~25 host calls a rank's sweep takes (launches, event records and waits, copies or RCCL
@@ -2213,11 +2208,8 @@ static bool capture_sweep(hipStream_t origin, const std::vector<std::pair<hipStr
     } catch (...) {
         ok = false;
     }
-    TRACE("capture: end");
     if (hipStreamEndCapture(origin, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); ok = false; }
-    TRACE(ok ? "capture: instantiate" : "capture: FAILED");
     if (ok && hipGraphInstantiate(exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); *exec = nullptr; ok = false; }
-    TRACE(ok ? "capture: ready" : "capture: not instantiated");
     if (graph) (void)hipGraphDestroy(graph);
     return ok;
 }

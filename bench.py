@@ -258,8 +258,9 @@ def main():
     ap.add_argument("--lattice", type=int, default=0, help="nodes per side of the synthetic level (default 67; 134 for `partitioned`)")
     ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
     ap.add_argument("--variant", type=int, default=-1, help="MGCFD_OPT_FLUX_VARIANT (see include/mgcfd.h)")
-    ap.add_argument("--exchange", default="library", choices=["library", "torch"],
-                    help="partitioned workload: who runs the sweep loop and the halo exchange (the library over RCCL, or torch.distributed from Python)")
+    ap.add_argument("--exchange", default="library", choices=["library", "ipc", "torch"],
+                    help="partitioned workload: who runs the sweep loop and the halo exchange — the library over RCCL send/receive (default), the library with "
+                         "direct stores into the neighbours' memory through HIP IPC (opt-in: rehearsed on one GPU only), or torch.distributed from Python")
     ap.add_argument("--rank-graphs", action="store_true",
                     help="partitioned workload, library exchange: replay every rank's sweep from a captured hipGraph (MGCFD_OPT_GRAPH)")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle leg (a rocprofv3 summary of the command then holds only the timed workload's launches)")
@@ -372,7 +373,7 @@ def main():
         exchange = "torch.distributed: a fused launch per stage, pack / batch_isend_irecv / unpack per peer from Python"
         if world == 1:
             step, exchange = (lambda: solver.smooth(0, 1)), None
-        elif args.exchange == "library" and not rehearsal:
+        elif args.exchange in ("library", "ipc") and not rehearsal:
             # the sweep loop inside the library (mgcfd_rank_sweeps): boundary tiles, one pack, ncclSend/ncclRecv grouped on a
             # second stream, the interior tiles under the transfer, one unpack.  Before it is trusted it must reproduce, on
             # this rank, the sweep the torch path makes from the same state, bit for bit; otherwise the torch path runs
@@ -382,6 +383,13 @@ def main():
                 dist.broadcast_object_list(uid, src=0)
                 solver.rank_attach_rccl(rank, world, uid[0])
                 solver.rank_set_halo(0, P)
+                if args.exchange == "ipc":
+                    # messages as direct stores into the neighbours' memory (HIP IPC): every rank's handles to every rank,
+                    # each opens its neighbours'; nobody pushes before everybody has attached
+                    blobs = [None] * world
+                    dist.all_gather_object(blobs, solver.rank_ipc_export(0))
+                    solver.rank_ipc_attach(0, [blobs[p] for p in sorted(set(P.send) | set(P.recv))])
+                    dist.barrier()
                 solver.set_option("graph", 1 if args.rank_graphs else 0)
                 sw.sweep()
                 torch.cuda.synchronize()
@@ -391,13 +399,18 @@ def main():
                 solver.rank_sweeps(0, 1)
                 torch.cuda.synchronize()
                 same = bool(np.array_equal(solver.get(0, "variables").view(np.int64), want.view(np.int64)))
+                if args.exchange == "ipc" and solver.rank_ipc_status(0) != 0:
+                    same = False                            # (a wait for a neighbour's message gave up)
                 ok = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if float(ok.item()) != 1.0:
                     raise RuntimeError("the library's sweep differs from the torch path's on some rank")
                 step = lambda: solver.rank_sweeps(0, 1)
                 info = solver.rank_halo_info(0)
-                exchange = (f"libmgcfd_hip (mgcfd_rank_sweeps): RCCL ncclSend/ncclRecv grouped on a second stream under the interior tiles; "
+                exchange = ("libmgcfd_hip (mgcfd_rank_sweeps, HIP IPC): one launch per stage stores a rank's nodes into its neighbours' ghost slots and raises their flags; "
+                            if args.exchange == "ipc" else
+                            "libmgcfd_hip (mgcfd_rank_sweeps): RCCL ncclSend/ncclRecv grouped on a second stream under the interior tiles; ")
+                exchange = (exchange +
                             f"rank 0: {info['boundary_tiles']} boundary + {info['interior_tiles']} interior tiles; checked against the torch path at start-up"
                             + ("; sweeps replayed from hipGraphs" if args.rank_graphs else ""))
             except Exception as e:                       # the torch path stands

@@ -31,6 +31,14 @@ struct PushPeers {
     int n = 0;
 };
 
+// The flags a push raises in its peers once its stores are on their way (ranks in different processes: kernels.hip,
+// k_halo_push with flags, k_flags_wait): flag[p] = the word in peer p's memory, value = this message's sequence number.
+struct PushFlags {
+    unsigned long long *flag[kMaxPushPeers] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned long long value = 0;
+    int n = 0;
+};
+
 // Arguments of the time_step half of a fused flux + time_step launch (kernels.hip: k_flux_tile<FUSE>).
 struct FusedStep {
     double rk_div = 1.0;                      // double(RK+1-j)

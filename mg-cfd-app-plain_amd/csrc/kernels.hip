@@ -1655,6 +1655,55 @@ k_halo_push(int64_t n, int64_t stride, const int32_t *__restrict__ idx, const in
     for (int f = 0; f < 5; f++) dst[f * ps + g] = field[f * stride + i];
 }
 
+// The same between PROCESSES (the peers' buffers opened through HIP IPC): the push also tells every peer that the message is
+// complete, by a sequence number in a word of the peer's memory.  Every wave drains its stores, the workgroup counts itself
+// off (device-scope ticket), and the workgroup that counts last raises the flags behind a system-scope release — so a peer
+// that reads the number finds the whole message.  The receiver does not poll inside a compute kernel: k_flags_wait is a
+// launch of its own in front of the boundary tiles (one wave; it gives up after about two seconds and says so), and the
+// boundary launch behind it starts with the acquire every launch starts with.
+__global__ void __launch_bounds__(kBlock)
+k_halo_push_flags(int64_t n, int64_t stride, const int32_t *__restrict__ idx, const int32_t *__restrict__ target,
+                  const double *__restrict__ field, PushPeers peers, PushFlags flags, unsigned *__restrict__ ticket)
+{
+    const int64_t k = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    if (k < n) {
+        double *dst = peers.base[0];
+        int64_t ps = peers.stride[0];
+#pragma unroll
+        for (int p = 1; p < kMaxPushPeers; p++)
+            if (p < peers.n && k >= peers.first[p]) { dst = peers.base[p]; ps = peers.stride[p]; }
+        const int64_t i = idx[k], g = target[k];
+        for (int f = 0; f < 5; f++) dst[f * ps + g] = field[f * stride + i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        const unsigned done = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (the next push starts from zero again)
+            __threadfence_system();
+#pragma unroll
+            for (int p = 0; p < kMaxPushPeers; p++)
+                if (p < flags.n) __hip_atomic_store(flags.flag[p], flags.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// wait until every peer's flag word [peer][slot] has reached `value` (see above); *timed_out counts the waits that gave up
+__global__ void k_flags_wait(const unsigned long long *__restrict__ flags, int n_peers, int slot, unsigned long long value,
+                             int *__restrict__ timed_out)
+{
+    const int p = threadIdx.x;
+    if (p >= n_peers) return;
+    const unsigned long long *w = flags + p * 4 + slot;
+    const unsigned long long t0 = wall_clock64();                       // (100 MHz)
+    while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
+        __builtin_amdgcn_s_sleep(64);
+        if (wall_clock64() - t0 > 200000000ull) { atomicAdd(timed_out, 1); break; }
+    }
+}
+
 // One multigrid level per rank: the restricted variables arrive from the rank that holds the finer level as a whole
 // [5][stride] array.  mg_restrict leaves a coarse node WITHOUT children at its old value (mg_loops.cpp:63-78,174-189),
 // and only the rank that sweeps the coarse level has that value: take the message for nodes with children only.
@@ -2089,6 +2138,13 @@ void launch_halo_pack(hipStream_t st, int64_t n, int64_t stride, const int32_t *
 
 void launch_halo_push(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const int32_t *target, const double *field, const PushPeers &peers)
 { if (n > 0) hipLaunchKernelGGL(k_halo_push, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, target, field, peers); }
+
+void launch_halo_push_flags(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const int32_t *target, const double *field,
+                            const PushPeers &peers, const PushFlags &flags, unsigned *ticket)
+{ if (n > 0) hipLaunchKernelGGL(k_halo_push_flags, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, target, field, peers, flags, ticket); }
+
+void launch_flags_wait(hipStream_t st, const unsigned long long *flags, int n_peers, int slot, unsigned long long value, int *timed_out)
+{ if (n_peers > 0) hipLaunchKernelGGL(k_flags_wait, dim3(1), dim3(64), 0, st, flags, n_peers, slot, value, timed_out); }
 
 void launch_halo_unpack(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const double *msg, double *field)
 { if (n > 0) hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, msg, field); }

@@ -87,6 +87,17 @@ struct HaloExchange {
     int32_t *push_target = nullptr;                      // device [total_send]: slot k's node in the numbering of the peer it goes to
     hipEvent_t bdone[3] = {nullptr, nullptr, nullptr};   // [stage] this rank's boundary tiles and push of that stage are enqueued up to here
     bool direct = false;
+    // ranks in different PROCESSES, direct mode (mgcfd_rank_ipc_*): the peers' state buffers and flag words opened through HIP IPC
+    bool ipc = false;
+    unsigned long long *flags = nullptr;                 // device [kMaxPushPeers][4]: word [k][slot] is raised by peer k (slot = stage; 3 spare)
+    unsigned *ticket = nullptr;                          // device: workgroups of the running push that are done
+    int *ipc_timeouts = nullptr;                         // device: waits that gave up (a peer that never arrived)
+    unsigned long long seq = 0;                          // messages pushed so far (all ranks push in lockstep)
+    double *peer_state[kMaxPushPeers][3] = {};           // opened: peer k's three state buffers, as the peer numbers them
+    int64_t peer_stride[kMaxPushPeers] = {};
+    int peer_rot_delta[kMaxPushPeers] = {};              // (peer's rotation - ours) mod 3 when the buffers were exchanged
+    unsigned long long *peer_flag[kMaxPushPeers] = {};   // opened: the words of peer k's flag array this rank raises
+    std::vector<void *> ipc_opened;                      // every mapping opened (closed again in mgcfd_rank_detach / the destructor)
     int64_t total_send() const { return send_off.empty() ? 0 : send_off.back(); }
     int64_t total_recv() const { return recv_off.empty() ? 0 : recv_off.back(); }
 };
@@ -494,7 +505,8 @@ mgcfd_solver::~mgcfd_solver()
         for (auto &hp : lv.halo_plans) if (hp.first) (void)hipFree(hp.first);
         if (lv.hx) {
             HaloExchange &hx = *lv.hx;
-            void *hp[] = {hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.gmin, hx.peer_scalars, hx.push_target};
+            for (void *m : hx.ipc_opened) (void)hipIpcCloseMemHandle(m);
+            void *hp[] = {hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.gmin, hx.peer_scalars, hx.push_target, hx.flags, hx.ticket, hx.ipc_timeouts};
             for (hipEvent_t e : hx.bdone) if (e) (void)hipEventDestroy(e);
             for (void *p : hp) if (p) (void)hipFree(p);
             for (int b = 0; b < HaloExchange::kSets; b++) {
@@ -2214,6 +2226,75 @@ static bool capture_sweep(hipStream_t origin, const std::vector<std::pair<hipStr
     return ok;
 }
 
+
+// ---- ranks in different processes, direct mode (HIP IPC) -------------------------------------------------------------------
+// What the in-process groups do with events, done between processes: every rank publishes IPC handles of its three state
+// buffers and of a small array of flag words (mgcfd_rank_ipc_export), opens its neighbours' (mgcfd_rank_ipc_attach), and from
+// then on a stage is: k_flags_wait (the neighbours' messages of the stage before have arrived) -> boundary tiles -> ONE
+// k_halo_push_flags (stores into the neighbours' ghost slots, then raises their flags) -> interior tiles.  No message
+// buffers, no second stream, no RCCL call per stage; the all-reduce of the global time step stays on RCCL.
+// Opt-in (bench.py --exchange ipc): it could be rehearsed with two processes on ONE GPU only (tests/test_gpu_configs.py).
+namespace {
+struct IpcExportHeader {
+    hipIpcMemHandle_t state[3], flags;
+    int64_t stride, n_recv;
+    int32_t rot, rank, n_peers, reserved;
+    int32_t peers[kMaxPushPeers];
+    int64_t recv_off[kMaxPushPeers + 1];
+};
+}
+
+static void ipc_wait(mgcfd_solver *s, HaloExchange &hx, int slot)
+{
+    exact::launch_flags_wait(s->stream, hx.flags, static_cast<int>(hx.peer.size()), slot, hx.seq, hx.ipc_timeouts);
+}
+
+// this rank's nodes of `field` into the peers' buffers state[(rot + which) % 3] (which: 0 variables, 1 q_alt, 2 old_variables,
+// by the PEER's numbering of its buffers), flag word `slot`
+static void ipc_push(mgcfd_solver *s, DeviceLevel &lv, const double *field, int which, int slot)
+{
+    HaloExchange &hx = *lv.hx;
+    PushPeers pp;
+    PushFlags pf;
+    pp.n = pf.n = static_cast<int>(hx.peer.size());
+    for (int k = 0; k < pp.n; k++) {
+        pp.base[k] = hx.peer_state[k][(lv.rot + hx.peer_rot_delta[k] + which) % 3];
+        pp.stride[k] = hx.peer_stride[k];
+        pp.first[k] = hx.send_off[static_cast<size_t>(k)];
+        pf.flag[k] = hx.peer_flag[k] + slot;
+    }
+    pp.first[pp.n] = hx.total_send();
+    hx.seq++;
+    pf.value = hx.seq;
+    exact::launch_halo_push_flags(s->stream, hx.total_send(), lv.dp.stride, hx.send_idx, hx.push_target, field, pp, pf, hx.ticket);
+}
+
+static void rank_sweep_once_ipc(mgcfd_solver *s, int level)
+{
+    mgcfd_comm &c = comm_of(s);
+    DeviceLevel &lv = s->level(level);
+    HaloExchange &hx = *lv.hx;
+    const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
+    if (global_dt && !c.rccl) throw std::invalid_argument("a global time step needs the all-reduce: attach RCCL (mgcfd_rank_attach_rccl) as well");
+    sweep_first_half(s, level);
+    if (global_dt) RCCL_CHECK(g_rccl.AllReduce(lv.min_dt, lv.min_dt, 1, Rccl::kDouble, Rccl::kMin, c.rccl, s->stream));
+    for (int j = 0; j < MGCFD_RK; j++) {
+        double *const start = lv.q, *const b1 = lv.q_alt, *const b2 = lv.old_variables;
+        double *in = j == 0 ? start : (j == 1 ? b1 : b2);
+        double *out = j == 0 ? b1 : (j == 1 ? b2 : b1);
+        ipc_wait(s, hx, (j + 2) % 3);                       // the ghosts of `in`: the peers' pushes of the stage before (stage 0: of the last sweep, or of the exchange)
+        if (j == 0) {
+            if (!lv.fluxes_zero) throw std::invalid_argument("a partitioned sweep needs zero fluxes (as after time_step)");
+            s->settle_fluxes(lv);
+        }
+        s->force_check = s->next_check();
+        s->op_fused_stage(level, j, in, out, j == 0 && global_dt ? 2 : 0, j == 2, start, j == 2 && global_dt && part_look_ahead(), false, nullptr, hx.tiles_boundary, hx.n_boundary, true, nullptr, 0);
+        lv.stage_out = out;
+        ipc_push(s, lv, out, j == 1 ? 2 : 1, j);            // (before the rotation: stage 1 writes old_variables' buffer, stages 0 and 2 q_alt's)
+        stage_interior(s, level, j, global_dt ? 2 : 0, nullptr, 0);
+    }
+}
+
 extern "C" {
 
 int mgcfd_rccl_unique_id(void *out128)
@@ -2235,6 +2316,120 @@ int mgcfd_rank_attach_rccl(mgcfd_solver *s, int rank, int world, const void *id1
         c.rank = rank; c.world = world;
         RCCL_CHECK(g_rccl.CommInitRank(&c.rccl, world, id, rank));
         g_comms[s] = c;
+    });
+}
+
+// a rank of `world` processes without an RCCL communicator: enough for a level with a local time step (mesh_name = fvcorr),
+// whose sweeps need no all-reduce, once the neighbours' buffers are attached (mgcfd_rank_ipc_attach)
+int mgcfd_rank_attach_plain(mgcfd_solver *s, int rank, int world)
+{
+    REQUIRE(s);
+    return guarded([&] {
+        if (rank < 0 || rank >= world) throw std::invalid_argument("rank out of range");
+        mgcfd_comm c;
+        c.rank = rank; c.world = world;
+        g_comms[s] = c;
+    });
+}
+
+int mgcfd_rank_ipc_export_size(mgcfd_solver *s, int level, int64_t *bytes)
+{
+    REQUIRE(s); REQUIRE(bytes);
+    return guarded([&] {
+        DeviceLevel &lv = s->level(level);
+        if (!lv.hx) throw std::invalid_argument("the level has no halo lists: call mgcfd_rank_set_halo first");
+        *bytes = static_cast<int64_t>(sizeof(IpcExportHeader) + sizeof(int32_t) * lv.hx->recv_idx_host.size());
+    });
+}
+
+int mgcfd_rank_ipc_export(mgcfd_solver *s, int level, void *out)
+{
+    REQUIRE(s); REQUIRE(out);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        if (!lv.hx) throw std::invalid_argument("the level has no halo lists: call mgcfd_rank_set_halo first");
+        HaloExchange &hx = *lv.hx;
+        if (static_cast<int>(hx.peer.size()) > kMaxPushPeers) throw std::invalid_argument("more neighbouring ranks than a push addresses (8)");
+        if (lv.n_owned < lv.info.nel && !lv.plan.ghosts_last) throw std::invalid_argument("the level's plan mixes ghosts into the tiles");
+        if (!hx.flags) {
+            hx.flags = dev_alloc<unsigned long long>(kMaxPushPeers * 4);
+            HIP_CHECK(hipMemset(hx.flags, 0, sizeof(unsigned long long) * kMaxPushPeers * 4));
+            hx.ticket = dev_alloc<unsigned>(1);
+            HIP_CHECK(hipMemset(hx.ticket, 0, sizeof(unsigned)));
+            hx.ipc_timeouts = dev_alloc<int>(1);
+            HIP_CHECK(hipMemset(hx.ipc_timeouts, 0, sizeof(int)));
+        }
+        IpcExportHeader h{};
+        for (int k = 0; k < 3; k++) HIP_CHECK(hipIpcGetMemHandle(&h.state[k], lv.state[k]));
+        HIP_CHECK(hipIpcGetMemHandle(&h.flags, hx.flags));
+        h.stride = lv.dp.stride;
+        h.n_recv = static_cast<int64_t>(hx.recv_idx_host.size());
+        h.rot = lv.rot % 3;
+        h.rank = comm_of(s).rank;
+        h.n_peers = static_cast<int32_t>(hx.peer.size());
+        for (size_t k = 0; k < hx.peer.size(); k++) h.peers[k] = hx.peer[k];
+        for (size_t k = 0; k <= hx.peer.size(); k++) h.recv_off[k] = hx.recv_off[k];
+        std::memcpy(out, &h, sizeof(h));
+        std::memcpy(static_cast<char *>(out) + sizeof(h), hx.recv_idx_host.data(), sizeof(int32_t) * hx.recv_idx_host.size());
+    });
+}
+
+// exports[k] = what neighbour hx.peer[k] exported (in the order of mgcfd_rank_set_halo's peers)
+int mgcfd_rank_ipc_attach(mgcfd_solver *s, int level, int n_peers, const void *const *exports)
+{
+    REQUIRE(s);
+    if (n_peers > 0) REQUIRE(exports);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        if (!lv.hx || !lv.hx->flags) throw std::invalid_argument("export this rank's buffers first (mgcfd_rank_ipc_export)");
+        HaloExchange &hx = *lv.hx;
+        if (n_peers != static_cast<int>(hx.peer.size())) throw std::invalid_argument("one export per neighbouring rank, in the order of mgcfd_rank_set_halo");
+        const int me = comm_of(s).rank;
+        std::vector<int32_t> target(static_cast<size_t>(hx.total_send()), 0);
+        for (int k = 0; k < n_peers; k++) {
+            IpcExportHeader h;
+            std::memcpy(&h, exports[k], sizeof(h));
+            if (h.rank != hx.peer[static_cast<size_t>(k)]) throw std::invalid_argument("the exports are not in the order of the peers");
+            int kd = -1;
+            for (int q = 0; q < h.n_peers; q++) if (h.peers[q] == me) kd = q;
+            if (kd < 0) throw std::logic_error("halo lists of two ranks do not match");
+            const int64_t n = hx.send_off[static_cast<size_t>(k) + 1] - hx.send_off[static_cast<size_t>(k)];
+            if (n != h.recv_off[kd + 1] - h.recv_off[kd]) throw std::logic_error("halo message lengths of two ranks do not match");
+            const int32_t *ridx = reinterpret_cast<const int32_t *>(static_cast<const char *>(exports[k]) + sizeof(h));
+            for (int64_t i = 0; i < n; i++) target[static_cast<size_t>(hx.send_off[static_cast<size_t>(k)] + i)] = ridx[h.recv_off[kd] + i];
+            for (int b = 0; b < 3; b++) {
+                void *m = nullptr;
+                HIP_CHECK(hipIpcOpenMemHandle(&m, h.state[b], hipIpcMemLazyEnablePeerAccess));
+                hx.ipc_opened.push_back(m);
+                hx.peer_state[k][b] = static_cast<double *>(m);
+            }
+            void *f = nullptr;
+            HIP_CHECK(hipIpcOpenMemHandle(&f, h.flags, hipIpcMemLazyEnablePeerAccess));
+            hx.ipc_opened.push_back(f);
+            hx.peer_flag[k] = static_cast<unsigned long long *>(f) + kd * 4;
+            hx.peer_stride[k] = h.stride;
+            hx.peer_rot_delta[k] = ((h.rot - lv.rot % 3) % 3 + 3) % 3;
+        }
+        if (hx.push_target) { HIP_CHECK(hipFree(hx.push_target)); hx.push_target = nullptr; }
+        hx.push_target = dev_upload(target);
+        hx.ipc = true;
+    });
+}
+
+// how many waits for a neighbour's message gave up since the last call (0: every message arrived).  Synchronises.
+int mgcfd_rank_ipc_status(mgcfd_solver *s, int level, int *timed_out)
+{
+    REQUIRE(s); REQUIRE(timed_out);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        *timed_out = 0;
+        if (!lv.hx || !lv.hx->ipc) return;
+        HIP_CHECK(hipMemcpyAsync(timed_out, lv.hx->ipc_timeouts, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        HIP_CHECK(hipMemsetAsync(lv.hx->ipc_timeouts, 0, sizeof(int), s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
     });
 }
 
@@ -2281,9 +2476,19 @@ static bool sweep_graphs_enabled()
 int mgcfd_rank_exchange(mgcfd_solver *s, int level)
 {
     OP({
-        if (!comm_of(s).rccl) throw std::invalid_argument("in-process ranks exchange through mgcfd_group_exchange");
         DeviceLevel &lv = s->level(level);
         if (!lv.hx) throw std::invalid_argument("the level has no halo lists");
+        if (lv.hx->ipc) {
+            // direct mode between processes: behind whatever the peers still read of the last sweep, this rank's owned
+            // `variables` into their ghost slots; the rank's own stream goes on behind the messages INTO it
+            s->settle_residuals(lv);
+            ipc_wait(s, *lv.hx, 2);
+            ipc_push(s, lv, lv.q, 0, 2);
+            ipc_wait(s, *lv.hx, 2);
+            lv.min_ahead = false;
+            return;
+        }
+        if (!comm_of(s).rccl) throw std::invalid_argument("in-process ranks exchange through mgcfd_group_exchange");
         halo_start(s, level, lv.q, 0);
         halo_finish(s, level, lv.q, 0);
         lv.min_ahead = false;
@@ -2294,11 +2499,16 @@ int mgcfd_rank_sweeps(mgcfd_solver *s, int level, int sweeps)
 {
     OP({
         mgcfd_comm &c = comm_of(s);
-        if (!c.rccl) throw std::invalid_argument("in-process ranks sweep through mgcfd_group_sweeps");
         DeviceLevel &lv = s->level(level);
         if (!lv.hx) throw std::invalid_argument("the level has no halo lists: call mgcfd_rank_set_halo first");
         HaloExchange &hx = *lv.hx;
         s->settle_fluxes(lv);                               // (outside any capture: a lazy zero is not part of a sweep)
+        if (hx.ipc) {
+            for (int k = 0; k < sweeps; k++) rank_sweep_once_ipc(s, level);
+            ipc_wait(s, hx, 2);                             // (the ghosts of `variables` are complete in this rank's stream order)
+            return;
+        }
+        if (!c.rccl) throw std::invalid_argument("in-process ranks sweep through mgcfd_group_sweeps");
         for (int k = 0; k < sweeps; k++) {
             const int rot = lv.rot % 3;
             // MGCFD_OPT_GRAPH = 1: the sweep replayed from a hipGraph (measured with the one rank a one-GPU box offers: 76 us

@@ -129,6 +129,11 @@ _SIGNATURES = [
     ("mgcfd_group_create", C.c_int, [C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
     ("mgcfd_group_destroy", None, [_vp]),
     ("mgcfd_group_exchange", C.c_int, [_vp, C.c_int]),
+    ("mgcfd_rank_attach_plain", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("mgcfd_rank_ipc_export_size", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
+    ("mgcfd_rank_ipc_export", C.c_int, [_vp, C.c_int, _vp]),
+    ("mgcfd_rank_ipc_attach", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("mgcfd_rank_ipc_status", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_group_sweeps", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mgcfd_group_sweeps_rms", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_group_rms", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
@@ -523,6 +528,26 @@ class Solver:
         self._c(self.lib.mgcfd_rank_attach_rccl(self.handle, rank, world, buf))
 
     def rank_detach(self): self._c(self.lib.mgcfd_rank_detach(self.handle))
+    def rank_attach_plain(self, rank: int, world: int): self._c(self.lib.mgcfd_rank_attach_plain(self.handle, rank, world))
+
+    def rank_ipc_export(self, l: int) -> bytes:
+        """HIP IPC handles of this rank's state buffers and flag words + its ghost list: for the neighbouring ranks' rank_ipc_attach."""
+        n = _i64(0)
+        self._c(self.lib.mgcfd_rank_ipc_export_size(self.handle, l, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        self._c(self.lib.mgcfd_rank_ipc_export(self.handle, l, buf))
+        return buf.raw
+
+    def rank_ipc_attach(self, l: int, exports):
+        """exports[k] = what neighbour k (in the order of rank_set_halo's peers) exported."""
+        keep = [C.create_string_buffer(e, len(e)) for e in exports]
+        arr = (_vp * max(len(keep), 1))(*[C.cast(b, _vp) for b in keep])
+        self._c(self.lib.mgcfd_rank_ipc_attach(self.handle, l, len(keep), arr))
+
+    def rank_ipc_status(self, l: int) -> int:
+        n = C.c_int(0)
+        self._c(self.lib.mgcfd_rank_ipc_status(self.handle, l, C.byref(n)))
+        return n.value
     def rank_exchange(self, l: int): self._c(self.lib.mgcfd_rank_exchange(self.handle, l))
     def rank_sweeps(self, l: int, sweeps: int = 1): self._c(self.lib.mgcfd_rank_sweeps(self.handle, l, sweeps))
 

@@ -440,6 +440,22 @@ def test_library_loop_in_its_other_forms(form, monkeypatch):
     _group_sweeps_check(mg, 3, 5)
 
 
+@pytest.mark.parametrize("ranks,lattice,sweeps", [(2, 14, 5), (3, 20, 7)])
+def test_ranks_in_different_processes_store_into_each_other_through_hip_ipc(ranks, lattice, sweeps):
+    """tools/ipc_ranks_check.py: `ranks` PROCESSES on this one GPU, each with its part of a local-time-step level, the state
+    buffers and flag words of its neighbours opened through HIP IPC (mgcfd_rank_ipc_export / _attach): a stage's message is one
+    launch that stores into the neighbours' ghost slots and raises their flags, the next stage waits for them.  Every rank
+    compares its owned nodes and its ghosts with the unpartitioned level, bit for bit, and no wait may have given up."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ipc_ranks_check.py"), "--ranks", str(ranks), "--lattice", str(lattice), "--sweeps", str(sweeps)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("owned equal, ghosts equal, waits that gave up: 0") == ranks
+
+
 def test_cfg5_eight_parts_library_loop():
     """BASELINE configs[4] at size with the sweep loop in the library: the 134^3 level in 8 parts as an in-process group
     (all on this GPU), four sweeps — a host thread per rank —, against mgcfd_smooth on the whole 2.4 M-node level."""

@@ -373,22 +373,26 @@ def main():
         exchange = "torch.distributed: a fused launch per stage, pack / batch_isend_irecv / unpack per peer from Python"
         if world == 1:
             step, exchange = (lambda: solver.smooth(0, 1)), None
-        elif args.exchange in ("library", "ipc") and not rehearsal:
+        elif args.exchange in ("library", "ipc") and (not rehearsal or args.exchange == "ipc"):
             # the sweep loop inside the library (mgcfd_rank_sweeps): boundary tiles, one pack, ncclSend/ncclRecv grouped on a
             # second stream, the interior tiles under the transfer, one unpack.  Before it is trusted it must reproduce, on
             # this rank, the sweep the torch path makes from the same state, bit for bit; otherwise the torch path runs
             # and the line says so.
             try:
-                uid = [mgcfd.rccl_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                solver.rank_attach_rccl(rank, world, uid[0])
+                if rehearsal:
+                    # (every rank on device 0: RCCL refuses that, and the IPC form needs no collective library at all)
+                    solver.rank_attach_plain(rank, world)
+                else:
+                    uid = [mgcfd.rccl_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(uid, src=0)
+                    solver.rank_attach_rccl(rank, world, uid[0])
                 solver.rank_set_halo(0, P)
                 if args.exchange == "ipc":
                     # messages as direct stores into the neighbours' memory (HIP IPC): every rank's handles to every rank,
                     # each opens its neighbours'; nobody pushes before everybody has attached
                     blobs = [None] * world
                     dist.all_gather_object(blobs, solver.rank_ipc_export(0))
-                    solver.rank_ipc_attach(0, [blobs[p] for p in sorted(set(P.send) | set(P.recv))])
+                    solver.rank_ipc_attach(0, blobs)          # (every rank's: the time-step all-reduce goes through the flags too)
                     dist.barrier()
                 solver.set_option("graph", 1 if args.rank_graphs else 0)
                 sw.sweep()

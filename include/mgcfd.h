@@ -376,15 +376,17 @@ int mgcfd_rank_residual_sumsq(mgcfd_solver *s, int level, double *sum_all_ranks)
  * publishes HIP IPC handles of its three state buffers and of a few flag words, opens its neighbours', and a stage's message
  * is then ONE launch that stores the nodes the neighbours need straight into their ghost slots (over xGMI between devices)
  * and raises their flags; the neighbour's next stage starts behind a one-wave launch that waits for them.  No message
- * buffers, no second stream, no RCCL call per stage (the all-reduce of a global time step stays on RCCL).
- *   mgcfd_rank_attach_rccl (or, for a local time step, mgcfd_rank_attach_plain), mgcfd_rank_set_halo, then
- *   mgcfd_rank_ipc_export_size / _export, the blobs handed to the neighbours by the launcher, mgcfd_rank_ipc_attach
- *   (exports[k] = neighbour peers[k]'s blob); from then on mgcfd_rank_exchange / mgcfd_rank_sweeps run the direct form.
+ * buffers, no second stream, no RCCL call per stage; with EVERY rank attached the all-reduce of a global time step goes
+ * through the same flags (every rank stores its minimum into every other rank's memory) and no collective library is needed
+ * at all, otherwise it stays on RCCL.
+ *   mgcfd_rank_attach_plain (or mgcfd_rank_attach_rccl), mgcfd_rank_set_halo, then mgcfd_rank_ipc_export_size / _export, the
+ *   blobs handed round by the launcher, mgcfd_rank_ipc_attach (the other ranks' blobs in any order: at least the neighbours',
+ *   at most 16 ranks); from then on mgcfd_rank_exchange / mgcfd_rank_sweeps run the direct form.
  *   mgcfd_rank_ipc_status: waits for a neighbour that gave up (about 2 s each) since the last call; 0 = all messages arrived. */
 int mgcfd_rank_attach_plain(mgcfd_solver *s, int rank, int world);
 int mgcfd_rank_ipc_export_size(mgcfd_solver *s, int level, int64_t *bytes);
 int mgcfd_rank_ipc_export(mgcfd_solver *s, int level, void *out);
-int mgcfd_rank_ipc_attach(mgcfd_solver *s, int level, int n_peers, const void *const *exports);
+int mgcfd_rank_ipc_attach(mgcfd_solver *s, int level, int n_exports, const void *const *exports);
 int mgcfd_rank_ipc_status(mgcfd_solver *s, int level, int *timed_out);
 int mgcfd_group_create(int n, mgcfd_solver *const *solvers, mgcfd_group **out);   /* solvers[r] becomes rank r of n */
 void mgcfd_group_destroy(mgcfd_group *g);

@@ -38,6 +38,18 @@ struct PushFlags {
     unsigned long long value = 0;
     int n = 0;
 };
+// A rank's flag words are rows of four (one per Runge-Kutta stage + one for the time-step all-reduce), one row per SOURCE rank.
+constexpr int kMaxIpcRanks = 16;
+struct FlagRows { int row[kMaxIpcRanks] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; };
+// The all-reduce(MIN) of the time step between processes without a collective library: every rank stores its minimum into
+// slot [parity][its rank] of every other rank's array and raises that rank's flag (k_min_publish); whoever has seen all flags
+// holds all minima.
+struct MinPublish {
+    double *mins[kMaxIpcRanks] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};              // rank p's array [2][kMaxIpcRanks] (own rank: the local one)
+    unsigned long long *flag[kMaxIpcRanks] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // rank p's flag word [this rank][3]
+    int world = 0, me = 0, parity = 0;
+    unsigned long long value = 0;
+};
 
 // Arguments of the time_step half of a fused flux + time_step launch (kernels.hip: k_flux_tile<FUSE>).
 struct FusedStep {

@@ -1690,18 +1690,37 @@ k_halo_push_flags(int64_t n, int64_t stride, const int32_t *__restrict__ idx, co
     }
 }
 
-// wait until every peer's flag word [peer][slot] has reached `value` (see above); *timed_out counts the waits that gave up
-__global__ void k_flags_wait(const unsigned long long *__restrict__ flags, int n_peers, int slot, unsigned long long value,
+// wait until the flag words [row][slot] of the given source ranks have reached `value` (see above); *timed_out counts the waits that gave up
+__global__ void k_flags_wait(const unsigned long long *__restrict__ flags, FlagRows rows, int slot, unsigned long long value,
                              int *__restrict__ timed_out)
 {
     const int p = threadIdx.x;
-    if (p >= n_peers) return;
-    const unsigned long long *w = flags + p * 4 + slot;
+    int row = rows.row[0];
+#pragma unroll
+    for (int q = 1; q < kMaxIpcRanks; q++) if (q == p) row = rows.row[q];         // (selects, no indexed access to the argument block)
+    if (p >= rows.n) return;
+    const unsigned long long *w = flags + row * 4 + slot;
     const unsigned long long t0 = wall_clock64();                       // (100 MHz)
     while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
         __builtin_amdgcn_s_sleep(64);
         if (wall_clock64() - t0 > 200000000ull) { atomicAdd(timed_out, 1); break; }
     }
+}
+
+// this rank's time-step minimum into every rank's array, then their flags (one lane per destination rank)
+__global__ void k_min_publish(const double *__restrict__ my_min, MinPublish mp)
+{
+    const int p = threadIdx.x;
+    double *dst = mp.mins[0];
+    unsigned long long *flag = mp.flag[0];
+#pragma unroll
+    for (int q = 1; q < kMaxIpcRanks; q++) if (q == p) { dst = mp.mins[q]; flag = mp.flag[q]; }
+    if (p >= mp.world) return;
+    const double v = *my_min;
+    __hip_atomic_store(dst + mp.parity * kMaxIpcRanks + mp.me, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p == mp.me) return;
+    __threadfence_system();
+    __hip_atomic_store(flag, mp.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // One multigrid level per rank: the restricted variables arrive from the rank that holds the finer level as a whole
@@ -2143,8 +2162,11 @@ void launch_halo_push_flags(hipStream_t st, int64_t n, int64_t stride, const int
                             const PushPeers &peers, const PushFlags &flags, unsigned *ticket)
 { if (n > 0) hipLaunchKernelGGL(k_halo_push_flags, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, target, field, peers, flags, ticket); }
 
-void launch_flags_wait(hipStream_t st, const unsigned long long *flags, int n_peers, int slot, unsigned long long value, int *timed_out)
-{ if (n_peers > 0) hipLaunchKernelGGL(k_flags_wait, dim3(1), dim3(64), 0, st, flags, n_peers, slot, value, timed_out); }
+void launch_flags_wait(hipStream_t st, const unsigned long long *flags, const FlagRows &rows, int slot, unsigned long long value, int *timed_out)
+{ if (rows.n > 0) hipLaunchKernelGGL(k_flags_wait, dim3(1), dim3(64), 0, st, flags, rows, slot, value, timed_out); }
+
+void launch_min_publish(hipStream_t st, const double *my_min, const MinPublish &mp)
+{ hipLaunchKernelGGL(k_min_publish, dim3(1), dim3(64), 0, st, my_min, mp); }
 
 void launch_halo_unpack(hipStream_t st, int64_t n, int64_t stride, const int32_t *idx, const double *msg, double *field)
 { if (n > 0) hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(kBlock), 0, st, n, stride, idx, msg, field); }

@@ -35,8 +35,9 @@
     void launch_halo_push_flags(hipStream_t, int64_t n, int64_t stride, const int32_t *idx, const int32_t *target,   \
                                 const double *field, const PushPeers &peers, const PushFlags &flags,                 \
                                 unsigned *ticket);                                                                   \
-    void launch_flags_wait(hipStream_t, const unsigned long long *flags, int n_peers, int slot,                      \
+    void launch_flags_wait(hipStream_t, const unsigned long long *flags, const FlagRows &rows, int slot,             \
                            unsigned long long value, int *timed_out);                                                \
+    void launch_min_publish(hipStream_t, const double *my_min, const MinPublish &mp);                                \
     void launch_append_scalar(hipStream_t, const double *src, double *ring, int *count, int cap);                    \
     void launch_min_over_peers(hipStream_t, const double *const *scalars, int n, double *out);                       \
     void launch_accept_restricted(hipStream_t, int64_t nel_coarse, int64_t stride_coarse, const int32_t *child_ptr,  \

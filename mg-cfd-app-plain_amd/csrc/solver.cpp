@@ -89,7 +89,12 @@ struct HaloExchange {
     bool direct = false;
     // ranks in different PROCESSES, direct mode (mgcfd_rank_ipc_*): the peers' state buffers and flag words opened through HIP IPC
     bool ipc = false;
-    unsigned long long *flags = nullptr;                 // device [kMaxPushPeers][4]: word [k][slot] is raised by peer k (slot = stage; 3 spare)
+    unsigned long long *flags = nullptr;                 // device [kMaxIpcRanks][4]: word [r][slot] is raised by rank r (slot = stage; 3 = the time-step all-reduce)
+    double *gmins = nullptr;                             // device [2][kMaxIpcRanks]: every rank's time-step minimum of this sweep (parity) / the last
+    bool ipc_all = false;                                // every rank of the job is attached: the time-step all-reduce goes through the flags too
+    unsigned long long sweep_seq = 0;                    // all-reduces published so far
+    double *all_mins[kMaxIpcRanks] = {};                 // opened (own: gmins): rank r's gmins
+    unsigned long long *all_flag[kMaxIpcRanks] = {};     // opened: rank r's flag word [this rank][3]
     unsigned *ticket = nullptr;                          // device: workgroups of the running push that are done
     int *ipc_timeouts = nullptr;                         // device: waits that gave up (a peer that never arrived)
     unsigned long long seq = 0;                          // messages pushed so far (all ranks push in lockstep)
@@ -506,7 +511,7 @@ mgcfd_solver::~mgcfd_solver()
         if (lv.hx) {
             HaloExchange &hx = *lv.hx;
             for (void *m : hx.ipc_opened) (void)hipIpcCloseMemHandle(m);
-            void *hp[] = {hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.gmin, hx.peer_scalars, hx.push_target, hx.flags, hx.ticket, hx.ipc_timeouts};
+            void *hp[] = {hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.gmin, hx.peer_scalars, hx.push_target, hx.flags, hx.ticket, hx.ipc_timeouts, hx.gmins};
             for (hipEvent_t e : hx.bdone) if (e) (void)hipEventDestroy(e);
             for (void *p : hp) if (p) (void)hipFree(p);
             for (int b = 0; b < HaloExchange::kSets; b++) {
@@ -2236,7 +2241,7 @@ static bool capture_sweep(hipStream_t origin, const std::vector<std::pair<hipStr
 // Opt-in (bench.py --exchange ipc): it could be rehearsed with two processes on ONE GPU only (tests/test_gpu_configs.py).
 namespace {
 struct IpcExportHeader {
-    hipIpcMemHandle_t state[3], flags;
+    hipIpcMemHandle_t state[3], flags, gmins;
     int64_t stride, n_recv;
     int32_t rot, rank, n_peers, reserved;
     int32_t peers[kMaxPushPeers];
@@ -2246,7 +2251,31 @@ struct IpcExportHeader {
 
 static void ipc_wait(mgcfd_solver *s, HaloExchange &hx, int slot)
 {
-    exact::launch_flags_wait(s->stream, hx.flags, static_cast<int>(hx.peer.size()), slot, hx.seq, hx.ipc_timeouts);
+    FlagRows rows;
+    rows.n = static_cast<int>(hx.peer.size());
+    for (int k = 0; k < rows.n; k++) rows.row[k] = hx.peer[static_cast<size_t>(k)];       // (a rank's row is its rank)
+    exact::launch_flags_wait(s->stream, hx.flags, rows, slot, hx.seq, hx.ipc_timeouts);
+}
+
+// all-reduce(MIN) of lv.min_dt over every rank through the flags: the minima end up in hx.gmins[parity][0..world)
+static const double *ipc_allreduce_min(mgcfd_solver *s, DeviceLevel &lv)
+{
+    HaloExchange &hx = *lv.hx;
+    const mgcfd_comm &c = comm_of(s);
+    MinPublish mp;
+    mp.world = c.world; mp.me = c.rank;
+    mp.parity = static_cast<int>(hx.sweep_seq & 1ull);
+    hx.sweep_seq++;
+    mp.value = hx.sweep_seq;
+    FlagRows rows;
+    for (int r = 0; r < c.world; r++) {
+        mp.mins[r] = hx.all_mins[r];
+        mp.flag[r] = hx.all_flag[r];
+        if (r != c.rank) rows.row[rows.n++] = r;
+    }
+    exact::launch_min_publish(s->stream, lv.min_dt, mp);
+    exact::launch_flags_wait(s->stream, hx.flags, rows, 3, hx.sweep_seq, hx.ipc_timeouts);
+    return hx.gmins + mp.parity * kMaxIpcRanks;
 }
 
 // this rank's nodes of `field` into the peers' buffers state[(rot + which) % 3] (which: 0 variables, 1 q_alt, 2 old_variables,
@@ -2275,9 +2304,16 @@ static void rank_sweep_once_ipc(mgcfd_solver *s, int level)
     DeviceLevel &lv = s->level(level);
     HaloExchange &hx = *lv.hx;
     const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
-    if (global_dt && !c.rccl) throw std::invalid_argument("a global time step needs the all-reduce: attach RCCL (mgcfd_rank_attach_rccl) as well");
+    if (global_dt && !c.rccl && !hx.ipc_all) throw std::invalid_argument("a global time step needs the all-reduce: attach every rank (mgcfd_rank_ipc_attach with all exports) or RCCL");
     sweep_first_half(s, level);
-    if (global_dt) RCCL_CHECK(g_rccl.AllReduce(lv.min_dt, lv.min_dt, 1, Rccl::kDouble, Rccl::kMin, c.rccl, s->stream));
+    // the time step: over the flags when every rank is attached (the ranks' minima side by side, the first stage takes their
+    // minimum), else RCCL's all-reduce into the scalar
+    const double *min_list = nullptr;
+    int n_min = 0, apply = 0;
+    if (global_dt) {
+        if (hx.ipc_all) { min_list = ipc_allreduce_min(s, lv); n_min = c.world; apply = 3; }
+        else { RCCL_CHECK(g_rccl.AllReduce(lv.min_dt, lv.min_dt, 1, Rccl::kDouble, Rccl::kMin, c.rccl, s->stream)); apply = 2; }
+    }
     for (int j = 0; j < MGCFD_RK; j++) {
         double *const start = lv.q, *const b1 = lv.q_alt, *const b2 = lv.old_variables;
         double *in = j == 0 ? start : (j == 1 ? b1 : b2);
@@ -2288,10 +2324,10 @@ static void rank_sweep_once_ipc(mgcfd_solver *s, int level)
             s->settle_fluxes(lv);
         }
         s->force_check = s->next_check();
-        s->op_fused_stage(level, j, in, out, j == 0 && global_dt ? 2 : 0, j == 2, start, j == 2 && global_dt && part_look_ahead(), false, nullptr, hx.tiles_boundary, hx.n_boundary, true, nullptr, 0);
+        s->op_fused_stage(level, j, in, out, j == 0 ? apply : 0, j == 2, start, j == 2 && global_dt && part_look_ahead(), false, nullptr, hx.tiles_boundary, hx.n_boundary, true, min_list, n_min);
         lv.stage_out = out;
         ipc_push(s, lv, out, j == 1 ? 2 : 1, j);            // (before the rotation: stage 1 writes old_variables' buffer, stages 0 and 2 q_alt's)
-        stage_interior(s, level, j, global_dt ? 2 : 0, nullptr, 0);
+        stage_interior(s, level, j, apply, min_list, n_min);
     }
 }
 
@@ -2353,8 +2389,9 @@ int mgcfd_rank_ipc_export(mgcfd_solver *s, int level, void *out)
         if (static_cast<int>(hx.peer.size()) > kMaxPushPeers) throw std::invalid_argument("more neighbouring ranks than a push addresses (8)");
         if (lv.n_owned < lv.info.nel && !lv.plan.ghosts_last) throw std::invalid_argument("the level's plan mixes ghosts into the tiles");
         if (!hx.flags) {
-            hx.flags = dev_alloc<unsigned long long>(kMaxPushPeers * 4);
-            HIP_CHECK(hipMemset(hx.flags, 0, sizeof(unsigned long long) * kMaxPushPeers * 4));
+            hx.flags = dev_alloc<unsigned long long>(kMaxIpcRanks * 4);
+            HIP_CHECK(hipMemset(hx.flags, 0, sizeof(unsigned long long) * kMaxIpcRanks * 4));
+            hx.gmins = dev_upload(std::vector<double>(2 * kMaxIpcRanks, std::numeric_limits<double>::infinity()));
             hx.ticket = dev_alloc<unsigned>(1);
             HIP_CHECK(hipMemset(hx.ticket, 0, sizeof(unsigned)));
             hx.ipc_timeouts = dev_alloc<int>(1);
@@ -2363,6 +2400,8 @@ int mgcfd_rank_ipc_export(mgcfd_solver *s, int level, void *out)
         IpcExportHeader h{};
         for (int k = 0; k < 3; k++) HIP_CHECK(hipIpcGetMemHandle(&h.state[k], lv.state[k]));
         HIP_CHECK(hipIpcGetMemHandle(&h.flags, hx.flags));
+        HIP_CHECK(hipIpcGetMemHandle(&h.gmins, hx.gmins));
+        if (comm_of(s).world > kMaxIpcRanks) throw std::invalid_argument("more ranks than flag rows (16)");
         h.stride = lv.dp.stride;
         h.n_recv = static_cast<int64_t>(hx.recv_idx_host.size());
         h.rot = lv.rot % 3;
@@ -2375,43 +2414,58 @@ int mgcfd_rank_ipc_export(mgcfd_solver *s, int level, void *out)
     });
 }
 
-// exports[k] = what neighbour hx.peer[k] exported (in the order of mgcfd_rank_set_halo's peers)
-int mgcfd_rank_ipc_attach(mgcfd_solver *s, int level, int n_peers, const void *const *exports)
+// exports: what other ranks exported, in any order — at least every neighbouring rank's (mgcfd_rank_set_halo's peers); with
+// EVERY other rank's the all-reduce of a global time step goes through the flags as well and no RCCL call is left in a sweep
+int mgcfd_rank_ipc_attach(mgcfd_solver *s, int level, int n_exports, const void *const *exports)
 {
     REQUIRE(s);
-    if (n_peers > 0) REQUIRE(exports);
+    if (n_exports > 0) REQUIRE(exports);
     return guarded([&] {
         s->use_device();
         DeviceLevel &lv = s->level(level);
         if (!lv.hx || !lv.hx->flags) throw std::invalid_argument("export this rank's buffers first (mgcfd_rank_ipc_export)");
         HaloExchange &hx = *lv.hx;
-        if (n_peers != static_cast<int>(hx.peer.size())) throw std::invalid_argument("one export per neighbouring rank, in the order of mgcfd_rank_set_halo");
-        const int me = comm_of(s).rank;
+        const mgcfd_comm &c = comm_of(s);
+        const int me = c.rank;
         std::vector<int32_t> target(static_cast<size_t>(hx.total_send()), 0);
-        for (int k = 0; k < n_peers; k++) {
+        std::vector<char> peer_seen(hx.peer.size(), 0), rank_seen(static_cast<size_t>(c.world), 0);
+        auto open = [&](const hipIpcMemHandle_t &h) {
+            void *m = nullptr;
+            HIP_CHECK(hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess));
+            hx.ipc_opened.push_back(m);
+            return m;
+        };
+        for (int e = 0; e < n_exports; e++) {
             IpcExportHeader h;
-            std::memcpy(&h, exports[k], sizeof(h));
-            if (h.rank != hx.peer[static_cast<size_t>(k)]) throw std::invalid_argument("the exports are not in the order of the peers");
+            std::memcpy(&h, exports[e], sizeof(h));
+            if (h.rank == me) continue;
+            if (h.rank < 0 || h.rank >= c.world || rank_seen[static_cast<size_t>(h.rank)]) throw std::invalid_argument("an export of an unknown rank, or of one rank twice");
+            rank_seen[static_cast<size_t>(h.rank)] = 1;
+            unsigned long long *their_flags = static_cast<unsigned long long *>(open(h.flags));
+            hx.all_flag[h.rank] = their_flags + me * 4 + 3;
+            hx.all_mins[h.rank] = static_cast<double *>(open(h.gmins));
+            const auto it = std::find(hx.peer.begin(), hx.peer.end(), h.rank);
+            if (it == hx.peer.end()) continue;              // (not a neighbour: only the all-reduce talks to it)
+            const size_t k = static_cast<size_t>(it - hx.peer.begin());
+            peer_seen[k] = 1;
             int kd = -1;
             for (int q = 0; q < h.n_peers; q++) if (h.peers[q] == me) kd = q;
             if (kd < 0) throw std::logic_error("halo lists of two ranks do not match");
-            const int64_t n = hx.send_off[static_cast<size_t>(k) + 1] - hx.send_off[static_cast<size_t>(k)];
+            const int64_t n = hx.send_off[k + 1] - hx.send_off[k];
             if (n != h.recv_off[kd + 1] - h.recv_off[kd]) throw std::logic_error("halo message lengths of two ranks do not match");
-            const int32_t *ridx = reinterpret_cast<const int32_t *>(static_cast<const char *>(exports[k]) + sizeof(h));
-            for (int64_t i = 0; i < n; i++) target[static_cast<size_t>(hx.send_off[static_cast<size_t>(k)] + i)] = ridx[h.recv_off[kd] + i];
-            for (int b = 0; b < 3; b++) {
-                void *m = nullptr;
-                HIP_CHECK(hipIpcOpenMemHandle(&m, h.state[b], hipIpcMemLazyEnablePeerAccess));
-                hx.ipc_opened.push_back(m);
-                hx.peer_state[k][b] = static_cast<double *>(m);
-            }
-            void *f = nullptr;
-            HIP_CHECK(hipIpcOpenMemHandle(&f, h.flags, hipIpcMemLazyEnablePeerAccess));
-            hx.ipc_opened.push_back(f);
-            hx.peer_flag[k] = static_cast<unsigned long long *>(f) + kd * 4;
+            const int32_t *ridx = reinterpret_cast<const int32_t *>(static_cast<const char *>(exports[e]) + sizeof(h));
+            for (int64_t i = 0; i < n; i++) target[static_cast<size_t>(hx.send_off[k] + i)] = ridx[h.recv_off[kd] + i];
+            for (int b = 0; b < 3; b++) hx.peer_state[k][b] = static_cast<double *>(open(h.state[b]));
+            hx.peer_flag[k] = their_flags + me * 4;
             hx.peer_stride[k] = h.stride;
             hx.peer_rot_delta[k] = ((h.rot - lv.rot % 3) % 3 + 3) % 3;
         }
+        for (char seen : peer_seen) if (!seen) throw std::invalid_argument("the export of a neighbouring rank is missing");
+        hx.all_mins[me] = hx.gmins;
+        hx.all_flag[me] = hx.flags + me * 4 + 3;            // (never raised: a rank does not wait for itself)
+        int others = 0;
+        for (char seen : rank_seen) others += seen;
+        hx.ipc_all = others == c.world - 1;
         if (hx.push_target) { HIP_CHECK(hipFree(hx.push_target)); hx.push_target = nullptr; }
         hx.push_target = dev_upload(target);
         hx.ipc = true;

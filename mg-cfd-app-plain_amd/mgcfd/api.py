@@ -539,7 +539,8 @@ class Solver:
         return buf.raw
 
     def rank_ipc_attach(self, l: int, exports):
-        """exports[k] = what neighbour k (in the order of rank_set_halo's peers) exported."""
+        """exports: what other ranks exported (any order; the own one is skipped): at least every neighbour's — with every
+        rank's the time-step all-reduce goes through the flags as well."""
         keep = [C.create_string_buffer(e, len(e)) for e in exports]
         arr = (_vp * max(len(keep), 1))(*[C.cast(b, _vp) for b in keep])
         self._c(self.lib.mgcfd_rank_ipc_attach(self.handle, l, len(keep), arr))

@@ -342,13 +342,19 @@ def test_bench_rehearsal_two_ranks_on_this_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MGCFD_BENCH_REHEARSAL="1")
-    for extra, kind, scaling in ((["--lattice", "30"], "partitioned", "strong"), (["--workload", "copies", "--lattice", "24"], "copies", "weak")):
+    for extra, kind, scaling in ((["--lattice", "30"], "partitioned", "strong"), (["--workload", "copies", "--lattice", "24"], "copies", "weak"),
+                                 (["--lattice", "30", "--exchange", "ipc"], "partitioned", "strong")):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"] + extra,
                            capture_output=True, text=True, env=env, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["n_gpus"] == 2 and line["config"]["workload_kind"] == kind and line["scaling"] == scaling
         assert line["value"] > 0
+        if "ipc" in extra:
+            # the LIBRARY's rank loop ran (two processes storing into each other through HIP IPC, the time-step all-reduce through
+            # the same flags) and had reproduced the torch path's sweep bit for bit at start-up — no fall-back
+            assert "HIP IPC" in line["config"]["exchange"] and "checked against the torch path" in line["config"]["exchange"]
+            assert "not used" not in line["config"]["exchange"]
 
 
 def _group_sweeps_check(mg, n_parts, sweeps, partitioner="rcb"):
@@ -440,17 +446,19 @@ def test_library_loop_in_its_other_forms(form, monkeypatch):
     _group_sweeps_check(mg, 3, 5)
 
 
-@pytest.mark.parametrize("ranks,lattice,sweeps", [(2, 14, 5), (3, 20, 7)])
-def test_ranks_in_different_processes_store_into_each_other_through_hip_ipc(ranks, lattice, sweeps):
+@pytest.mark.parametrize("ranks,lattice,sweeps,mesh", [(2, 14, 5, "fvcorr"), (3, 20, 7, "fvcorr"), (2, 16, 6, "m6wing"), (4, 22, 9, "m6wing")])
+def test_ranks_in_different_processes_store_into_each_other_through_hip_ipc(ranks, lattice, sweeps, mesh):
     """tools/ipc_ranks_check.py: `ranks` PROCESSES on this one GPU, each with its part of a local-time-step level, the state
     buffers and flag words of its neighbours opened through HIP IPC (mgcfd_rank_ipc_export / _attach): a stage's message is one
     launch that stores into the neighbours' ghost slots and raises their flags, the next stage waits for them.  Every rank
-    compares its owned nodes and its ghosts with the unpartitioned level, bit for bit, and no wait may have given up."""
+    compares its owned nodes and its ghosts with the unpartitioned level, bit for bit, and no wait may have given up.  With a
+    global time step (m6wing) every rank also stores its minimum into every other rank's memory each sweep: the all-reduce
+    without a collective library."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ipc_ranks_check.py"), "--ranks", str(ranks), "--lattice", str(lattice), "--sweeps", str(sweeps)],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ipc_ranks_check.py"), "--ranks", str(ranks), "--lattice", str(lattice), "--sweeps", str(sweeps), "--mesh", mesh],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("owned equal, ghosts equal, waits that gave up: 0") == ranks

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Ranks in different PROCESSES storing their halo messages straight into each other's memory through HIP IPC
 (include/mgcfd.h: mgcfd_rank_ipc_*) — rehearsed on ONE GPU: this script starts N processes that all use device 0, each builds
-its part of a level with a local time step (mesh_name = fvcorr: no all-reduce, so no RCCL — which refuses two ranks on one
-device), they hand each other their IPC exports through files, sweep, and every rank compares its owned nodes and ghosts with
-the unpartitioned level it computes for itself, bit for bit.
+its part of a level (local time step, or a global one whose all-reduce then goes through the same flags: no RCCL, which
+refuses two ranks on one device), they hand each other their IPC exports through files, sweep, and every rank compares its
+owned nodes and ghosts with the unpartitioned level it computes for itself, bit for bit.
     python tools/ipc_ranks_check.py [--ranks 2] [--lattice 14] [--sweeps 5]
 (rank processes are started with --rank R --dir D)"""
 import argparse, os, subprocess, sys, tempfile, time
@@ -32,7 +32,10 @@ def rank_main(a):
     from mgcfd import meshgen
     from mgcfd.partition import partition_level, rcb_partition
     from conftest import perturbed_state
-    mg = meshgen.make_multigrid((a.lattice,), "fvcorr", seed=4, cavity_radius=0.01, volume_noise=0.02)
+    if a.mesh == "fvcorr":                                  # local time step: no all-reduce in a sweep
+        mg = meshgen.make_multigrid((a.lattice,), "fvcorr", seed=4, cavity_radius=0.01, volume_noise=0.02)
+    else:                                                   # global time step: every rank's minimum to every rank, through the flags
+        mg = meshgen.make_multigrid((a.lattice,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
     L = mgcfd.generated_to_levels(mg)[0]
     parts = partition_level(L, rcb_partition(np.asarray(L["coords"]), a.ranks))
     P = parts[a.rank]
@@ -48,7 +51,7 @@ def rank_main(a):
     s.rank_set_halo(0, P)
     publish(os.path.join(a.dir, f"export.{a.rank}"), s.rank_ipc_export(0))
     peers = sorted(set(P.send) | set(P.recv))
-    s.rank_ipc_attach(0, [wait_for(os.path.join(a.dir, f"export.{p}")) for p in peers])
+    s.rank_ipc_attach(0, [wait_for(os.path.join(a.dir, f"export.{p}")) for p in range(a.ranks) if p != a.rank])
     # nobody pushes before everybody has opened everybody's buffers
     publish(os.path.join(a.dir, f"attached.{a.rank}"), b"1")
     for p in range(a.ranks):
@@ -85,6 +88,7 @@ def main():
     ap.add_argument("--ranks", type=int, default=2)
     ap.add_argument("--lattice", type=int, default=14)
     ap.add_argument("--sweeps", type=int, default=5)
+    ap.add_argument("--mesh", default="fvcorr", choices=["fvcorr", "m6wing"], help="local (fvcorr) or global (m6wing) time step")
     ap.add_argument("--time", type=int, default=0, help="also time that many sweeps per rank")
     ap.add_argument("--rank", type=int, default=-1)
     ap.add_argument("--dir", default="")
@@ -92,7 +96,7 @@ def main():
     if a.rank >= 0:
         sys.exit(rank_main(a))
     with tempfile.TemporaryDirectory(prefix="mgcfd_ipc_") as d:
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ranks", str(a.ranks), "--lattice", str(a.lattice), "--sweeps", str(a.sweeps),
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ranks", str(a.ranks), "--lattice", str(a.lattice), "--sweeps", str(a.sweeps), "--mesh", a.mesh,
                                    "--time", str(a.time), "--rank", str(r), "--dir", d]) for r in range(a.ranks)]
         rcs = [p.wait(timeout=600) for p in procs]
     print("ranks returned", rcs)

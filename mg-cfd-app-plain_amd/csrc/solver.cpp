@@ -2389,9 +2389,18 @@ int mgcfd_rank_ipc_export(mgcfd_solver *s, int level, void *out)
         if (static_cast<int>(hx.peer.size()) > kMaxPushPeers) throw std::invalid_argument("more neighbouring ranks than a push addresses (8)");
         if (lv.n_owned < lv.info.nel && !lv.plan.ghosts_last) throw std::invalid_argument("the level's plan mixes ghosts into the tiles");
         if (!hx.flags) {
-            hx.flags = dev_alloc<unsigned long long>(kMaxIpcRanks * 4);
+            // the words other devices write and this one polls: fine-grained device memory (not cached across the writes of
+            // another agent) where the runtime grants it, ordinary device memory otherwise
+            auto fine = [](size_t bytes) {
+                void *m = nullptr;
+                if (hipExtMallocWithFlags(&m, bytes, hipDeviceMallocFinegrained) != hipSuccess || !m) { (void)hipGetLastError(); HIP_CHECK(hipMalloc(&m, bytes)); }
+                return m;
+            };
+            hx.flags = static_cast<unsigned long long *>(fine(sizeof(unsigned long long) * kMaxIpcRanks * 4));
             HIP_CHECK(hipMemset(hx.flags, 0, sizeof(unsigned long long) * kMaxIpcRanks * 4));
-            hx.gmins = dev_upload(std::vector<double>(2 * kMaxIpcRanks, std::numeric_limits<double>::infinity()));
+            hx.gmins = static_cast<double *>(fine(sizeof(double) * 2 * kMaxIpcRanks));
+            const std::vector<double> inf(2 * kMaxIpcRanks, std::numeric_limits<double>::infinity());
+            HIP_CHECK(hipMemcpy(hx.gmins, inf.data(), sizeof(double) * inf.size(), hipMemcpyHostToDevice));
             hx.ticket = dev_alloc<unsigned>(1);
             HIP_CHECK(hipMemset(hx.ticket, 0, sizeof(unsigned)));
             hx.ipc_timeouts = dev_alloc<int>(1);

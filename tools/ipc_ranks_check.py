@@ -34,6 +34,8 @@ def rank_main(a):
     from conftest import perturbed_state
     if a.mesh == "fvcorr":                                  # local time step: no all-reduce in a sweep
         mg = meshgen.make_multigrid((a.lattice,), "fvcorr", seed=4, cavity_radius=0.01, volume_noise=0.02)
+    elif a.mesh == "tet":                                   # unstructured (long rows), global time step; --lattice = nodes / 100
+        mg = meshgen.make_tet_multigrid((a.lattice * 100,), "m6wing", seed=6)
     else:                                                   # global time step: every rank's minimum to every rank, through the flags
         mg = meshgen.make_multigrid((a.lattice,), "m6wing", seed=4, cavity_radius=0.15, jitter=0.2, area_noise=0.05, volume_noise=0.05)
     L = mgcfd.generated_to_levels(mg)[0]
@@ -88,7 +90,7 @@ def main():
     ap.add_argument("--ranks", type=int, default=2)
     ap.add_argument("--lattice", type=int, default=14)
     ap.add_argument("--sweeps", type=int, default=5)
-    ap.add_argument("--mesh", default="fvcorr", choices=["fvcorr", "m6wing"], help="local (fvcorr) or global (m6wing) time step")
+    ap.add_argument("--mesh", default="fvcorr", choices=["fvcorr", "m6wing", "tet"], help="local (fvcorr) or global (m6wing) time step")
     ap.add_argument("--time", type=int, default=0, help="also time that many sweeps per rank")
     ap.add_argument("--rank", type=int, default=-1)
     ap.add_argument("--dir", default="")

@@ -21,8 +21,10 @@ Workloads (--workload; `auto` = level0 at N = 1, partitioned at N > 1):
                  (configs[2]; `vcycle` in the JSON line; --no-vcycle skips it, e.g. under rocprofv3).
   partitioned    configs[4]: the level tiled 8x (134^3 lattice = 2.4 M nodes / 7.2 M edges, connected), split over the
                  N ranks by recursive coordinate bisection; every rank sweeps its owned nodes with one fused launch per
-                 Runge-Kutta stage, a halo message to every neighbouring rank after each stage (RCCL point-to-point
-                 over xGMI) and one all-reduce(MIN) of the time step per sweep.  Total work fixed: "scaling": "strong".
+                 Runge-Kutta stage, a halo message to every neighbouring rank after each stage and one all-reduce(MIN)
+                 of the time step per sweep.  Total work fixed: "scaling": "strong".  The loop runs inside the library
+                 (--exchange auto): direct stores into the neighbours' memory over xGMI (HIP IPC) if that form reproduces
+                 the torch path bit for bit at start-up AND over the whole run, else RCCL send/receive, else torch.
   copies         the reference's own -m N mesh duplication (src/Base/io_enhanced.cpp:89-201): one level0 mesh per rank,
                  coupled only by the global-min time step (src/Kernels/cfd_loops.cpp:137-150).  "scaling": "weak".
   level-per-gpu  configs[3]: the 4-level hierarchy with level l on rank l % N; a STEP is one V-cycle; restricted
@@ -258,9 +260,11 @@ def main():
     ap.add_argument("--lattice", type=int, default=0, help="nodes per side of the synthetic level (default 67; 134 for `partitioned`)")
     ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
     ap.add_argument("--variant", type=int, default=-1, help="MGCFD_OPT_FLUX_VARIANT (see include/mgcfd.h)")
-    ap.add_argument("--exchange", default="library", choices=["library", "ipc", "torch"],
-                    help="partitioned workload: who runs the sweep loop and the halo exchange — the library over RCCL send/receive (default), the library with "
-                         "direct stores into the neighbours' memory through HIP IPC (opt-in: rehearsed on one GPU only), or torch.distributed from Python")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "library", "ipc", "torch"],
+                    help="partitioned workload: who runs the sweep loop and the halo exchange — the library with direct stores into the neighbours' memory "
+                         "through HIP IPC (`ipc`), the library over RCCL send/receive (`library`), or torch.distributed from Python (`torch`).  `auto` "
+                         "(default) tries them in that order: each must reproduce the torch path's sweep bit for bit at start-up, and the IPC form's "
+                         "figure counts only if its final state equals the torch path's after the same sweeps — it has been rehearsed on one GPU only")
     ap.add_argument("--rank-graphs", action="store_true",
                     help="partitioned workload, library exchange: replay every rank's sweep from a captured hipGraph (MGCFD_OPT_GRAPH)")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle leg (a rocprofv3 summary of the command then holds only the timed workload's launches)")
@@ -371,39 +375,41 @@ def main():
         sw.exchange("variables")
         step = sw.sweep
         exchange = "torch.distributed: a fused launch per stage, pack / batch_isend_irecv / unpack per peer from Python"
-        if world == 1:
-            step, exchange = (lambda: solver.smooth(0, 1)), None
-        elif args.exchange in ("library", "ipc") and (not rehearsal or args.exchange == "ipc"):
-            # the sweep loop inside the library (mgcfd_rank_sweeps): boundary tiles, one pack, ncclSend/ncclRecv grouped on a
-            # second stream, the interior tiles under the transfer, one unpack.  Before it is trusted it must reproduce, on
-            # this rank, the sweep the torch path makes from the same state, bit for bit; otherwise the torch path runs
-            # and the line says so.
+        torch_exchange = exchange
+        part_candidates = []                                 # ways to run the sweep loop inside the library still to be tried, in order
+        part_mode = "torch"
+        part_notes = []
+
+        def part_reset():
+            """every rank back at the perturbed start state, ghosts current (whatever runs the loop)"""
+            solver.set(0, "variables", q[P.global_ids])
+            if part_mode == "torch":
+                sw.exchange("variables")
+            else:
+                solver.rank_exchange(0)
+
+        def part_try(mode):
+            """The sweep loop inside the library (mgcfd_rank_sweeps) — `library`: boundary tiles, one pack, ncclSend/ncclRecv
+            grouped on a second stream, the interior tiles under the transfer, one unpack; `ipc`: the messages as direct stores
+            into the neighbours' memory (HIP IPC), the time-step all-reduce through the same flags.  Before it is trusted it
+            must reproduce, on every rank, the sweep the torch path makes from the same state, bit for bit."""
+            nonlocal step, exchange, part_mode
             try:
-                if rehearsal:
-                    # (every rank on device 0: RCCL refuses that, and the IPC form needs no collective library at all)
-                    solver.rank_attach_plain(rank, world)
-                else:
-                    uid = [mgcfd.rccl_unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(uid, src=0)
-                    solver.rank_attach_rccl(rank, world, uid[0])
-                solver.rank_set_halo(0, P)
-                if args.exchange == "ipc":
-                    # messages as direct stores into the neighbours' memory (HIP IPC): every rank's handles to every rank,
-                    # each opens its neighbours'; nobody pushes before everybody has attached
+                if mode == "ipc":
                     blobs = [None] * world
                     dist.all_gather_object(blobs, solver.rank_ipc_export(0))
                     solver.rank_ipc_attach(0, blobs)          # (every rank's: the time-step all-reduce goes through the flags too)
-                    dist.barrier()
-                solver.set_option("graph", 1 if args.rank_graphs else 0)
+                    dist.barrier()                            # nobody pushes before everybody has attached
+                solver.set_option("graph", 1 if (args.rank_graphs and mode == "library") else 0)
+                part_mode = "torch"; part_reset()
                 sw.sweep()
                 torch.cuda.synchronize()
                 want = solver.get(0, "variables")
-                solver.set(0, "variables", q[P.global_ids])
-                solver.rank_exchange(0)
+                part_mode = mode; part_reset()
                 solver.rank_sweeps(0, 1)
                 torch.cuda.synchronize()
                 same = bool(np.array_equal(solver.get(0, "variables").view(np.int64), want.view(np.int64)))
-                if args.exchange == "ipc" and solver.rank_ipc_status(0) != 0:
+                if mode == "ipc" and (solver.rank_ipc_status(0) != 0 or os.environ.get("MGCFD_BENCH_FAIL_IPC") == "start"):
                     same = False                            # (a wait for a neighbour's message gave up)
                 ok = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -411,18 +417,52 @@ def main():
                     raise RuntimeError("the library's sweep differs from the torch path's on some rank")
                 step = lambda: solver.rank_sweeps(0, 1)
                 info = solver.rank_halo_info(0)
-                exchange = ("libmgcfd_hip (mgcfd_rank_sweeps, HIP IPC): one launch per stage stores a rank's nodes into its neighbours' ghost slots and raises their flags; "
-                            if args.exchange == "ipc" else
-                            "libmgcfd_hip (mgcfd_rank_sweeps): RCCL ncclSend/ncclRecv grouped on a second stream under the interior tiles; ")
-                exchange = (exchange +
-                            f"rank 0: {info['boundary_tiles']} boundary + {info['interior_tiles']} interior tiles; checked against the torch path at start-up"
-                            + ("; sweeps replayed from hipGraphs" if args.rank_graphs else ""))
-            except Exception as e:                       # the torch path stands
+                exchange = (("libmgcfd_hip (mgcfd_rank_sweeps, HIP IPC): one launch per stage stores a rank's nodes into its neighbours' ghost slots and raises "
+                             "their flags, the time-step all-reduce through the same flags; " if mode == "ipc" else
+                             "libmgcfd_hip (mgcfd_rank_sweeps): RCCL ncclSend/ncclRecv grouped on a second stream under the interior tiles; ")
+                            + f"rank 0: {info['boundary_tiles']} boundary + {info['interior_tiles']} interior tiles; checked against the torch path at start-up"
+                            + ("; sweeps replayed from hipGraphs" if (args.rank_graphs and mode == "library") else ""))
+                return True
+            except Exception as e:
                 if rank == 0:
-                    print(f"bench.py: library exchange not used: {e}", file=sys.stderr)
-                solver.set(0, "variables", q[P.global_ids])
-                sw.exchange("variables")
-                exchange += f" (the library's RCCL loop was not used: {e})"
+                    print(f"bench.py: exchange '{mode}' not used: {e}", file=sys.stderr)
+                part_notes.append(f"'{mode}' not used: {e}")
+                if mode == "ipc":
+                    try:
+                        solver.rank_ipc_detach(0)
+                    except Exception:
+                        pass
+                part_mode = "torch"
+                step, exchange = sw.sweep, torch_exchange
+                return False
+
+        def part_next():
+            """the next way that passes its start-up check (the torch path when none does)"""
+            while part_candidates:
+                if part_try(part_candidates.pop(0)):
+                    break
+            part_reset()
+
+        if world == 1:
+            step, exchange = (lambda: solver.smooth(0, 1)), None
+        elif args.exchange != "torch":
+            try:
+                if rehearsal:
+                    # (every rank on device 0: RCCL refuses that; the IPC form needs no collective library at all)
+                    solver.rank_attach_plain(rank, world)
+                    part_candidates = ["ipc"] if args.exchange in ("auto", "ipc") else []
+                else:
+                    uid = [mgcfd.rccl_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(uid, src=0)
+                    solver.rank_attach_rccl(rank, world, uid[0])
+                    part_candidates = ["ipc", "library"] if args.exchange == "auto" else [args.exchange]
+                solver.rank_set_halo(0, P)
+            except Exception as e:
+                if rank == 0:
+                    print(f"bench.py: the library's rank loop not used: {e}", file=sys.stderr)
+                part_notes.append(f"the library's rank loop not used: {e}")
+                part_candidates = []
+            part_next()
         scaling = "strong"
         edges_per_step_all_ranks = 3 * n_int
         halo_nodes = int(halo_volume(L, part)) if world > 1 else 0
@@ -466,24 +506,52 @@ def main():
         flux_only = solver.bench_flux(0, ROOFLINE_LAUNCHES)
         probe = solver.bench_indirect_rw(0, ROOFLINE_LAUNCHES) if hasattr(solver, "bench_indirect_rw") else None
         solver.zero_fluxes(0)                                   # (the sweeps start from zero fluxes, as after any time_step)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    solver.reset_monitoring()
-    # ONE hipEvent pair around the whole timed region, on the stream the launches go to (no event inside the region:
-    # on ROCm an event record is a barrier packet between two launches).  A level0 step is exactly three fused-stage
-    # launches back to back, so (event time) / 3K is that kernel's launch-to-launch duration over the timed region.
-    live_timing = os.environ.get("MGCFD_BENCH_NO_TIMING") != "1" and workload in ("level0", "copies")
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gpu_seconds = ev0.elapsed_time(ev1) * 1e-3
+    while True:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        solver.reset_monitoring()
+        # ONE hipEvent pair around the whole timed region, on the stream the launches go to (no event inside the region:
+        # on ROCm an event record is a barrier packet between two launches).  A level0 step is exactly three fused-stage
+        # launches back to back, so (event time) / 3K is that kernel's launch-to-launch duration over the timed region.
+        live_timing = os.environ.get("MGCFD_BENCH_NO_TIMING") != "1" and workload in ("level0", "copies")
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(args.steps):
+            step()
+        ev1.record(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        gpu_seconds = ev0.elapsed_time(ev1) * 1e-3
+        if not (workload == "partitioned" and world > 1 and part_mode == "ipc"):
+            break
+        # The IPC exchange has only ever been rehearsed on ONE GPU, so its figure counts only if the state it leaves is the
+        # state the torch path leaves after the same W + K sweeps from the same start, bit for bit on every rank, and no wait
+        # for a neighbour gave up; otherwise the next way runs and is timed instead.
+        got, late = solver.get(0, "variables"), solver.rank_ipc_status(0)
+        part_mode = "torch"; part_reset()
+        for _ in range(args.warmup + args.steps):
+            sw.sweep()
+        torch.cuda.synchronize()
+        same = late == 0 and bool(np.array_equal(got.view(np.int64), solver.get(0, "variables").view(np.int64))) and os.environ.get("MGCFD_BENCH_FAIL_IPC") != "end"
+        ok = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 1.0:
+            exchange += f"; the state after the {args.warmup} + {args.steps} sweeps equals the torch path's bit for bit on every rank"
+            break
+        if rank == 0:
+            print("bench.py: the IPC exchange left a different state than the torch path (or a wait gave up): its figure is discarded", file=sys.stderr)
+        part_notes.append("'ipc' discarded after the run: its final state differed from the torch path's, or a wait for a neighbour gave up")
+        try:
+            solver.rank_ipc_detach(0)
+        except Exception:
+            pass
+        step, exchange = sw.sweep, torch_exchange
+        part_next()
+    if workload == "partitioned":
+        config["exchange"] = exchange + ("".join(f" ({n})" for n in part_notes) if world > 1 else "") if exchange else exchange
     flux_launches = 3 * args.steps if live_timing and workload == "level0" else 0
     flux_avg = gpu_seconds / flux_launches if flux_launches else 0.0
     rc, bad = solver.check_for_invalid_variables(0)

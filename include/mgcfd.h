@@ -388,6 +388,7 @@ int mgcfd_rank_ipc_export_size(mgcfd_solver *s, int level, int64_t *bytes);
 int mgcfd_rank_ipc_export(mgcfd_solver *s, int level, void *out);
 int mgcfd_rank_ipc_attach(mgcfd_solver *s, int level, int n_exports, const void *const *exports);
 int mgcfd_rank_ipc_status(mgcfd_solver *s, int level, int *timed_out);
+int mgcfd_rank_ipc_detach(mgcfd_solver *s, int level);       /* back to the buffered form; closes the neighbours' mappings */
 int mgcfd_group_create(int n, mgcfd_solver *const *solvers, mgcfd_group **out);   /* solvers[r] becomes rank r of n */
 void mgcfd_group_destroy(mgcfd_group *g);
 int mgcfd_group_exchange(mgcfd_group *g, int level);

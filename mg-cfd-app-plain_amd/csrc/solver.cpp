@@ -2481,6 +2481,23 @@ int mgcfd_rank_ipc_attach(mgcfd_solver *s, int level, int n_exports, const void 
     });
 }
 
+// back to the buffered form (RCCL send / receive): the neighbours' mappings are closed.  Synchronises.
+int mgcfd_rank_ipc_detach(mgcfd_solver *s, int level)
+{
+    REQUIRE(s);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        if (!lv.hx || !lv.hx->ipc) return;
+        HaloExchange &hx = *lv.hx;
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        for (void *m : hx.ipc_opened) (void)hipIpcCloseMemHandle(m);
+        hx.ipc_opened.clear();
+        hx.ipc = false;
+        hx.ipc_all = false;
+    });
+}
+
 // how many waits for a neighbour's message gave up since the last call (0: every message arrived).  Synchronises.
 int mgcfd_rank_ipc_status(mgcfd_solver *s, int level, int *timed_out)
 {

@@ -134,6 +134,7 @@ _SIGNATURES = [
     ("mgcfd_rank_ipc_export", C.c_int, [_vp, C.c_int, _vp]),
     ("mgcfd_rank_ipc_attach", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_rank_ipc_status", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    ("mgcfd_rank_ipc_detach", C.c_int, [_vp, C.c_int]),
     ("mgcfd_group_sweeps", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mgcfd_group_sweeps_rms", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_group_rms", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
@@ -544,6 +545,8 @@ class Solver:
         keep = [C.create_string_buffer(e, len(e)) for e in exports]
         arr = (_vp * max(len(keep), 1))(*[C.cast(b, _vp) for b in keep])
         self._c(self.lib.mgcfd_rank_ipc_attach(self.handle, l, len(keep), arr))
+
+    def rank_ipc_detach(self, l: int): self._c(self.lib.mgcfd_rank_ipc_detach(self.handle, l))
 
     def rank_ipc_status(self, l: int) -> int:
         n = C.c_int(0)

@@ -350,11 +350,11 @@ def test_bench_rehearsal_two_ranks_on_this_gpu():
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["n_gpus"] == 2 and line["config"]["workload_kind"] == kind and line["scaling"] == scaling
         assert line["value"] > 0
-        if "ipc" in extra:
+        if kind == "partitioned":                           # (--exchange auto tries the IPC form first; explicit or not, it must have run)
             # the LIBRARY's rank loop ran (two processes storing into each other through HIP IPC, the time-step all-reduce through
             # the same flags) and had reproduced the torch path's sweep bit for bit at start-up — no fall-back
             assert "HIP IPC" in line["config"]["exchange"] and "checked against the torch path" in line["config"]["exchange"]
-            assert "not used" not in line["config"]["exchange"]
+            assert "not used" not in line["config"]["exchange"] and "bit for bit on every rank" in line["config"]["exchange"]
 
 
 def _group_sweeps_check(mg, n_parts, sweeps, partitioner="rcb"):

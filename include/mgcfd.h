@@ -382,7 +382,10 @@ int mgcfd_rank_residual_sumsq(mgcfd_solver *s, int level, double *sum_all_ranks)
  *   mgcfd_rank_attach_plain (or mgcfd_rank_attach_rccl), mgcfd_rank_set_halo, then mgcfd_rank_ipc_export_size / _export, the
  *   blobs handed round by the launcher, mgcfd_rank_ipc_attach (the other ranks' blobs in any order: at least the neighbours',
  *   at most 16 ranks); from then on mgcfd_rank_exchange / mgcfd_rank_sweeps run the direct form.
- *   mgcfd_rank_ipc_status: waits for a neighbour that gave up (about 2 s each) since the last call; 0 = all messages arrived. */
+ *   mgcfd_rank_ipc_status: waits for a neighbour that gave up (about 2 s each) since the last call; 0 = all messages arrived.
+ *   The ranks keep each other in step through the flags only WITHIN this form: before the first mgcfd_rank_exchange — and
+ *   whenever a rank has touched the level by other means (mgcfd_set_array, another kind of sweep) — the caller synchronises
+ *   the ranks (a barrier), or a neighbour's stores may land in a buffer that is still in use. */
 int mgcfd_rank_attach_plain(mgcfd_solver *s, int rank, int world);
 int mgcfd_rank_ipc_export_size(mgcfd_solver *s, int level, int64_t *bytes);
 int mgcfd_rank_ipc_export(mgcfd_solver *s, int level, void *out);

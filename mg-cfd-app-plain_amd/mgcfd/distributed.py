@@ -211,14 +211,26 @@ class PartitionedSweep:
         d = self.dist
         if d is None:
             return
+        staged = any(_gloo_on_device(d, b) for b in list(self.buf_send.values()) + list(self.buf_recv.values()))
+        if staged:
+            import torch
+            torch.cuda.current_stream().synchronize()          # the pack kernels have written the messages
+            send = {p: b.cpu() for p, b in self.buf_send.items()}
+            recv = {p: torch.empty(b.shape, dtype=b.dtype) for p, b in self.buf_recv.items()}
+        else:
+            send, recv = self.buf_send, self.buf_recv
         ops = []
         for p in self.peers:
-            if p in self.buf_send:
-                ops.append(d.P2POp(d.isend, self.buf_send[p], p))
-            if p in self.buf_recv:
-                ops.append(d.P2POp(d.irecv, self.buf_recv[p], p))
+            if p in send:
+                ops.append(d.P2POp(d.isend, send[p], p))
+            if p in recv:
+                ops.append(d.P2POp(d.irecv, recv[p], p))
         for req in d.batch_isend_irecv(ops):
             req.wait()
+        if staged:
+            for p, h in recv.items():
+                self.buf_recv[p].copy_(h)
+            torch.cuda.current_stream().synchronize()
 
     def exchange(self, name="variables"):
         s = self.s
@@ -242,7 +254,7 @@ class PartitionedSweep:
             if self.allreduce_min_fn:
                 self.allreduce_min_fn(self)
             elif self.dist:
-                self.dist.all_reduce(s.min_tensor(0), op=self.dist.ReduceOp.MIN)
+                _all_reduce_min(self.dist, s.min_tensor(0))
             s.step_factor_apply(0)
         else:
             s.compute_step_factor(0)
@@ -311,6 +323,28 @@ class LevelPerRankCycle:
                     s.smooth(l, 1)
 
 
+def _gloo_on_device(dist, t) -> bool:
+    """gloo given a DEVICE tensor (bench.py's one-GPU rehearsal): its point-to-point calls know nothing of streams — a send
+    may read the buffer before the pack kernel has written it (tools/torch_path_check.py: the sweeps then differ from the
+    whole level in most runs) — so such messages are staged through the host with the stream drained on both sides."""
+    try:
+        return bool(getattr(t, "is_cuda", False)) and dist.get_backend() == "gloo"
+    except Exception:
+        return False
+
+
+def _all_reduce_min(dist, t):
+    if _gloo_on_device(dist, t):
+        import torch
+        torch.cuda.current_stream().synchronize()
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MIN)
+        t.copy_(h)
+        torch.cuda.current_stream().synchronize()
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+
+
 def _fused_partitioned_sweep(s, level, global_time_step, allreduce_min_fn, dist, exchange_stage, owner):
     """A sweep of a partitioned level with one fused launch per Runge-Kutta stage: the first half of
     compute_step_factor reduced to the rank's scalar minimum (the ranks' levels differ in size, so their per-workgroup
@@ -321,7 +355,7 @@ def _fused_partitioned_sweep(s, level, global_time_step, allreduce_min_fn, dist,
         if allreduce_min_fn:
             allreduce_min_fn(owner, level)
         elif dist:
-            dist.all_reduce(s.min_tensor(level), op=dist.ReduceOp.MIN)
+            _all_reduce_min(dist, s.min_tensor(level))
     for j in range(RK):
         s.sweep_stage(level, j, False)
         exchange_stage()

@@ -464,6 +464,21 @@ def test_ranks_in_different_processes_store_into_each_other_through_hip_ipc(rank
     assert r.stdout.count("owned equal, ghosts equal, waits that gave up: 0") == ranks
 
 
+def test_torch_path_over_gloo_on_this_gpu_equals_the_whole_level():
+    """The torch.distributed path of a partitioned level as bench.py's one-GPU rehearsal runs it — two processes, gloo, the
+    messages in DEVICE tensors (tools/torch_path_check.py): seven sweeps must equal the whole level on every rank.  (gloo's
+    point-to-point calls know nothing of streams; mgcfd/distributed.py stages such messages through the host.)  It is the
+    reference bench.py checks the library's rank loops against, so it has to be right itself."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
+                        os.path.join(root, "tools", "torch_path_check.py"), "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count(": 0 node(s) differ from the whole level") == 2, r.stdout[-1000:]
+
+
 def test_cfg5_eight_parts_library_loop():
     """BASELINE configs[4] at size with the sweep loop in the library: the 134^3 level in 8 parts as an in-process group
     (all on this GPU), four sweeps — a host thread per rank —, against mgcfd_smooth on the whole 2.4 M-node level."""

@@ -59,7 +59,11 @@ def rank_main(a):
     for p in range(a.ranks):
         wait_for(os.path.join(a.dir, f"attached.{p}"))
     s.rank_exchange(0)
-    s.rank_sweeps(0, a.sweeps)
+    if a.one_by_one:
+        for _ in range(a.sweeps):                           # (as bench.py issues them: a call per sweep)
+            s.rank_sweeps(0, 1)
+    else:
+        s.rank_sweeps(0, a.sweeps)
     got = s.get(0, "variables")
     late = s.rank_ipc_status(0)
     own, gh = P.global_ids[:P.n_owned], P.global_ids[P.n_owned:]
@@ -92,6 +96,7 @@ def main():
     ap.add_argument("--sweeps", type=int, default=5)
     ap.add_argument("--mesh", default="fvcorr", choices=["fvcorr", "m6wing", "tet"], help="local (fvcorr) or global (m6wing) time step")
     ap.add_argument("--time", type=int, default=0, help="also time that many sweeps per rank")
+    ap.add_argument("--one-by-one", action="store_true", help="one mgcfd_rank_sweeps call per sweep")
     ap.add_argument("--rank", type=int, default=-1)
     ap.add_argument("--dir", default="")
     a = ap.parse_args()
@@ -99,7 +104,7 @@ def main():
         sys.exit(rank_main(a))
     with tempfile.TemporaryDirectory(prefix="mgcfd_ipc_") as d:
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ranks", str(a.ranks), "--lattice", str(a.lattice), "--sweeps", str(a.sweeps), "--mesh", a.mesh,
-                                   "--time", str(a.time), "--rank", str(r), "--dir", d]) for r in range(a.ranks)]
+                                   "--time", str(a.time), "--rank", str(r), "--dir", d] + (["--one-by-one"] if a.one_by_one else [])) for r in range(a.ranks)]
         rcs = [p.wait(timeout=600) for p in procs]
     print("ranks returned", rcs)
     sys.exit(0 if all(rc == 0 for rc in rcs) else 1)

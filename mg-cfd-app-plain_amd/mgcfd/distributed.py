@@ -280,8 +280,26 @@ class LevelPerRankCycle:
         self.s, self.n, self.rank, self.world = solver, n_levels, rank, world
         self.rank_of = rank_of or (lambda l: l % world)
         self.dist = dist
-        self.send = send or (lambda t, dst: dist.send(t, dst))
-        self.recv = recv or (lambda t, src: dist.recv(t, src))
+        def _send(t, dst):
+            if _gloo_on_device(dist, t):                    # (see _gloo_on_device: staged through the host, stream drained)
+                import torch
+                torch.cuda.current_stream().synchronize()
+                dist.send(t.cpu(), dst)
+            else:
+                dist.send(t, dst)
+
+        def _recv(t, src):
+            if _gloo_on_device(dist, t):
+                import torch
+                torch.cuda.current_stream().synchronize()
+                h = torch.empty(t.shape, dtype=t.dtype)
+                dist.recv(h, src)
+                t.copy_(h)
+                torch.cuda.current_stream().synchronize()
+            else:
+                dist.recv(t, src)
+        self.send = send or _send
+        self.recv = recv or _recv
         self._stage = {}
 
     def _hand_over(self, level, name, src, dst):

@@ -398,7 +398,8 @@ def main():
             nonlocal step, exchange, part_mode
             try:
                 solver.rank_ipc_detach(0)                     # (whatever was tried before: from closed mappings, the buffered form)
-                if mode == "ipc":
+                solver.set_option("rank_split", 0 if mode == "ipc-unsplit" else 1)
+                if mode.startswith("ipc"):
                     blobs = [None] * world
                     dist.all_gather_object(blobs, solver.rank_ipc_export(0))
                     solver.rank_ipc_attach(0, blobs)          # (every rank's: the time-step all-reduce goes through the flags too)
@@ -416,7 +417,7 @@ def main():
                 torch.cuda.synchronize()
                 got1 = solver.get(0, "variables")
                 same = bool(np.array_equal(got1.view(np.int64), want.view(np.int64)))
-                if mode == "ipc" and (solver.rank_ipc_status(0) != 0 or os.environ.get("MGCFD_BENCH_FAIL_IPC") == "start"):
+                if mode.startswith("ipc") and (solver.rank_ipc_status(0) != 0 or os.environ.get("MGCFD_BENCH_FAIL_IPC") == "start"):
                     same = False                            # (a wait for a neighbour's message gave up)
                 ok = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -425,7 +426,8 @@ def main():
                 step = lambda: solver.rank_sweeps(0, 1)
                 info = solver.rank_halo_info(0)
                 exchange = (("libmgcfd_hip (mgcfd_rank_sweeps, HIP IPC): one launch per stage stores a rank's nodes into its neighbours' ghost slots and raises "
-                             "their flags, the time-step all-reduce through the same flags; " if mode == "ipc" else
+                             "their flags, the time-step all-reduce through the same flags"
+                             + ("; boundary tiles, message, interior tiles; " if mode == "ipc" else "; all tiles in one launch, then the message; ") if mode.startswith("ipc") else
                              "libmgcfd_hip (mgcfd_rank_sweeps): RCCL ncclSend/ncclRecv grouped on a second stream under the interior tiles; ")
                             + f"rank 0: {info['boundary_tiles']} boundary + {info['interior_tiles']} interior tiles; checked against the torch path at start-up"
                             + ("; sweeps replayed from hipGraphs" if (args.rank_graphs and mode == "library") else ""))
@@ -434,7 +436,7 @@ def main():
                 if rank == 0:
                     print(f"bench.py: exchange '{mode}' not used: {e}", file=sys.stderr)
                 part_notes.append(f"'{mode}' not used: {e}")
-                if mode == "ipc":
+                if mode.startswith("ipc"):
                     try:
                         solver.rank_ipc_detach(0)
                     except Exception:
@@ -479,14 +481,12 @@ def main():
                 if rehearsal:
                     # (every rank on device 0: RCCL refuses that; the IPC form needs no collective library at all)
                     solver.rank_attach_plain(rank, world)
-                    part_candidates = ["ipc"] if args.exchange in ("auto", "ipc") else []
-                    if os.environ.get("MGCFD_BENCH_REHEARSE_PICK") == "1":
-                        part_candidates = ["ipc", "ipc"]      # (rehearses the choice between two validated forms and the re-attachment)
+                    part_candidates = ["ipc", "ipc-unsplit"] if args.exchange == "auto" else (["ipc"] if args.exchange == "ipc" else [])
                 else:
                     uid = [mgcfd.rccl_unique_id() if rank == 0 else None]
                     dist.broadcast_object_list(uid, src=0)
                     solver.rank_attach_rccl(rank, world, uid[0])
-                    part_candidates = ["ipc", "library"] if args.exchange == "auto" else [args.exchange]
+                    part_candidates = ["ipc", "ipc-unsplit", "library"] if args.exchange == "auto" else [args.exchange]
                 solver.rank_set_halo(0, P)
             except Exception as e:
                 if rank == 0:
@@ -559,12 +559,13 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         gpu_seconds = ev0.elapsed_time(ev1) * 1e-3
-        if not (workload == "partitioned" and world > 1 and part_mode == "ipc"):
+        if not (workload == "partitioned" and world > 1 and part_mode.startswith("ipc")):
             break
         # The IPC exchange has only ever been rehearsed on ONE GPU, so its figure counts only if the state it leaves is the
         # state the torch path leaves after the same W + K sweeps from the same start, bit for bit on every rank, and no wait
         # for a neighbour gave up; otherwise the next way runs and is timed instead.
         got, late = solver.get(0, "variables"), solver.rank_ipc_status(0)
+        part_mode_run = part_mode
         part_mode = "torch"; part_reset()
         for _ in range(args.warmup + args.steps):
             sw.sweep()
@@ -582,7 +583,7 @@ def main():
             break
         if rank == 0:
             print("bench.py: the IPC exchange left a different state than the torch path (or a wait gave up): its figure is discarded", file=sys.stderr)
-        part_notes.append("'ipc' discarded after the run: its final state differed from the torch path's, or a wait for a neighbour gave up")
+        part_notes.append(f"'{part_mode_run}' discarded after the run: its final state differed from the torch path's, or a wait for a neighbour gave up")
         try:
             solver.rank_ipc_detach(0)
         except Exception:

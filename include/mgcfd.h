@@ -81,11 +81,15 @@ enum {
                                    Every variant gives bit-identical results. */
     MGCFD_OPT_FUSE_UPDATE = 5, /* 1 (default): mgcfd_smooth / mgcfd_run_cycles run each Runge-Kutta stage as ONE
                                   launch (fluxes + time_step, same operations); 0: one launch per loop */
-    MGCFD_OPT_GRAPH = 6        /* 1: replay each smoothing sweep / multigrid cycle from a captured hipGraph (one host
+    MGCFD_OPT_GRAPH = 6,       /* 1: replay each smoothing sweep / multigrid cycle from a captured hipGraph (one host
                                   call instead of 3 / ~24 launches).  0 (default): launch the kernels directly — on
                                   ROCm 7.2 / MI355X the graph costs ~1.7 us per kernel node more than direct launches
                                   (sweep 75 us replayed, 70 us launched), so it only pays when the host cannot keep
                                   the queue full */
+    MGCFD_OPT_RANK_SPLIT = 7   /* ranks in different processes, direct stores (mgcfd_rank_ipc_*): 1 (default) a stage runs its
+                                  boundary tiles first, sends, then the interior tiles (the message's flight is hidden);
+                                  0: all tiles in ONE launch, then the message (two launches less per stage, the flight
+                                  exposed).  Which is faster depends on the flight time: bench.py times both. */
 };
 
 /* Same 40-byte layout as the reference's edge_neighbour (src/Base/definitions.h:83). */

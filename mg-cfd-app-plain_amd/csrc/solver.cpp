@@ -69,7 +69,7 @@ struct HaloExchange {
     std::vector<int64_t> send_off, recv_off;             // [n_peers+1] node offsets of the peers' segments
     int32_t *send_idx = nullptr, *recv_idx = nullptr;    // device: library node ids, all peers concatenated
     double *send_buf[kSets] = {nullptr, nullptr, nullptr}, *recv_buf[kSets] = {nullptr, nullptr, nullptr};   // device: [nodes][5]
-    int32_t *tiles_boundary = nullptr, *tiles_interior = nullptr;
+    int32_t *tiles_boundary = nullptr, *tiles_interior = nullptr, *tiles_all = nullptr;   // (all = boundary then interior: one launch per stage)
     int32_t n_boundary = 0, n_interior = 0;
     hipStream_t comm_stream = nullptr;
     hipEvent_t packed[kSets] = {nullptr, nullptr, nullptr}, arrived[kSets] = {nullptr, nullptr, nullptr};
@@ -169,6 +169,7 @@ struct mgcfd_solver {
     unsigned long long *err = nullptr;       // device: packed (cell << 8 | code), ~0 = clean
     int opt_exact = 1, opt_timing = 0, opt_indirect_rw = 0, opt_check = 1, opt_variant = -1, opt_fuse = 1, opt_graph = 0;
     // (MGCFD_LAZY_RESIDUAL=0: every sweep's last stage writes residuals[] — for A/B measurements)
+    int opt_rank_split = 1;
     bool opt_lazy_residual = !(std::getenv("MGCFD_LAZY_RESIDUAL") && std::atoi(std::getenv("MGCFD_LAZY_RESIDUAL")) == 0);
     // check_for_invalid_variables: every checked launch carries its sequence number since the host last read the
     // error word, so the EARLIEST failing time_step wins, as in the reference (kernels.hip: err_key)
@@ -511,7 +512,7 @@ mgcfd_solver::~mgcfd_solver()
         if (lv.hx) {
             HaloExchange &hx = *lv.hx;
             for (void *m : hx.ipc_opened) (void)hipIpcCloseMemHandle(m);
-            void *hp[] = {hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.gmin, hx.peer_scalars, hx.push_target, hx.flags, hx.ticket, hx.ipc_timeouts, hx.gmins};
+            void *hp[] = {hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.tiles_all, hx.gmin, hx.peer_scalars, hx.push_target, hx.flags, hx.ticket, hx.ipc_timeouts, hx.gmins};
             for (hipEvent_t e : hx.bdone) if (e) (void)hipEventDestroy(e);
             for (void *p : hp) if (p) (void)hipFree(p);
             for (int b = 0; b < HaloExchange::kSets; b++) {
@@ -916,6 +917,7 @@ int mgcfd_set_option(mgcfd_solver *s, int option, int value)
             case MGCFD_OPT_FLUX_VARIANT: s->opt_variant = value; break;
             case MGCFD_OPT_FUSE_UPDATE: s->opt_fuse = value != 0; break;
             case MGCFD_OPT_GRAPH: s->opt_graph = value != 0; break;
+            case MGCFD_OPT_RANK_SPLIT: s->opt_rank_split = value != 0; break;
             default: throw std::invalid_argument("unknown option");
         }
     });
@@ -963,6 +965,7 @@ int mgcfd_get_option(const mgcfd_solver *s, int option, int *value)
         case MGCFD_OPT_FLUX_VARIANT: *value = s->opt_variant; break;
         case MGCFD_OPT_FUSE_UPDATE: *value = s->opt_fuse; break;
         case MGCFD_OPT_GRAPH: *value = s->opt_graph; break;
+        case MGCFD_OPT_RANK_SPLIT: *value = s->opt_rank_split; break;
         default: g_last_error = "unknown option"; return MGCFD_ERR_ARG;
     }
     return MGCFD_OK;
@@ -1842,6 +1845,11 @@ static void build_halo(mgcfd_solver *s, int level, int n_peers, const int *peers
     hx->n_interior = static_cast<int32_t>(ti.size());
     hx->tiles_boundary = dev_upload(tb);
     hx->tiles_interior = dev_upload(ti);
+    {
+        std::vector<int32_t> all(tb);
+        all.insert(all.end(), ti.begin(), ti.end());
+        hx->tiles_all = dev_upload(all);
+    }
     lv.hx = std::move(hx);
 }
 
@@ -2324,10 +2332,24 @@ static void rank_sweep_once_ipc(mgcfd_solver *s, int level)
             s->settle_fluxes(lv);
         }
         s->force_check = s->next_check();
-        s->op_fused_stage(level, j, in, out, j == 0 ? apply : 0, j == 2, start, j == 2 && global_dt && part_look_ahead(), false, nullptr, hx.tiles_boundary, hx.n_boundary, true, min_list, n_min);
-        lv.stage_out = out;
-        ipc_push(s, lv, out, j == 1 ? 2 : 1, j);            // (before the rotation: stage 1 writes old_variables' buffer, stages 0 and 2 q_alt's)
-        stage_interior(s, level, j, apply, min_list, n_min);
+        if (s->opt_rank_split) {
+            s->op_fused_stage(level, j, in, out, j == 0 ? apply : 0, j == 2, start, j == 2 && global_dt && part_look_ahead(), false, nullptr, hx.tiles_boundary, hx.n_boundary, true, min_list, n_min);
+            lv.stage_out = out;
+            ipc_push(s, lv, out, j == 1 ? 2 : 1, j);        // (before the rotation: stage 1 writes old_variables' buffer, stages 0 and 2 q_alt's)
+            stage_interior(s, level, j, apply, min_list, n_min);
+        } else {
+            // MGCFD_OPT_RANK_SPLIT = 0: every tile of the rank in one launch, the message behind it
+            s->op_fused_stage(level, j, in, out, j == 0 ? apply : 0, j == 2, start, j == 2 && global_dt && part_look_ahead(), false, nullptr, hx.tiles_all, hx.n_boundary + hx.n_interior, true, min_list, n_min);
+            s->force_check = -1;
+            lv.stage_out = out;
+            ipc_push(s, lv, out, j == 1 ? 2 : 1, j);
+            if (j == 2) {
+                lv.rot = (lv.rot + 1) % 3;
+                lv.apply_rot();
+                lv.stage_out = lv.q;
+                lv.min_ahead = apply != 0 && part_look_ahead();
+            }
+        }
     }
 }
 

@@ -24,7 +24,7 @@ NVAR = 5
 RK = 3
 LOOPS = ("flux", "update", "compute_step", "time_step", "restrict", "prolong", "indirect_rw")
 ARR = {"variables": 0, "old_variables": 1, "fluxes": 2, "residuals": 3, "step_factors": 4, "volumes": 5, "stage": 6}
-OPT = {"exact": 0, "timing": 1, "indirect_rw": 2, "check_invalid": 3, "flux_variant": 4, "fuse_update": 5, "graph": 6}
+OPT = {"exact": 0, "timing": 1, "indirect_rw": 2, "check_invalid": 3, "flux_variant": 4, "fuse_update": 5, "graph": 6, "rank_split": 7}
 ERR_NAMES = {0: "OK", 1: "ERR_ARG", 2: "ERR_IO", 3: "ERR_HIP", 4: "ERR_NAN", 5: "ERR_NEG_DENSITY",
              6: "ERR_NEG_ENERGY", 7: "ERR_VALIDATION"}
 

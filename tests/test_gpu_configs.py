@@ -446,8 +446,9 @@ def test_library_loop_in_its_other_forms(form, monkeypatch):
     _group_sweeps_check(mg, 3, 5)
 
 
-@pytest.mark.parametrize("ranks,lattice,sweeps,mesh", [(2, 14, 5, "fvcorr"), (3, 20, 7, "fvcorr"), (2, 16, 6, "m6wing"), (4, 22, 9, "m6wing")])
-def test_ranks_in_different_processes_store_into_each_other_through_hip_ipc(ranks, lattice, sweeps, mesh):
+@pytest.mark.parametrize("ranks,lattice,sweeps,mesh,extra", [(2, 14, 5, "fvcorr", []), (3, 20, 7, "fvcorr", []), (2, 16, 6, "m6wing", []), (4, 22, 9, "m6wing", []),
+                                                             (3, 20, 7, "m6wing", ["--unsplit"]), (2, 30, 8, "tet", ["--one-by-one"])])
+def test_ranks_in_different_processes_store_into_each_other_through_hip_ipc(ranks, lattice, sweeps, mesh, extra):
     """tools/ipc_ranks_check.py: `ranks` PROCESSES on this one GPU, each with its part of a local-time-step level, the state
     buffers and flag words of its neighbours opened through HIP IPC (mgcfd_rank_ipc_export / _attach): a stage's message is one
     launch that stores into the neighbours' ghost slots and raises their flags, the next stage waits for them.  Every rank
@@ -458,7 +459,7 @@ def test_ranks_in_different_processes_store_into_each_other_through_hip_ipc(rank
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ipc_ranks_check.py"), "--ranks", str(ranks), "--lattice", str(lattice), "--sweeps", str(sweeps), "--mesh", mesh],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ipc_ranks_check.py"), "--ranks", str(ranks), "--lattice", str(lattice), "--sweeps", str(sweeps), "--mesh", mesh] + extra,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("owned equal, ghosts equal, waits that gave up: 0") == ranks

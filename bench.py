@@ -398,7 +398,7 @@ def main():
             nonlocal step, exchange, part_mode
             try:
                 solver.rank_ipc_detach(0)                     # (whatever was tried before: from closed mappings, the buffered form)
-                solver.set_option("rank_split", 0 if mode == "ipc-unsplit" else 1)
+                solver.set_option("rank_split", {"ipc-unsplit": 0, "ipc-fused": 2}.get(mode, 1))
                 if mode.startswith("ipc"):
                     blobs = [None] * world
                     dist.all_gather_object(blobs, solver.rank_ipc_export(0))
@@ -427,7 +427,8 @@ def main():
                 info = solver.rank_halo_info(0)
                 exchange = (("libmgcfd_hip (mgcfd_rank_sweeps, HIP IPC): one launch per stage stores a rank's nodes into its neighbours' ghost slots and raises "
                              "their flags, the time-step all-reduce through the same flags"
-                             + ("; boundary tiles, message, interior tiles; " if mode == "ipc" else "; all tiles in one launch, then the message; ") if mode.startswith("ipc") else
+                             + {"ipc": "; boundary tiles, message, interior tiles; ", "ipc-unsplit": "; all tiles in one launch, then the message; ",
+                                "ipc-fused": "; ONE launch per stage that sends its own message (boundary tiles first); "}[mode] if mode.startswith("ipc") else
                              "libmgcfd_hip (mgcfd_rank_sweeps): RCCL ncclSend/ncclRecv grouped on a second stream under the interior tiles; ")
                             + f"rank 0: {info['boundary_tiles']} boundary + {info['interior_tiles']} interior tiles; checked against the torch path at start-up"
                             + ("; sweeps replayed from hipGraphs" if (args.rank_graphs and mode == "library") else ""))
@@ -481,12 +482,12 @@ def main():
                 if rehearsal:
                     # (every rank on device 0: RCCL refuses that; the IPC form needs no collective library at all)
                     solver.rank_attach_plain(rank, world)
-                    part_candidates = ["ipc", "ipc-unsplit"] if args.exchange == "auto" else (["ipc"] if args.exchange == "ipc" else [])
+                    part_candidates = ["ipc-fused", "ipc", "ipc-unsplit"] if args.exchange == "auto" else (["ipc"] if args.exchange == "ipc" else [])
                 else:
                     uid = [mgcfd.rccl_unique_id() if rank == 0 else None]
                     dist.broadcast_object_list(uid, src=0)
                     solver.rank_attach_rccl(rank, world, uid[0])
-                    part_candidates = ["ipc", "ipc-unsplit", "library"] if args.exchange == "auto" else [args.exchange]
+                    part_candidates = ["ipc-fused", "ipc", "ipc-unsplit", "library"] if args.exchange == "auto" else [args.exchange]
                 solver.rank_set_halo(0, P)
             except Exception as e:
                 if rank == 0:

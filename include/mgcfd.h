@@ -89,7 +89,9 @@ enum {
     MGCFD_OPT_RANK_SPLIT = 7   /* ranks in different processes, direct stores (mgcfd_rank_ipc_*): 1 (default) a stage runs its
                                   boundary tiles first, sends, then the interior tiles (the message's flight is hidden);
                                   0: all tiles in ONE launch, then the message (two launches less per stage, the flight
-                                  exposed).  Which is faster depends on the flight time: bench.py times both. */
+                                  exposed); 2: ONE launch that sends its own message — the boundary tiles come first, their
+                                  epilogue stores into the neighbours, the last of them raises the flags while the interior
+                                  tiles still run.  Which is fastest depends on the flight time: bench.py times all three. */
 };
 
 /* Same 40-byte layout as the reference's edge_neighbour (src/Base/definitions.h:83). */

@@ -38,6 +38,20 @@ struct PushFlags {
     unsigned long long value = 0;
     int n = 0;
 };
+// The message of a stage sent by the stage launch itself (k_flux_tile<..., PUSH>): the launch covers a rank's boundary tiles
+// FIRST (workgroups [0, n_boundary)) and its interior tiles behind them; a boundary tile's epilogue stores the nodes the
+// neighbours need (per-node lists: send_ptr / send_peer / send_target) into their ghost slots, and the boundary tile that
+// finishes last raises the neighbours' flags — while the interior tiles of the same launch are still running.
+struct StagePush {
+    const int32_t *send_ptr = nullptr;      // [nel + 1] (library numbering): a node's entries
+    const int8_t *send_peer = nullptr;      // [entries] position of the destination in peers
+    const int32_t *send_target = nullptr;   // [entries] the node's index in that peer's numbering
+    PushPeers peers;
+    PushFlags flags;
+    unsigned *ticket = nullptr;
+    int32_t n_boundary = 0;
+};
+
 // A rank's flag words are rows of four (one per Runge-Kutta stage + one for the time-step all-reduce), one row per SOURCE rank.
 constexpr int kMaxIpcRanks = 16;
 struct FlagRows { int row[kMaxIpcRanks] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; };

@@ -542,7 +542,7 @@ __device__ __forceinline__ void boundary_rows(const NodeQ &me, const FluxC &fm, 
 // TAIL: the level has long rows (TailPlan): the per-node loop stops at the tile's row limit and the workgroup
 // evaluates the remaining entries together (see below).
 // WMODE: 0 = the length factor k recomputed from the row's weights, 1 = k streamed with them, 2 = indexed weights (above).
-template <int MINW, int WMODE, bool FUSE, bool ACC, int ROLE, bool TAIL>
+template <int MINW, int WMODE, bool FUSE, bool ACC, int ROLE, bool TAIL, bool PUSH = false>
 __global__ void __launch_bounds__(kBlock, MINW)
 k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at wave launch (Makefile:
             // -amdgpu-kernarg-preload-count): what the first loads of the prologue need comes first
@@ -552,9 +552,11 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
             const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
             double *__restrict__ fluxes, int classes, FusedStep fs, TailPlan tp,
-            const uint16_t *__restrict__ gat16, const int32_t *__restrict__ te_chunk_ptr, const double *__restrict__ te_w3)
+            const uint16_t *__restrict__ gat16, const int32_t *__restrict__ te_chunk_ptr, const double *__restrict__ te_w3,
+            StagePush push /* PUSH instantiations only: the stage sends its own message (device_plan.hpp) */)
 {
     constexpr bool LOADK = WMODE == 1;
+    static_assert(!PUSH || FUSE, "only a fused stage sends its message");
     constexpr bool IDXW = WMODE == 2;
     static_assert(!(IDXW && TAIL), "indexed weights: levels without long rows only");
     __shared__ double2 tile[kTileCap * kLdsRecD2];
@@ -573,6 +575,12 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     unsigned t = xcd_contiguous_block(blockIdx.x, n_tiles);            // n_tiles == gridDim.x, without the hidden-argument load
+    if (PUSH) {
+        // boundary tiles in dispatch order first (their message leaves while the rest of the launch runs), the interior
+        // tiles behind them in XCD-contiguous ranges
+        const unsigned nb = unsigned(push.n_boundary);
+        t = blockIdx.x < nb ? blockIdx.x : nb + xcd_contiguous_block(blockIdx.x - nb, n_tiles - nb);
+    }
     if (FUSE && fs.tile_list) t = unsigned(fs.tile_list[t]);           // a launch over part of the level (uniform branch)
     const int64_t base = int64_t(t) * kTile;
     const int64_t i = base + tid;
@@ -920,6 +928,34 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         } else if (ROLE == 4) {
             const Derived d = derive(rho, mx, my, mz, en);
             fs.next_legacy_sf[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
+        }
+        if (PUSH && blockIdx.x < unsigned(push.n_boundary)) {
+            // this node into the ghost slots of the neighbours that hold it
+            for (int32_t e = push.send_ptr[i]; e < push.send_ptr[i + 1]; e++) {
+                const int k = push.send_peer[e];
+                const int64_t g = push.send_target[e];
+                double *dst = push.peers.base[0];
+                int64_t ps = push.peers.stride[0];
+#pragma unroll
+                for (int p = 1; p < kMaxPushPeers; p++) if (p == k) { dst = push.peers.base[p]; ps = push.peers.stride[p]; }
+                dst[g] = rho; dst[ps + g] = mx; dst[2 * ps + g] = my; dst[3 * ps + g] = mz; dst[4 * ps + g] = en;
+            }
+        }
+    }
+    if (PUSH && blockIdx.x < unsigned(push.n_boundary)) {              // (uniform per workgroup)
+        // as k_halo_push_flags: the stores acknowledged, the workgroup counted off, the last boundary tile raises the flags
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            const unsigned done = __hip_atomic_fetch_add(push.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == unsigned(push.n_boundary) - 1u) {
+                __hip_atomic_store(push.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+#pragma unroll
+                for (int p = 0; p < kMaxPushPeers; p++)
+                    if (p < push.flags.n) __hip_atomic_store(push.flags.flag[p], push.flags.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     if (ROLE == 3 || (ROLE >= 2 && ROLE <= 4 && fs.sumsq_partial)) {  // uniform: every thread of the workgroup takes part
@@ -2012,7 +2048,7 @@ void launch_step_factor_legacy(hipStream_t st, int64_t nel, int64_t stride, cons
 { hipLaunchKernelGGL(k_step_factor_legacy, dim3(grid_for(nel)), dim3(kBlock), 0, st, nel, stride, q, volumes, sf, old_variables); }
 
 void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const FarField &ff, double *fluxes,
-                 int classes, int accumulate, int variant, const FusedStep *fused)
+                 int classes, int accumulate, int variant, const FusedStep *fused, const StagePush *push)
 {
     const dim3 block(kBlock);
     FusedStep fs{};
@@ -2029,9 +2065,33 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     hipLaunchKernelGGL((k_flux_tile<((TAIL) && ((ACC) || (ROLE) == 5)) ? 2 : 3, WMODE, FUSE, ACC, ROLE, TAIL>), grid, block, 0, st, q, p.tile_halo,     \
                        uint32_t(grid.x), p.pad_row, p.stride, nel_arg, p.slice_row0, p.rows_int, p.rows_bnd, \
                        p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs, p.tail, p.gat16,     \
-                       p.te_chunk_ptr, p.te_w3)
+                       p.te_chunk_ptr, p.te_w3, StagePush{})
     // levels with long rows (tetrahedral meshes, hubs) run the instantiation that hands them to the workgroup
     const bool tail = p.has_tail && (classes & 1);
+    // a stage that sends its own message (StagePush): fused stages over a tile list, roles 0-4, k streamed or recomputed
+    if (push && fused && part && !fs.vin_flux) {
+        const int role_p = fs.partial_min ? 0 : (fs.next_partial_min ? 3 : (fs.next_legacy_sf ? 4 : (fs.residuals ? 2 : 1)));
+#define MGCFD_PUSH_LAUNCH_T(WMODE, ROLE, TAIL)                                                                  \
+    hipLaunchKernelGGL((k_flux_tile<3, WMODE, true, false, ROLE, TAIL, true>), grid, block, 0, st, q, p.tile_halo,     \
+                       uint32_t(grid.x), p.pad_row, p.stride, nel_arg, p.slice_row0, p.rows_int, p.rows_bnd, \
+                       p.nbr16, p.w, p.tile_ovf_ptr, p.tile_ovf, ff, fluxes, classes, fs, p.tail, p.gat16,     \
+                       p.te_chunk_ptr, p.te_w3, *push)
+#define MGCFD_PUSH_LAUNCH_R(WMODE, TAIL)                                                                        \
+    do {                                                                                                       \
+        if (role_p == 0) MGCFD_PUSH_LAUNCH_T(WMODE, 0, TAIL);                                                  \
+        else if (role_p == 2) MGCFD_PUSH_LAUNCH_T(WMODE, 2, TAIL);                                             \
+        else if (role_p == 3) MGCFD_PUSH_LAUNCH_T(WMODE, 3, TAIL);                                             \
+        else if (role_p == 4) MGCFD_PUSH_LAUNCH_T(WMODE, 4, TAIL);                                             \
+        else MGCFD_PUSH_LAUNCH_T(WMODE, 1, TAIL);                                                              \
+    } while (0)
+        if (role_p == 0 && q != fs.old_variables) throw std::logic_error("a first stage whose input is not the sweep's start state");
+        const bool k_streamed = (variant & 1) == 0;
+        if (tail) { if (k_streamed) MGCFD_PUSH_LAUNCH_R(1, true); else MGCFD_PUSH_LAUNCH_R(0, true); }
+        else { if (k_streamed) MGCFD_PUSH_LAUNCH_R(1, false); else MGCFD_PUSH_LAUNCH_R(0, false); }
+#undef MGCFD_PUSH_LAUNCH_R
+#undef MGCFD_PUSH_LAUNCH_T
+        return;
+    }
     // variant bit 4 (16): indexed weights — every edge's weights once per tile (needs the tile edge lists: p.edge_once)
     const bool indexed = (variant & 16) && p.edge_once && p.te_w3 && !tail;
 #define MGCFD_TILE_LAUNCH_R(LOADK, FUSE, ACC, ROLE)                                                            \

@@ -14,7 +14,8 @@
     void launch_step_factor_legacy(hipStream_t, int64_t nel, int64_t stride, const double *q, const double *volumes, \
                                    double *sf, double *old_variables);                                               \
     void launch_flux(hipStream_t, const DevicePlan &, const double *q, const FarField &, double *fluxes,             \
-                     int classes, int accumulate, int variant, const FusedStep *fused);                              \
+                     int classes, int accumulate, int variant, const FusedStep *fused,                               \
+                     const StagePush *push = nullptr);                                                               \
     void launch_indirect_rw(hipStream_t, const DevicePlan &, const double *q, double *fluxes, int variant);                       \
     void launch_time_step(hipStream_t, int64_t nel, int64_t stride, int j, double *sf, double *fluxes,               \
                           const double *old_variables, double *q, const int32_t *old_of_new,                         \

@@ -103,6 +103,8 @@ struct HaloExchange {
     int peer_rot_delta[kMaxPushPeers] = {};              // (peer's rotation - ours) mod 3 when the buffers were exchanged
     unsigned long long *peer_flag[kMaxPushPeers] = {};   // opened: the words of peer k's flag array this rank raises
     std::vector<void *> ipc_opened;                      // every mapping opened (closed again in mgcfd_rank_detach / the destructor)
+    int32_t *node_send_ptr = nullptr, *node_send_target = nullptr;   // device: the message per NODE (StagePush: a stage that sends it itself)
+    int8_t *node_send_peer = nullptr;
     int64_t total_send() const { return send_off.empty() ? 0 : send_off.back(); }
     int64_t total_recv() const { return recv_off.empty() ? 0 : recv_off.back(); }
 };
@@ -340,7 +342,8 @@ struct mgcfd_solver {
     void op_fused_stage(int l, int j, const double *in, double *out, int apply_min, bool with_residual,
                         const double *old = nullptr, bool look_ahead = false, bool sumsq = false,
                         const double *vin_flux = nullptr, const int32_t *tile_list = nullptr, int32_t n_list = 0,
-                        bool count_iters = true, const double *min_list = nullptr, int n_min = 0, bool lazy_residual = false)
+                        bool count_iters = true, const double *min_list = nullptr, int n_min = 0, bool lazy_residual = false,
+                        const StagePush *push = nullptr)
     {
         DeviceLevel &lv = level(l);
         settle_residuals(lv);                       // (a sweep that supersedes the residual has dropped the flag: smooth_once)
@@ -369,8 +372,8 @@ struct mgcfd_solver {
         if (vin_flux) fs.check_vin = next_check();       // the absorbed first stage's check_for_invalid_variables comes first
         fs.check = force_check >= 0 ? force_check : next_check();
         Timed t(this, l, MGCFD_LOOP_FLUX, true);
-        if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs);
-        else fast::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs);
+        if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs, push);
+        else fast::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs, push);
         if (count_iters) {                          // (a stage launched in two parts counts once)
             lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
             lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
@@ -512,7 +515,7 @@ mgcfd_solver::~mgcfd_solver()
         if (lv.hx) {
             HaloExchange &hx = *lv.hx;
             for (void *m : hx.ipc_opened) (void)hipIpcCloseMemHandle(m);
-            void *hp[] = {hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.tiles_all, hx.gmin, hx.peer_scalars, hx.push_target, hx.flags, hx.ticket, hx.ipc_timeouts, hx.gmins};
+            void *hp[] = {hx.node_send_ptr, hx.node_send_target, hx.node_send_peer, hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.tiles_all, hx.gmin, hx.peer_scalars, hx.push_target, hx.flags, hx.ticket, hx.ipc_timeouts, hx.gmins};
             for (hipEvent_t e : hx.bdone) if (e) (void)hipEventDestroy(e);
             for (void *p : hp) if (p) (void)hipFree(p);
             for (int b = 0; b < HaloExchange::kSets; b++) {
@@ -917,7 +920,7 @@ int mgcfd_set_option(mgcfd_solver *s, int option, int value)
             case MGCFD_OPT_FLUX_VARIANT: s->opt_variant = value; break;
             case MGCFD_OPT_FUSE_UPDATE: s->opt_fuse = value != 0; break;
             case MGCFD_OPT_GRAPH: s->opt_graph = value != 0; break;
-            case MGCFD_OPT_RANK_SPLIT: s->opt_rank_split = value != 0; break;
+            case MGCFD_OPT_RANK_SPLIT: s->opt_rank_split = value < 0 ? 0 : (value > 2 ? 2 : value); break;
             default: throw std::invalid_argument("unknown option");
         }
     });
@@ -2332,7 +2335,32 @@ static void rank_sweep_once_ipc(mgcfd_solver *s, int level)
             s->settle_fluxes(lv);
         }
         s->force_check = s->next_check();
-        if (s->opt_rank_split) {
+        if (s->opt_rank_split == 2 && hx.n_boundary > 0) {
+            // MGCFD_OPT_RANK_SPLIT = 2: ONE launch per stage that sends its own message — the boundary tiles first, their
+            // epilogue stores into the neighbours, the last of them raises the flags, the interior tiles run on meanwhile
+            StagePush sp;
+            sp.send_ptr = hx.node_send_ptr; sp.send_peer = hx.node_send_peer; sp.send_target = hx.node_send_target;
+            sp.ticket = hx.ticket;
+            sp.n_boundary = hx.n_boundary;
+            const int which = j == 1 ? 2 : 1;
+            sp.peers.n = sp.flags.n = static_cast<int>(hx.peer.size());
+            for (int k = 0; k < sp.peers.n; k++) {
+                sp.peers.base[k] = hx.peer_state[k][(lv.rot + hx.peer_rot_delta[k] + which) % 3];
+                sp.peers.stride[k] = hx.peer_stride[k];
+                sp.flags.flag[k] = hx.peer_flag[k] + j;
+            }
+            hx.seq++;
+            sp.flags.value = hx.seq;
+            s->op_fused_stage(level, j, in, out, j == 0 ? apply : 0, j == 2, start, j == 2 && global_dt && part_look_ahead(), false, nullptr, hx.tiles_all, hx.n_boundary + hx.n_interior, true, min_list, n_min, false, &sp);
+            s->force_check = -1;
+            lv.stage_out = out;
+            if (j == 2) {
+                lv.rot = (lv.rot + 1) % 3;
+                lv.apply_rot();
+                lv.stage_out = lv.q;
+                lv.min_ahead = apply != 0 && part_look_ahead();
+            }
+        } else if (s->opt_rank_split) {
             s->op_fused_stage(level, j, in, out, j == 0 ? apply : 0, j == 2, start, j == 2 && global_dt && part_look_ahead(), false, nullptr, hx.tiles_boundary, hx.n_boundary, true, min_list, n_min);
             lv.stage_out = out;
             ipc_push(s, lv, out, j == 1 ? 2 : 1, j);        // (before the rotation: stage 1 writes old_variables' buffer, stages 0 and 2 q_alt's)
@@ -2499,6 +2527,26 @@ int mgcfd_rank_ipc_attach(mgcfd_solver *s, int level, int n_exports, const void 
         hx.ipc_all = others == c.world - 1;
         if (hx.push_target) { HIP_CHECK(hipFree(hx.push_target)); hx.push_target = nullptr; }
         hx.push_target = dev_upload(target);
+        {   // the same message per node (library numbering): what a stage that sends its own message walks (StagePush)
+            std::vector<int32_t> sidx(static_cast<size_t>(hx.total_send()));
+            HIP_CHECK(hipMemcpy(sidx.data(), hx.send_idx, sizeof(int32_t) * sidx.size(), hipMemcpyDeviceToHost));
+            std::vector<int32_t> ptr(static_cast<size_t>(lv.dp.stride) + 2, 0), tgt(sidx.size());
+            std::vector<int8_t> peer(sidx.size());
+            for (int32_t n : sidx) ptr[static_cast<size_t>(n) + 1]++;
+            for (size_t n = 1; n < ptr.size(); n++) ptr[n] += ptr[n - 1];
+            std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+            for (size_t k = 0; k < hx.peer.size(); k++)
+                for (int64_t m = hx.send_off[k]; m < hx.send_off[k + 1]; m++) {
+                    const int32_t at = fill[static_cast<size_t>(sidx[static_cast<size_t>(m)])]++;
+                    peer[static_cast<size_t>(at)] = static_cast<int8_t>(k);
+                    tgt[static_cast<size_t>(at)] = target[static_cast<size_t>(m)];
+                }
+            for (void *old : {static_cast<void *>(hx.node_send_ptr), static_cast<void *>(hx.node_send_target), static_cast<void *>(hx.node_send_peer)}) if (old) HIP_CHECK(hipFree(old));
+            hx.node_send_ptr = dev_upload(ptr);
+            if (tgt.empty()) { tgt.push_back(0); peer.push_back(0); }
+            hx.node_send_target = dev_upload(tgt);
+            hx.node_send_peer = dev_upload(peer);
+        }
         hx.ipc = true;
     });
 }

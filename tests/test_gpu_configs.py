@@ -447,7 +447,9 @@ def test_library_loop_in_its_other_forms(form, monkeypatch):
 
 
 @pytest.mark.parametrize("ranks,lattice,sweeps,mesh,extra", [(2, 14, 5, "fvcorr", []), (3, 20, 7, "fvcorr", []), (2, 16, 6, "m6wing", []), (4, 22, 9, "m6wing", []),
-                                                             (3, 20, 7, "m6wing", ["--unsplit"]), (2, 30, 8, "tet", ["--one-by-one"])])
+                                                             (3, 20, 7, "m6wing", ["--unsplit"]), (2, 30, 8, "tet", ["--one-by-one"]),
+                                                             (2, 16, 6, "m6wing", ["--fused"]), (4, 24, 9, "m6wing", ["--fused"]), (3, 20, 7, "fvcorr", ["--fused"]),
+                                                             (3, 40, 5, "tet", ["--fused", "--one-by-one"])])
 def test_ranks_in_different_processes_store_into_each_other_through_hip_ipc(ranks, lattice, sweeps, mesh, extra):
     """tools/ipc_ranks_check.py: `ranks` PROCESSES on this one GPU, each with its part of a local-time-step level, the state
     buffers and flag words of its neighbours opened through HIP IPC (mgcfd_rank_ipc_export / _attach): a stage's message is one

@@ -52,6 +52,8 @@ def rank_main(a):
     s.rank_attach_plain(a.rank, a.ranks)
     if a.unsplit:
         s.set_option("rank_split", 0)                       # every tile of a stage in one launch, the message behind it
+    if a.fused:
+        s.set_option("rank_split", 2)                       # one launch per stage that sends its own message (boundary tiles first)
     s.rank_set_halo(0, P)
     publish(os.path.join(a.dir, f"export.{a.rank}"), s.rank_ipc_export(0))
     peers = sorted(set(P.send) | set(P.recv))
@@ -100,6 +102,7 @@ def main():
     ap.add_argument("--time", type=int, default=0, help="also time that many sweeps per rank")
     ap.add_argument("--one-by-one", action="store_true", help="one mgcfd_rank_sweeps call per sweep")
     ap.add_argument("--unsplit", action="store_true", help="MGCFD_OPT_RANK_SPLIT = 0")
+    ap.add_argument("--fused", action="store_true", help="MGCFD_OPT_RANK_SPLIT = 2")
     ap.add_argument("--rank", type=int, default=-1)
     ap.add_argument("--dir", default="")
     a = ap.parse_args()
@@ -107,7 +110,7 @@ def main():
         sys.exit(rank_main(a))
     with tempfile.TemporaryDirectory(prefix="mgcfd_ipc_") as d:
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ranks", str(a.ranks), "--lattice", str(a.lattice), "--sweeps", str(a.sweeps), "--mesh", a.mesh,
-                                   "--time", str(a.time), "--rank", str(r), "--dir", d] + (["--one-by-one"] if a.one_by_one else []) + (["--unsplit"] if a.unsplit else [])) for r in range(a.ranks)]
+                                   "--time", str(a.time), "--rank", str(r), "--dir", d] + (["--one-by-one"] if a.one_by_one else []) + (["--unsplit"] if a.unsplit else []) + (["--fused"] if a.fused else [])) for r in range(a.ranks)]
         rcs = [p.wait(timeout=600) for p in procs]
     print("ranks returned", rcs)
     sys.exit(0 if all(rc == 0 for rc in rcs) else 1)

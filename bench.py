@@ -379,6 +379,7 @@ def main():
         part_candidates = []                                 # ways to run the sweep loop inside the library still to be tried, in order
         part_mode = "torch"
         part_notes = []
+        ipc_gave_up = False
 
         def part_reset():
             """every rank back at the perturbed start state, ghosts current (whatever runs the loop)"""
@@ -395,34 +396,57 @@ def main():
             grouped on a second stream, the interior tiles under the transfer, one unpack; `ipc`: the messages as direct stores
             into the neighbours' memory (HIP IPC), the time-step all-reduce through the same flags.  Before it is trusted it
             must reproduce, on every rank, the sweep the torch path makes from the same state, bit for bit."""
-            nonlocal step, exchange, part_mode
+            nonlocal step, exchange, part_mode, ipc_gave_up
+            if mode.startswith("ipc") and ipc_gave_up:
+                part_notes.append(f"'{mode}' not tried: a wait for a neighbour's message gave up in another IPC form")
+                return False
             try:
-                solver.rank_ipc_detach(0)                     # (whatever was tried before: from closed mappings, the buffered form)
-                solver.set_option("rank_split", {"ipc-unsplit": 0, "ipc-fused": 2}.get(mode, 1))
+                def phase(what, fn):
+                    """a step that only THIS rank can see failing: every rank learns of it before the next collective call"""
+                    err = None
+                    try:
+                        out = fn()
+                    except Exception as e:
+                        out, err = None, e
+                    t = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    if float(t.item()) != 1.0:
+                        raise RuntimeError(f"{what} failed on some rank" + (f" (here: {err})" if err else ""))
+                    return out
+
+                def prepare():
+                    solver.rank_ipc_detach(0)               # (whatever was tried before: from closed mappings, the buffered form)
+                    solver.set_option("rank_split", {"ipc-unsplit": 0, "ipc-fused": 2}.get(mode, 1))
+                    solver.set_option("graph", 1 if (args.rank_graphs and mode == "library") else 0)
+                    return solver.rank_ipc_export(0) if mode.startswith("ipc") else None
+                blob = phase("preparing the exchange", prepare)
                 if mode.startswith("ipc"):
                     blobs = [None] * world
-                    dist.all_gather_object(blobs, solver.rank_ipc_export(0))
-                    solver.rank_ipc_attach(0, blobs)          # (every rank's: the time-step all-reduce goes through the flags too)
-                    dist.barrier()                            # nobody pushes before everybody has attached
-                solver.set_option("graph", 1 if (args.rank_graphs and mode == "library") else 0)
+                    dist.all_gather_object(blobs, blob)
+                    phase("opening the neighbours' buffers (HIP IPC)", lambda: solver.rank_ipc_attach(0, blobs))   # (every rank's: the time-step all-reduce goes through the flags too)
                 part_mode = "torch"; part_reset()
                 sw.sweep()
                 torch.cuda.synchronize()
                 want = solver.get(0, "variables")
                 # (the IPC form stores into the NEIGHBOURS' buffers: no rank may start it while another one is still in the torch
-                #  path's sweep above — found as an intermittent start-up mismatch in the one-GPU rehearsal)
-                torch.cuda.synchronize(); dist.barrier()
+                #  path's sweep above — found as an intermittent start-up mismatch in the one-GPU rehearsal; part_reset has the barrier)
                 part_mode = mode; part_reset()
-                solver.rank_sweeps(0, 1)
-                torch.cuda.synchronize()
-                got1 = solver.get(0, "variables")
-                same = bool(np.array_equal(got1.view(np.int64), want.view(np.int64)))
-                if mode.startswith("ipc") and (solver.rank_ipc_status(0) != 0 or os.environ.get("MGCFD_BENCH_FAIL_IPC") == "start"):
-                    same = False                            # (a wait for a neighbour's message gave up)
-                ok = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if float(ok.item()) != 1.0:
-                    raise RuntimeError("the library's sweep differs from the torch path's on some rank")
+
+                def one_sweep():
+                    solver.rank_sweeps(0, 1)
+                    torch.cuda.synchronize()
+                    return solver.get(0, "variables"), (solver.rank_ipc_status(0) if mode.startswith("ipc") else 0)
+                got1, late = phase("the library's sweep", one_sweep)
+                same = bool(np.array_equal(got1.view(np.int64), want.view(np.int64))) and late == 0
+                if mode.startswith("ipc") and os.environ.get("MGCFD_BENCH_FAIL_IPC") == "start":
+                    same = False
+                # every rank's verdict, and whether a wait for a neighbour gave up anywhere (about 2 s each: the other IPC forms are then not tried)
+                verdict = torch.tensor([1.0 if same else 0.0, -1.0 if late else 0.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+                if float(verdict[1].item()) < 0.0:
+                    ipc_gave_up = True
+                if float(verdict[0].item()) != 1.0:
+                    raise RuntimeError("the library's sweep differs from the torch path's on some rank" + (", or a wait for a neighbour's message gave up" if ipc_gave_up else ""))
                 step = lambda: solver.rank_sweeps(0, 1)
                 info = solver.rank_halo_info(0)
                 exchange = (("libmgcfd_hip (mgcfd_rank_sweeps, HIP IPC): one launch per stage stores a rank's nodes into its neighbours' ghost slots and raises "
@@ -478,21 +502,36 @@ def main():
         if world == 1:
             step, exchange = (lambda: solver.smooth(0, 1)), None
         elif args.exchange != "torch":
+            setup_error = None
+            uid = [None]
+            if not rehearsal:
+                try:
+                    uid = [mgcfd.rccl_unique_id() if rank == 0 else None]
+                except Exception as e:                       # (rank 0 only can fail here; it still takes part in the broadcast)
+                    setup_error = e
+                dist.broadcast_object_list(uid, src=0)
             try:
+                if setup_error:
+                    raise setup_error
                 if rehearsal:
                     # (every rank on device 0: RCCL refuses that; the IPC form needs no collective library at all)
                     solver.rank_attach_plain(rank, world)
                     part_candidates = ["ipc-fused", "ipc", "ipc-unsplit"] if args.exchange == "auto" else (["ipc"] if args.exchange == "ipc" else [])
                 else:
-                    uid = [mgcfd.rccl_unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(uid, src=0)
+                    if uid[0] is None:
+                        raise RuntimeError("no RCCL unique id from rank 0")
                     solver.rank_attach_rccl(rank, world, uid[0])
                     part_candidates = ["ipc-fused", "ipc", "ipc-unsplit", "library"] if args.exchange == "auto" else [args.exchange]
                 solver.rank_set_halo(0, P)
             except Exception as e:
+                setup_error = e
+            # (a failure only one rank sees must not leave the others waiting in the next collective call)
+            t_ok = torch.tensor([0.0 if setup_error else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            if float(t_ok.item()) != 1.0:
                 if rank == 0:
-                    print(f"bench.py: the library's rank loop not used: {e}", file=sys.stderr)
-                part_notes.append(f"the library's rank loop not used: {e}")
+                    print(f"bench.py: the library's rank loop not used: {setup_error or 'it failed on another rank'}", file=sys.stderr)
+                part_notes.append(f"the library's rank loop not used: {setup_error or 'it failed on another rank'}")
                 part_candidates = []
             if args.exchange == "auto" and len(part_candidates) > 1:
                 part_pick()

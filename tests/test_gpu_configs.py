@@ -327,6 +327,8 @@ def test_bench_line_at_the_drivers_arguments():
     assert 0.3 < roof["frac"] < 0.8 and 10.0 < roof["empirical_ceiling_us"] < roof["avg_kernel_us"]
     assert roof["traffic"] is None or (roof["traffic"] >= roof["algorithmic_bytes_per_launch"] and "profiles/" in roof["traffic_source"])
     assert roof["fused_stage"]["launches"] == 60
+    # (FMA contraction allowed: the same launch, a little faster, reported beside the bit-identical figure)
+    assert 10.0 < roof["fma_contracted"]["avg_kernel_us"] < 1.05 * roof["avg_kernel_us"] and "1e-12" in roof["fma_contracted"]["numerics"]
     assert 0.0002 < d["vcycle"]["wall_s_per_cycle"] < 0.001
     cpu = d["cpu_baseline"]
     assert cpu["unit"] == "Medges/s" and cpu["cores"] == 1 and cpu["kind"] in ("reference", "port") and cpu["value"] > 1 and cpu["sample"] and cpu["cpu_model"]

@@ -578,14 +578,15 @@ def main():
         # driver's default of 5 warm-up steps is 0.3 ms.  The line says so in "preheat".
         solver.bench_flux(0, 2 * ROOFLINE_LAUNCHES)             # (untimed: the ramp itself)
         flux_only = solver.bench_flux(0, ROOFLINE_LAUNCHES)
-        probe = solver.bench_indirect_rw(0, ROOFLINE_LAUNCHES) if hasattr(solver, "bench_indirect_rw") else None
         flux_contracted = None
         if not args.fast:
             # the same launch with FMA contraction allowed (MGCFD_OPT_EXACT = 0: results within 1e-12 relative of the reference's,
             # tests/test_gpu_parity.py REL_FAST; north_star's bound is 1e-10) — reported beside the bit-identical figure, never as it
             solver.set_option("exact", 0)
+            solver.bench_flux(0, ROOFLINE_LAUNCHES)                 # (untimed: the first batch after the switch reads 1 % slower)
             flux_contracted = solver.bench_flux(0, ROOFLINE_LAUNCHES)
             solver.set_option("exact", 1)
+        probe = solver.bench_indirect_rw(0, ROOFLINE_LAUNCHES) if hasattr(solver, "bench_indirect_rw") else None
         solver.zero_fluxes(0)                                   # (the sweeps start from zero fluxes, as after any time_step)
     while True:
         for _ in range(args.warmup):
@@ -689,7 +690,7 @@ def main():
                     "launches": ROOFLINE_LAUNCHES, "avg_kernel_us": round(flux_only * 1e6, 3), "algorithmic_bytes_per_launch": bytes_flux,
                     "algorithmic_bytes": "40 B per internal edge + 80 B per node (SURVEY.md §8d)",
                     "medges_per_s": round(n_int / flux_only / 1e6, 1) if flux_only > 0 else None}
-            roof["preheat"] = (f"the {(3 if args.fast else 4) * ROOFLINE_LAUNCHES} flux + {ROOFLINE_LAUNCHES} probe launches above (2 x {ROOFLINE_LAUNCHES} of them untimed) ran BEFORE the warm-up and timed steps "
+            roof["preheat"] = (f"the {(3 if args.fast else 5) * ROOFLINE_LAUNCHES} flux + {ROOFLINE_LAUNCHES} probe launches above ({2 if args.fast else 3} x {ROOFLINE_LAUNCHES} of them untimed) ran BEFORE the warm-up and timed steps "
                                "(an idle MI355X needs ~30 ms of load before its clocks are up: tools/exp/first_steps.py)")
             if probe:
                 roof["empirical_ceiling_us"] = round(probe * 1e6, 3)

@@ -305,8 +305,12 @@ def main():
     import torch
     dist = None
     if world > 1:
+        import faulthandler
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # several ranks: a rank stuck in a collective or in an exchange that never completes says where and ends (a whole run
+        # takes two to three minutes; nothing multi-GPU has run on hardware yet)
+        faulthandler.dump_traceback_later(int(os.environ.get("MGCFD_BENCH_WATCHDOG_S", "900")), exit=True)
     if args.plumbing_only:
         return plumbing_only(args, dist, world, rank, workload, lattice)
     if not torch.cuda.is_available():
@@ -481,7 +485,14 @@ def main():
             """--exchange auto: every candidate that passes its start-up check runs a short burst of sweeps; the fastest one is
             used, the others stay behind it as fall-backs (in the order of their bursts)."""
             timed = []
+            held_back = []
             for mode in list(part_candidates):
+                if mode == "library" and timed:
+                    # (an IPC form is valid and, by the model of DESIGN.md §9.2, faster: the RCCL form — never run with more than
+                    #  one rank either — stays behind it as a fall-back and is not exercised unless it is needed)
+                    held_back.append(mode)
+                    part_notes.append("'library' kept as a fall-back, not timed: an IPC form passed its start-up check")
+                    continue
                 if part_try(mode):
                     part_reset()
                     for _ in range(3):
@@ -497,6 +508,7 @@ def main():
                     part_notes.append(f"start-up burst of '{mode}': {timed[-1][0] * 1e6:.0f} us per sweep")
             part_candidates.clear()
             part_candidates.extend(m for _, m in sorted(timed))
+            part_candidates.extend(held_back)
             part_next()
 
         if world == 1:
@@ -724,6 +736,7 @@ def main():
         sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
 
 
 def plumbing_only(args, dist, world, rank, workload, lattice):

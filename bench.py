@@ -590,13 +590,20 @@ def main():
         # driver's default of 5 warm-up steps is 0.3 ms.  The line says so in "preheat".
         solver.bench_flux(0, 2 * ROOFLINE_LAUNCHES)             # (untimed: the ramp itself)
         flux_only = solver.bench_flux(0, ROOFLINE_LAUNCHES)
-        flux_contracted = None
+        flux_contracted = flux_free = None
         if not args.fast:
             # the same launch with FMA contraction allowed (MGCFD_OPT_EXACT = 0: results within 1e-12 relative of the reference's,
             # tests/test_gpu_parity.py REL_FAST; north_star's bound is 1e-10) — reported beside the bit-identical figure, never as it
             solver.set_option("exact", 0)
             solver.bench_flux(0, ROOFLINE_LAUNCHES)                 # (untimed: the first batch after the switch reads 1 % slower)
             flux_contracted = solver.bench_flux(0, ROOFLINE_LAUNCHES)
+            # ... and with ORDER-FREE accumulation on top (k_flux_free, variant bit 6, the contracted namespace only: every edge of a
+            # tile evaluated once, the other end's share added to its LDS sum with ds_add_f64; tests/test_gpu_order_free.py)
+            if args.variant == -1 and solver.has_half_rows(0):
+                solver.set_option("flux_variant", 65)
+                solver.bench_flux(0, ROOFLINE_LAUNCHES)
+                flux_free = solver.bench_flux(0, ROOFLINE_LAUNCHES)
+                solver.set_option("flux_variant", args.variant)
             solver.set_option("exact", 1)
         probe = solver.bench_indirect_rw(0, ROOFLINE_LAUNCHES) if hasattr(solver, "bench_indirect_rw") else None
         solver.zero_fluxes(0)                                   # (the sweeps start from zero fluxes, as after any time_step)
@@ -702,7 +709,7 @@ def main():
                     "launches": ROOFLINE_LAUNCHES, "avg_kernel_us": round(flux_only * 1e6, 3), "algorithmic_bytes_per_launch": bytes_flux,
                     "algorithmic_bytes": "40 B per internal edge + 80 B per node (SURVEY.md §8d)",
                     "medges_per_s": round(n_int / flux_only / 1e6, 1) if flux_only > 0 else None}
-            roof["preheat"] = (f"the {(3 if args.fast else 5) * ROOFLINE_LAUNCHES} flux + {ROOFLINE_LAUNCHES} probe launches above ({2 if args.fast else 3} x {ROOFLINE_LAUNCHES} of them untimed) ran BEFORE the warm-up and timed steps "
+            roof["preheat"] = (f"the {(3 if args.fast else (7 if flux_free else 5)) * ROOFLINE_LAUNCHES} flux + {ROOFLINE_LAUNCHES} probe launches above ({2 if args.fast else (4 if flux_free else 3)} x {ROOFLINE_LAUNCHES} of them untimed) ran BEFORE the warm-up and timed steps "
                                "(an idle MI355X needs ~30 ms of load before its clocks are up: tools/exp/first_steps.py)")
             if probe:
                 roof["empirical_ceiling_us"] = round(probe * 1e6, 3)
@@ -713,6 +720,15 @@ def main():
                                           "frac": round(bytes_flux / flux_contracted / 1e9 / HBM_PEAK_GBS, 4),
                                           "numerics": "the same launch with FMA contraction allowed (MGCFD_OPT_EXACT = 0): within 1e-12 relative of the reference "
                                                       "(north_star allows 1e-10); the line's other figures are the bit-identical mode"}
+            if flux_free:
+                roof["order_free"] = {"avg_kernel_us": round(flux_free * 1e6, 3), "launches": ROOFLINE_LAUNCHES,
+                                      "frac": round(bytes_flux / flux_free / 1e9 / HBM_PEAK_GBS, 4),
+                                      "medges_per_s": round(n_int / flux_free / 1e6, 1),
+                                      "kernel": "k_flux_free (MGCFD_OPT_EXACT = 0, MGCFD_OPT_FLUX_VARIANT = 65): one 28-byte entry per edge and tile, -F added to the other "
+                                                "end's LDS sum with ds_add_f64, one barrier, 56-byte records, four workgroups per CU",
+                                      "numerics": "sums associated differently from the reference's and not reproducible bit for bit: <= 1e-12 relative per launch and "
+                                                  "sweep, <= 1e-10 on level-0 variables after 25 full-size V-cycles, the reference's -v rule passes "
+                                                  "(tests/test_gpu_order_free.py); opt-in, the line's other figures are the bit-identical mode"}
             if flux_avg > 0:
                 a2 = (bytes_flux + bytes_ts) / flux_avg / 1e9
                 roof["fused_stage"] = {"kernel": "one whole Runge-Kutta stage per launch = compute_flux_edge + boundary + far-field + time_step: what the timed sweeps run",

@@ -78,7 +78,14 @@ enum {
                                    bit 5 (32): half rows — every internal edge of a tile evaluated once, by one of its
                                    end points, the flux terms handed to the other through LDS (k_flux_half; levels that
                                    qualify, see mgcfd_level_has_half_rows; others run the node gather).
-                                   Every variant gives bit-identical results. */
+                                   Every variant above gives bit-identical results.
+                                   bit 6 (64), with MGCFD_OPT_EXACT = 0 only (the bit-identical kernels ignore it): ORDER-FREE
+                                   accumulation over the half-row plan (k_flux_free) — every internal edge of a tile evaluated
+                                   once, the other end's share added to its LDS sum with fp64 LDS atomics, no ordered hand-over.
+                                   Sums are associated differently from the reference's (src/Kernels/flux_loops.cpp:133-136 adds
+                                   in edge order) and are not reproducible bit for bit from run to run: <= 1e-12 relative per
+                                   launch, <= 1e-10 after 25 V-cycles, the reference's -v rule (validation.cpp:159-166) passes;
+                                   tests/test_gpu_order_free.py.  Levels without a half-row plan run the node gather. */
     MGCFD_OPT_FUSE_UPDATE = 5, /* 1 (default): mgcfd_smooth / mgcfd_run_cycles run each Runge-Kutta stage as ONE
                                   launch (fluxes + time_step, same operations); 0: one launch per loop */
     MGCFD_OPT_GRAPH = 6,       /* 1: replay each smoothing sweep / multigrid cycle from a captured hipGraph (one host

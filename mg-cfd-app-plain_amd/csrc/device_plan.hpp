@@ -133,6 +133,7 @@ struct DevicePlan {
     // edge-once tiles (preprocess.hpp: LevelPlan::te_*); edge_once == 0: not available on this level
     int vin_ok = 0;                     // no tile has overflow nodes or more than 256 halo nodes: role-5 launches allowed
     int lds_complete = 0;               // every halo node of every tile is staged in LDS (no overflow table entries)
+    int32_t halo_max = 0;               // the largest halo of a tile (k_flux_free: how many workgroups may share a CU)
     int edge_once = 0;
     int32_t *te_chunk_ptr = nullptr, *te_count = nullptr;
     uint16_t *te_slots = nullptr, *gat16 = nullptr;

@@ -39,8 +39,9 @@ namespace MGCFD_KERNEL_NS {
 // between phase boundaries of k_flux_half to its own slot.  The shipped build defines the marks away.
 #ifdef MGCFD_PHASES
 __device__ unsigned long long g_phase[4096 * 8];
-#define PH_MARK(k) do { if (threadIdx.x == 0) { unsigned long long now_ = wall_clock64(); g_phase[(blockIdx.x & 4095) * 8 + (k)] += now_ - ph_last_; ph_last_ = now_; } } while (0)
-#define PH_BEGIN() unsigned long long ph_last_ = wall_clock64(); if (threadIdx.x == 0) g_phase[(blockIdx.x & 4095) * 8 + 7] += 1ull
+__device__ unsigned long long g_phase_abs[4096 * 2];     // the LAST launch: when every workgroup began and passed its last mark (100 MHz ticks)
+#define PH_MARK(k) do { if (threadIdx.x == 0) { unsigned long long now_ = wall_clock64(); g_phase[(blockIdx.x & 4095) * 8 + (k)] += now_ - ph_last_; ph_last_ = now_; g_phase_abs[(blockIdx.x & 4095) * 2 + 1] = now_; } } while (0)
+#define PH_BEGIN() unsigned long long ph_last_ = wall_clock64(); if (threadIdx.x == 0) { g_phase[(blockIdx.x & 4095) * 8 + 7] += 1ull; g_phase_abs[(blockIdx.x & 4095) * 2] = ph_last_; }
 #else
 #define PH_MARK(k) do { } while (0)
 #define PH_BEGIN() do { } while (0)
@@ -1321,6 +1322,277 @@ k_flux_half(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
     PH_MARK(5);
 }
 
+#ifdef MGCFD_ORDER_FREE
+// ------------------------------------------------------------------------------------------
+// flux_free (the `fast` namespace only: MGCFD_OPT_EXACT = 0, MGCFD_OPT_FLUX_VARIANT bit 6): compute_flux_edge +
+// boundary + far-field faces with ORDER-FREE accumulation.
+//
+// Every byte-saving layout of the bit-identical kernels (edge-once tiles, indexed weights, half rows) lost what it
+// saved to the hand-over that keeps the reference's summation ORDER: a second pass over LDS and two more barriers.
+// north_star's bound is 1e-10, not bits, so this kernel drops the order and nothing else: a tile streams ONE 28-byte
+// entry per internal edge that touches it (the half-row plan, preprocess.hpp: the evaluator of an edge inside the tile
+// is one of its end points, a cut edge is evaluated by the tile of each end), the evaluating lane adds +F to its own
+// node's sum in registers and — for an edge inside the tile — adds -F to the other end's sum in LDS with ds_add_f64
+// (the reference's expressions for the other end evaluate to exactly -F, flux_kernel.elemfunc.c:142-189).  One barrier,
+// every node adds its LDS sum to its register sum, the boundary faces follow, store.  No second pass, no ordered adds;
+// the result differs from the reference's by the rounding of a differently associated sum (<= 1e-12 relative per
+// launch, tests/test_gpu_order_free.py) and is not reproducible bit for bit from run to run (LDS atomics commute, their
+// rounding does not).
+//
+// Records are 64 bytes (rho, m, E, p, |v| + c, 1/rho): with contraction allowed |v| + c may be kept as one number, and
+// the velocity is three multiplications away from 1/rho — one division and two square roots per staged node instead of
+// three and two, four 16-byte LDS reads per neighbour instead of six.  Quad q of slot s sits at position q ^ ((s >> 2) & 3)
+// of its record, so a 16-lane ds_read_b128 group reaches all 16 quad positions of the 256-byte bank row.
+// ------------------------------------------------------------------------------------------
+struct NodeF { double rho, mx, my, mz, en, p, sc, inv; };
+constexpr int kFreeRecD2 = 3;                  // double2 per record (+ one double in the array beside)
+
+// 1/x and sqrt(x) from the hardware's estimates and Newton steps in FMAs (~1e-16 relative; the IEEE sequences hipcc emits
+// under -fno-fast-math cost 15 and 20 instructions, and fp64 instructions issue at a quarter of the fp32 rate: the kernel's
+// phases are bound by them, profiles/r3_free_phases.txt)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;                  // g -> sqrt(x), h -> 0.5 / sqrt(x) (Goldschmidt)
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    // (x = 0: the estimate is infinite; negative or NaN: NaN, as sqrt gives)
+    return x > 0.0 ? g : (x == 0.0 ? 0.0 : __builtin_nan(""));
+}
+
+__device__ __forceinline__ NodeF make_nodef(double rho, double mx, double my, double mz, double en)
+{
+    NodeF n;
+    n.rho = rho; n.mx = mx; n.my = my; n.mz = mz; n.en = en;
+    n.inv = fast_rcp(rho);
+    const double vx = mx * n.inv, vy = my * n.inv, vz = mz * n.inv;
+    const double speed_sqd = vx * vx + vy * vy + vz * vz;
+    n.p = (kGamma - 1.0) * (en - 0.5 * rho * speed_sqd);
+    n.sc = fast_sqrt(speed_sqd) + fast_sqrt(kGamma * n.p * n.inv);
+    return n;
+}
+
+// LDS image of a staged node: 48 bytes (rho, m, E, p) in an array of records + |v| + c in an array of its own; 1/rho is five
+// instructions away from rho.  56 bytes per node instead of 64: with the tile's 10 KB of sums, 546 nodes fit the 40 KB a
+// workgroup may take when FOUR share a CU.  A 12-dword record stride spreads a 16-lane ds_read_b128 group over all 16 quad
+// positions of the 256-byte bank row by itself.
+__device__ __forceinline__ void lds_store_nodef(double2 *rec, double *scs, uint32_t slot, const NodeF &n)
+{
+    double2 *r = rec + slot * kFreeRecD2;
+    r[0] = make_double2(n.rho, n.mx);
+    r[1] = make_double2(n.my, n.mz);
+    r[2] = make_double2(n.en, n.p);
+    scs[slot] = n.sc;
+}
+
+__device__ __forceinline__ NodeF lds_load_nodef(const double2 *rec, const double *scs, uint32_t slot)
+{
+    const double2 *r = rec + slot * kFreeRecD2;
+    const double2 a = r[0], c = r[1], d = r[2];
+    NodeF n;
+    n.rho = a.x; n.mx = a.y; n.my = c.x; n.mz = c.y; n.en = d.x; n.p = d.y; n.sc = scs[slot];
+    n.inv = fast_rcp(n.rho);
+    return n;
+}
+
+// what the evaluating end keeps beside its record: velocity and total enthalpy per volume
+struct OwnF { double vx, vy, vz, H; };
+__device__ __forceinline__ OwnF make_ownf(const NodeF &n)
+{
+    OwnF o;
+    o.vx = n.mx * n.inv; o.vy = n.my * n.inv; o.vz = n.mz * n.inv; o.H = n.en + n.p;
+    return o;
+}
+
+// flux_kernel.elemfunc.c:130-161 seen from end `a` (the plan folded the b-side sign into the weights f), regrouped: with
+// d_x = f . m_x the contracted flux contributions are f . Phi_x = v_x d_x + p_x f for the momenta and H_x (f . v_x) for the
+// energy (cfd_loops.h:57-83), so nothing of the 3 x 3 tensors is formed: 53 fp64 instructions per edge instead of 81.
+__device__ __forceinline__ Flux5 edge_flux_f(const NodeF &a, const OwnF &oa, const NodeF &b, double fx, double fy, double fz)
+{
+    const double half_ewt = fast_sqrt(fx * fx + fy * fy + fz * fz);           // :27, the plan stores f = -+0.5 e
+    const double factor = -(half_ewt * double(0.2f)) * (a.sc + b.sc);         // :130-131
+    const double da = fx * a.mx + fy * a.my + fz * a.mz;
+    const double db = fx * b.mx + fy * b.my + fz * b.mz;
+    const double bvx = b.mx * b.inv, bvy = b.my * b.inv, bvz = b.mz * b.inv;
+    const double ps = a.p + b.p;
+    Flux5 f;
+    f.d = factor * (a.rho - b.rho) + (da + db);
+    f.mx = factor * (a.mx - b.mx) + oa.vx * da + bvx * db + ps * fx;
+    f.my = factor * (a.my - b.my) + oa.vy * da + bvy * db + ps * fy;
+    f.mz = factor * (a.mz - b.mz) + oa.vz * da + bvz * db + ps * fz;
+    f.en = factor * (a.en - b.en) + oa.H * (da * a.inv) + (b.en + b.p) * (db * b.inv);
+    return f;
+}
+
+__device__ __forceinline__ FluxC flux_contribution_f(const NodeF &q, const OwnF &o)
+{
+    FluxC f;
+    f.xx = o.vx * q.mx + q.p;
+    f.xy = o.vx * q.my;
+    f.xz = o.vx * q.mz;
+    f.yy = o.vy * q.my + q.p;
+    f.yz = o.vy * q.mz;
+    f.zz = o.vz * q.mz + q.p;
+    f.ex = o.vx * o.H;
+    f.ey = o.vy * o.H;
+    f.ez = o.vz * o.H;
+    return f;
+}
+
+__device__ __forceinline__ void lds_add(double *p, double v) { unsafeAtomicAdd(p, v); }    // ds_add_f64
+
+// CAP: nodes a tile may stage.  kFreeCap4 (halos of at most 290 nodes) lets four workgroups share a CU, kTileCap three.
+constexpr int kFreeCap4 = 546;
+template <bool FUSE, bool ACC, int CAP>
+__global__ void __launch_bounds__(kBlock, CAP <= kFreeCap4 ? 4 : 3)
+k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue's first loads need)
+            const double *__restrict__ q, const int32_t *__restrict__ tile_halo, uint32_t n_tiles, int32_t hr_pad_row,
+            int64_t stride, int64_t nel, const int32_t *__restrict__ hr_row0, const uint32_t *__restrict__ hr_code,
+            const double *__restrict__ hr_w, const int32_t *__restrict__ slice_row0,
+            const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
+            const uint16_t *__restrict__ nbr16, const double *__restrict__ w, FarField ff, double *__restrict__ fluxes,
+            int classes, FusedStep fs)
+{
+    __shared__ double2 tile[CAP * kFreeRecD2];
+    __shared__ double scs[CAP];
+    __shared__ double acc[5 * kTile];               // the sums neighbours leave for this tile's own nodes, [field][node]
+
+    PH_BEGIN();
+    double min_dt = 0.0;
+    if (FUSE && fs.partial_min) min_dt = block_min_of_partials(fs.partial_min, fs.n_partial);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const unsigned t = xcd_contiguous_block(blockIdx.x, n_tiles);
+    const int64_t i = int64_t(t) * kTile + tid;
+    const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
+
+    // load issue order as in k_flux_tile: halo ids, own state, the first two half rows, then the halo state by id;
+    // nothing under a branch
+    const int32_t *hrow = tile_halo + int64_t(t) * kHaloStride;
+    const int32_t hid = hrow[tid];
+    const int32_t hid2 = tid < kHaloStride - kBlock ? hrow[kBlock + tid] : -1;
+    const int32_t h0 = hr_row0[slice];
+    const int32_t n_h = (classes & 1) ? hr_row0[slice + 1] - h0 : 0;
+    const int32_t n_bnd = rows_bnd[slice];
+    const double o0 = q[i], o1 = q[stride + i], o2 = q[2 * stride + i], o3 = q[3 * stride + i], o4 = q[4 * stride + i];
+    // EVERY half row of the lane is requested here (the plan gives a lane at most kHalfMaxRows): the row loop then waits for
+    // nothing, and a workgroup has all of its tile's bytes in flight at once — what hides the memory latency is the other
+    // workgroups of the CU, not a prefetch distance
+    EdgeRow er[kHalfMaxRows];
+#pragma unroll
+    for (int j = 0; j < kHalfMaxRows; j++) er[j] = load_half_row(hr_code, hr_w, j < n_h ? h0 + j : hr_pad_row, lane);
+    const int64_t hnode = hid >= 0 ? int64_t(hid) : i;
+    const double g0 = q[hnode], g1 = q[stride + hnode], g2 = q[2 * stride + hnode], g3 = q[3 * stride + hnode], g4 = q[4 * stride + hnode];
+
+#pragma unroll
+    for (int f = 0; f < 5; f++) acc[f * kTile + tid] = 0.0;
+    const NodeF me = make_nodef(o0, o1, o2, o3, o4);
+    lds_store_nodef(tile, scs, uint32_t(tid), me);
+    lds_store_nodef(tile, scs, uint32_t(kTile + tid), make_nodef(g0, g1, g2, g3, g4));          // unconditional, see k_flux_tile
+    if (hid2 >= 0) {
+        const int64_t h = hid2;
+        lds_store_nodef(tile, scs, uint32_t(kTile + kBlock + tid), make_nodef(q[h], q[stride + h], q[2 * stride + h], q[3 * stride + h], q[4 * stride + h]));
+    }
+    const OwnF mo = make_ownf(me);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+    if (ACC) {
+        a0 = fluxes[i]; a1 = fluxes[stride + i]; a2 = fluxes[2 * stride + i];
+        a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
+    }
+    PH_MARK(0);
+    __syncthreads();
+    PH_MARK(1);
+
+    // ---- this lane's half rows, two at a time (independent arithmetic; a half row the slice does not have was read from the
+    //      padding row: zero weights, nothing added) ----
+    auto eval = [&](const EdgeRow &e0, bool may_be_foreign) {
+        const uint32_t s = e0.code & kT16SlotMask;
+        const bool v = s != kT16Pad;
+        const NodeF ot = lds_load_nodef(tile, scs, v ? s : uint32_t(tid));
+        Flux5 F;
+        bool mine = true;
+        if (may_be_foreign) {
+            // an evaluation another node owns (the plan found no room in that node's lane): its record comes from LDS too,
+            // and its share goes to its LDS sum
+            const bool foreign = (e0.code & kHalfForeign) != 0;
+            const uint32_t own = (e0.code >> 16) & 0xFFu;
+            const NodeF m0 = foreign ? lds_load_nodef(tile, scs, own) : me;
+            F = edge_flux_f(m0, make_ownf(m0), ot, e0.fx, e0.fy, e0.fz);
+            if (foreign && v) {
+                lds_add(&acc[own], F.d); lds_add(&acc[kTile + own], F.mx); lds_add(&acc[2 * kTile + own], F.my);
+                lds_add(&acc[3 * kTile + own], F.mz); lds_add(&acc[4 * kTile + own], F.en);
+            }
+            mine = !foreign;
+        } else {
+            F = edge_flux_f(me, mo, ot, e0.fx, e0.fy, e0.fz);
+        }
+        // (padding carries zero weights: F = 0)
+        if (mine) { a0 += F.d; a1 += F.mx; a2 += F.my; a3 += F.mz; a4 += F.en; }
+        if (v && (e0.code & kHalfMirror)) {
+            // the other end lies in this tile and does not evaluate the edge itself: it gets -F
+            lds_add(&acc[s], -F.d); lds_add(&acc[kTile + s], -F.mx); lds_add(&acc[2 * kTile + s], -F.my);
+            lds_add(&acc[3 * kTile + s], -F.mz); lds_add(&acc[4 * kTile + s], -F.en);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < kHalfMaxRows; j += 2) {
+        if (j >= n_h) break;                        // (uniform over the wave)
+        const bool two = j + 1 < kHalfMaxRows;      // (compile time)
+        const bool any_foreign = ((er[j].code | (two ? er[j + 1 < kHalfMaxRows ? j + 1 : j].code : 0u)) & kHalfForeign) != 0;
+        if (__builtin_expect(__any(any_foreign), 0)) {
+            eval(er[j], true);
+            if (two) eval(er[j + 1 < kHalfMaxRows ? j + 1 : j], true);
+        } else {
+            eval(er[j], false);
+            if (two) eval(er[j + 1 < kHalfMaxRows ? j + 1 : j], false);
+        }
+    }
+    PH_MARK(2);
+    __syncthreads();
+    PH_MARK(3);
+    a0 += acc[tid]; a1 += acc[kTile + tid]; a2 += acc[2 * kTile + tid]; a3 += acc[3 * kTile + tid]; a4 += acc[4 * kTile + tid];
+
+    if ((classes & 6) && n_bnd > 0) {
+        const int32_t row0 = slice_row0[slice];
+        const int64_t first_bnd = int64_t(row0) + rows_int[slice];
+        const FluxC fm = flux_contribution_f(me, mo);
+        for (int32_t r = 0; r < n_bnd; r++) {
+            const EdgeRow e = load_row<false>(nbr16, w, first_bnd + r, lane);
+            const double fx = e.fx, fy = e.fy, fz = e.fz;
+            if (e.code == kT16Wall && (classes & 2)) {
+                // flux_boundary_kernel.elemfunc.c:37-64: pressure force only
+                a1 += fx * me.p;
+                a2 += fy * me.p;
+                a3 += fz * me.p;
+            } else if (e.code == kT16Far && (classes & 4)) {
+                // flux_wall_kernel.elemfunc.c:51-88: average with the far-field state
+                a0 += fx * (ff.var[1] + me.mx) + fy * (ff.var[2] + me.my) + fz * (ff.var[3] + me.mz);
+                a4 += fx * (ff.fc_de[0] + fm.ex) + fy * (ff.fc_de[1] + fm.ey) + fz * (ff.fc_de[2] + fm.ez);
+                a1 += fx * (ff.fc_mx[0] + fm.xx) + fy * (ff.fc_mx[1] + fm.xy) + fz * (ff.fc_mx[2] + fm.xz);
+                a2 += fx * (ff.fc_my[0] + fm.xy) + fy * (ff.fc_my[1] + fm.yy) + fz * (ff.fc_my[2] + fm.yz);
+                a3 += fx * (ff.fc_mz[0] + fm.xz) + fy * (ff.fc_mz[1] + fm.yz) + fz * (ff.fc_mz[2] + fm.zz);
+            }
+        }
+    }
+    finish_node<FUSE>(i, nel, stride, a0, a1, a2, a3, a4, fluxes, fs, min_dt, t);
+    PH_MARK(4);
+}
+#endif // MGCFD_ORDER_FREE
+
 // ------------------------------------------------------------------------------------------
 // Two-phase ("fission") design point, MGCFD_OPT_FLUX_VARIANT bit 2 — the GPU form of the
 // reference's FLUX_FISSION build (flux_kernel.elemfunc.c:193-204 + update_edges,
@@ -2126,6 +2398,25 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
                                p.rows_int, p.rows_bnd, p.row_edge, p.nbr16, p.w, p.edge_flux, ff, fluxes, classes);
         return;
     }
+#ifdef MGCFD_ORDER_FREE
+    // variant bit 6 (64), this namespace only: order-free accumulation over the half-row plan (k_flux_free)
+    if ((variant & 64) && p.half && (classes & 1) && !(fused && fs.vin_flux) && !part) {
+#define MGCFD_FREE_LAUNCH_C(FUSE, ACC, CAP)                                                                     \
+    hipLaunchKernelGGL((k_flux_free<FUSE, ACC, CAP>), grid, block, 0, st, q, p.tile_halo, uint32_t(p.n_tiles),  \
+                       p.hr_pad_row, p.stride, p.nel, p.hr_row0, p.hr_code, p.hr_w, p.slice_row0,               \
+                       p.rows_int, p.rows_bnd, p.nbr16, p.w, ff, fluxes, classes, fs)
+        // (four workgroups per CU where every tile's halo fits the smaller LDS image, three otherwise; MGCFD_FREE_WG3=1: always three, for A/B)
+        static const bool wg3 = std::getenv("MGCFD_FREE_WG3") && std::atoi(std::getenv("MGCFD_FREE_WG3")) != 0;
+#define MGCFD_FREE_LAUNCH(FUSE, ACC)                                                                            \
+    do { if (p.halo_max <= kFreeCap4 - kTile && !wg3) MGCFD_FREE_LAUNCH_C(FUSE, ACC, kFreeCap4); else MGCFD_FREE_LAUNCH_C(FUSE, ACC, kTileCap); } while (0)
+        if (fused) MGCFD_FREE_LAUNCH(true, false);
+        else if (accumulate) MGCFD_FREE_LAUNCH(false, true);
+        else MGCFD_FREE_LAUNCH(false, false);
+#undef MGCFD_FREE_LAUNCH_C
+#undef MGCFD_FREE_LAUNCH
+        return;
+    }
+#endif
     // variant bit 5 (32): half rows — every edge evaluated once per tile by one of its end points (k_flux_half); the
     // split sweep's absorbed first stage (role 5) stays with the node gather
     if ((variant & 32) && p.half && (classes & 1) && !(fused && fs.vin_flux) && !part) {
@@ -2276,5 +2567,10 @@ extern "C" void mgcfd_debug_phases(unsigned long long *out, int reset)
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mgcfd::MGCFD_KERNEL_NS::g_phase), sizeof(unsigned long long) * 4096 * 8);
     if (reset) { static unsigned long long z[4096 * 8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(mgcfd::MGCFD_KERNEL_NS::g_phase), z, sizeof(z)); }
+}
+extern "C" void mgcfd_debug_phase_abs(unsigned long long *out)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mgcfd::MGCFD_KERNEL_NS::g_phase_abs), sizeof(unsigned long long) * 4096 * 2);
 }
 #endif

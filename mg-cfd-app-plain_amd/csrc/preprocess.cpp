@@ -650,7 +650,9 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                         const int32_t sl = host / kSlice, lane = host % kSlice, j = used[host]++;
                         const size_t hrow = static_cast<size_t>(P.hr_row0[static_cast<size_t>(s0 + sl)]) + static_cast<size_t>(j);
                         const int64_t e = en[1];
-                        P.hr_code[hrow * kSlice + lane] = uint32_t(P.nbr16[static_cast<size_t>(e)]) | (uint32_t(owner) << 16) | (host != owner ? kHalfForeign : 0u);
+                        const bool only = half_eval_a[static_cast<size_t>(en[0])] >= 0;     // (an edge inside the tile: nobody else evaluates it)
+                        P.hr_code[hrow * kSlice + lane] = uint32_t(P.nbr16[static_cast<size_t>(e)]) | (uint32_t(owner) << 16) | (host != owner ? kHalfForeign : 0u)
+                                                          | (only ? kHalfMirror : 0u);
                         const EdgeW &W = P.w[static_cast<size_t>(e)];
                         P.hr_w[(hrow * 3 + 0) * kSlice + lane] = W.x;
                         P.hr_w[(hrow * 3 + 1) * kSlice + lane] = W.y;

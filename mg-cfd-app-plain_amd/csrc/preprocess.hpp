@@ -36,6 +36,8 @@ constexpr int kProCap = 768;
 constexpr int kEdgeChunk = 256;
 constexpr int kMaxEdgeChunks = 5;
 constexpr uint32_t kHalfForeign = 1u << 24;
+constexpr uint32_t kHalfMirror = 1u << 25;    // the edge lies inside the tile and this is its only evaluation: the other end takes the
+                                              // negated terms (k_flux_free adds them to that node's LDS sum; k_flux_half hands them over by position)
 constexpr uint32_t kHalfPad = 0x00007FFFu;   // (low 15 bits = kT16Pad)
 constexpr int kHalfMaxRows = 5;            // half rows (edges a node evaluates) a thread keeps the results of in registers
 constexpr int kHalfTileRows = 21;          // half rows of a tile's four slices together (21 * 64 * 40 B = the whole LDS tile)
@@ -107,7 +109,8 @@ struct LevelPlan {
     std::vector<int32_t> hr_row0;         // [n_slices+1] first half row of each slice
     std::vector<uint32_t> hr_code;        // [half rows*64] low 16 bits as nbr16 (the other end's LDS slot | kT16RoleB when the OWNING end
                                           //   is the edge's b end), bits 16-23 the owning node's thread, kHalfForeign when the slot
-                                          //   sits in another node's lane (that lane reads the owner's record from LDS too); kHalfPad
+                                          //   sits in another node's lane (that lane reads the owner's record from LDS too), kHalfMirror when
+                                          //   the other end lies in the tile and leaves the evaluation to this entry; kHalfPad
     std::vector<double> hr_w;             // [half rows][3][64] the evaluator's weights (as w.x, w.y, w.z of its own entry)
     std::vector<uint16_t> hg16;           // [rows*64] internal rows: where the entry's flux terms are | kT16RoleB = subtract; kT16Pad
     int64_t hr_entries = 0, hr_padding = 0, hr_foreign = 0;

@@ -717,6 +717,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         }
         lv.dp.vin_ok = (P.halo_overflow_refs == 0 && P.halo_max <= kTile) ? 1 : 0;
         lv.dp.lds_complete = P.halo_overflow_refs == 0 ? 1 : 0;
+        lv.dp.halo_max = P.halo_max;
         lv.dp.edge_once = (P.edge_once && !std::getenv("MGCFD_NO_EDGE_ONCE")) ? 1 : 0;
         if (lv.dp.edge_once) {
             lv.dp.te_chunk_ptr = dev_upload(P.te_chunk_ptr);

@@ -20,7 +20,7 @@ for ns, contract in (("exact", "off"), ("fast", "fast")):
     o = os.path.join(OUT, f"k_{name}_{ns}.o")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wno-unused-result",
                            "-mllvm", "-amdgpu-kernarg-preload-count=16",      # (as the Makefile's DEVFLAGS: without it every launch reads 0.5 us slower)
-                           f"-ffp-contract={contract}", f"-DMGCFD_KERNEL_NS={ns}", f"-I{ROOT}/include", f"-I{CSRC}", "-c", f, "-o", o])
+                           f"-ffp-contract={contract}", f"-DMGCFD_KERNEL_NS={ns}"] + (["-DMGCFD_ORDER_FREE=1"] if ns == "fast" else []) + [ f"-I{ROOT}/include", f"-I{CSRC}", "-c", f, "-o", o])
     objs.append(o)
 host = [os.path.join(CSRC, "build", x) for x in ("solver.o", "mesh.o", "preprocess.o")]
 lib = os.path.join(OUT, f"libmgcfd_hip_{name}.so")

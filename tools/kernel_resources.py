@@ -5,8 +5,10 @@ import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc")
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
+NS = os.environ.get("NS", "exact")             # NS=fast: the contracted namespace (with its order-free kernels)
+NSFLAGS = ["-ffp-contract=fast", "-DMGCFD_KERNEL_NS=fast", "-DMGCFD_ORDER_FREE=1"] if NS == "fast" else ["-ffp-contract=off", "-DMGCFD_KERNEL_NS=exact"]
 r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wno-unused-result",
-                    "-mllvm", "-amdgpu-kernarg-preload-count=16", "-ffp-contract=off", "-DMGCFD_KERNEL_NS=exact", f"-I{ROOT}/include", f"-I{CS}",
+                    "-mllvm", "-amdgpu-kernarg-preload-count=16"] + NSFLAGS + [f"-I{ROOT}/include", f"-I{CS}",
                     "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CS, "kernels.hip"), "-o", "/tmp/kernel_resources.o"],
                    capture_output=True, text=True)
 blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)

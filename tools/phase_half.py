@@ -11,10 +11,12 @@ LIB = os.environ.get("PH_LIB") or os.path.join(OUT, "libmgcfd_hip_phases.so")
 def build():
     os.makedirs(OUT, exist_ok=True)
     objs = []
-    for ns, contract, extra in (("exact", "off", ["-DMGCFD_PHASE_EXPORT"]), ("fast", "fast", [])):
+    # (the export reads the marks of the namespace it is compiled in: PH_NS=fast for the order-free kernel)
+    ex_ns = os.environ.get("PH_NS", "exact")
+    for ns, contract, extra in (("exact", "off", ["-DMGCFD_PHASE_EXPORT"] if ex_ns == "exact" else []), ("fast", "fast", ["-DMGCFD_PHASE_EXPORT"] if ex_ns == "fast" else [])):
         o = os.path.join(OUT, f"k_phases_{ns}.o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wno-unused-result",
-                               "-mllvm", "-amdgpu-kernarg-preload-count=16", f"-ffp-contract={contract}", f"-DMGCFD_KERNEL_NS={ns}", "-DMGCFD_PHASES", *os.environ.get("PH_DEFS", "").split(),
+                               "-mllvm", "-amdgpu-kernarg-preload-count=16", f"-ffp-contract={contract}", f"-DMGCFD_KERNEL_NS={ns}", "-DMGCFD_PHASES", *(["-DMGCFD_ORDER_FREE=1"] if ns == "fast" else []), *os.environ.get("PH_DEFS", "").split(),
                                f"-I{ROOT}/include", f"-I{CSRC}", "-c", os.path.join(CSRC, "kernels.hip"), "-o", o] + extra)
         objs.append(o)
     host = [os.path.join(CSRC, "build", x) for x in ("solver.o", "mesh.o", "preprocess.o")]
@@ -32,6 +34,7 @@ def run():
     s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
     s.set(0, "variables", bench.perturbed_state(s.nel(0), s.far_field()[:5]))
     s.set_option("flux_variant", variant)
+    if variant & 64: s.set_option("exact", 0)          # the order-free kernel lives in the contracted namespace
     lib = C.CDLL(LIB)
     buf = (C.c_ulonglong * (4096 * 8))()
     if os.environ.get("PH_PROBE"):        # time the indirect_rw probe instead (ablation builds)
@@ -44,11 +47,29 @@ def run():
     a = np.ctypeslib.as_array(buf).reshape(4096, 8).astype(np.float64)
     n = a[:, 7].sum()
     tot = a.sum(0)
-    names = ["stage + barrier", "half rows", "barrier (records dead)", "hand-over + barrier", "ordered adds", "boundary + store"]
+    if variant & 64:
+        names = ["loads + derive + stage (thread 0)", "staging barrier", "half rows + LDS adds", "barrier", "own sums + boundary + store", "-"]
+    else:
+        names = ["stage + barrier", "half rows", "barrier (records dead)", "hand-over + barrier", "ordered adds", "boundary + store"]
     print(f"variant {variant} lattice {lattice}: kernel avg {t*1e6:.2f} us, {n:.0f} workgroups timed")
     for k, nm in enumerate(names):
         print(f"  {nm:24s} {tot[k] / n / 100.0:7.3f} us per workgroup")
     print(f"  {'total':24s} {sum(tot[:6]) / n / 100.0:7.3f} us per workgroup")
+    for lo, hi, nm in ((0, 768, "workgroups 0-767 (first on their CU slot)"), (768, 4096, "workgroups 768- (behind another)")):
+        nn = a[lo:hi, 7].sum()
+        if nn > 0: print(f"  {nm}: " + " | ".join(f"{a[lo:hi, k].sum() / nn / 100.0:.2f}" for k in range(6)))
+    if hasattr(lib, "mgcfd_debug_phase_abs"):
+        ab = (C.c_ulonglong * (4096 * 2))()
+        lib.mgcfd_debug_phase_abs(ab)
+        nb = min(4096, s.nel(0) // 256 + (1 if s.nel(0) % 256 else 0))
+        b = np.ctypeslib.as_array(ab).reshape(4096, 2)[:nb].astype(np.int64)
+        t0 = b[:, 0].min()
+        st, en = (b[:, 0] - t0) / 100.0, (b[:, 1] - t0) / 100.0
+        print(f"  last launch: workgroups begin 0 .. {st.max():.2f} us, end {en.min():.2f} .. {en.max():.2f} us; lifetime mean {np.mean(en - st):.2f} max {np.max(en - st):.2f}")
+        hist, edges = np.histogram(st, bins=12)
+        print("  begin-time histogram:", " ".join(f"{e:.1f}:{h}" for h, e in zip(hist, edges[:-1])))
+        hist, edges = np.histogram(en, bins=12)
+        print("  end-time histogram:  ", " ".join(f"{e:.1f}:{h}" for h, e in zip(hist, edges[:-1])))
 
 if __name__ == "__main__":
     (build if sys.argv[1] == "build" else run)()

@@ -175,6 +175,13 @@ int mgcfd_create_partitioned(const mgcfd_level_desc *levels, int nlevels, int me
  * (mgcfd/partition.py: partition_hierarchy, mgcfd/distributed.py: PartitionedCycle). */
 int mgcfd_create_partitioned_mg(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device,
                                 const int64_t *n_owned, const int64_t *const *order_keys, mgcfd_solver **out);
+/* Host only (no device): builds the gather plans the three calls above would build and checks every index the kernels
+ * form from them — LDS slots, halo / overflow positions, half-row owners, list entries, children, staged coarse nodes —
+ * against the size of what it indexes.  MGCFD_OK, or MGCFD_ERR_ARG with the violations in `report` (may be NULL).
+ * n_owned / order_keys as in mgcfd_create_partitioned_mg (NULL: every node owned).  The reference has no counterpart:
+ * its loops index the caller's arrays directly (src/Kernels/flux_loops.cpp:133-136). */
+int mgcfd_plan_audit(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, const int64_t *n_owned,
+                     const int64_t *const *order_keys, char *report, int64_t report_cap);
 void mgcfd_destroy(mgcfd_solver *s);
 int mgcfd_set_option(mgcfd_solver *s, int option, int value);
 /* *yes = 1 when level `level` can run the edge-once flux variant (MGCFD_OPT_FLUX_VARIANT bit 1). */
@@ -396,6 +403,9 @@ int mgcfd_rank_residual_sumsq(mgcfd_solver *s, int level, double *sum_all_ranks)
  *   blobs handed round by the launcher, mgcfd_rank_ipc_attach (the other ranks' blobs in any order: at least the neighbours',
  *   at most 16 ranks); from then on mgcfd_rank_exchange / mgcfd_rank_sweeps run the direct form.
  *   mgcfd_rank_ipc_status: waits for a neighbour that gave up (about 2 s each) since the last call; 0 = all messages arrived.
+ *   A wait that gave up is an ERROR, not a statistic: the stages behind it ran on stale ghosts.  While the count is not zero
+ *   mgcfd_synchronize and mgcfd_get_array return MGCFD_ERR_HIP, and so does the next mgcfd_rank_sweeps after one of them has
+ *   seen it; mgcfd_rank_ipc_status reads the count and thereby acknowledges it (mgcfd_rank_ipc_detach clears it too).
  *   The ranks keep each other in step through the flags only WITHIN this form: before the first mgcfd_rank_exchange — and
  *   whenever a rank has touched the level by other means (mgcfd_set_array, another kind of sweep) — the caller synchronises
  *   the ranks (a barrier), or a neighbour's stores may land in a buffer that is still in use. */

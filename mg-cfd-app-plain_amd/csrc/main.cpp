@@ -268,6 +268,62 @@ int fail(const char *what)
     return EXIT_FAILURE;
 }
 
+// What the reference does between its cycle loop and its CSV files (src/euler3d_cpu_double.cpp:704-772), for one GPU or
+// several: -v / validate_result = Y (NaN check of every level, then level 0 against the solution file with
+// identify_differences' tolerance) and the level-0 dumps.  get(which, ncols, out) reads a level-0 array of the WHOLE mesh in
+// original numbering; nan_check(level, &cell) is check_for_invalid_variables on that level.  Returns 0 or EXIT_FAILURE.
+template <typename Get, typename NanCheck>
+int validate_and_dump(const Config &conf, int levels, int mesh_variant, int64_t nel0, Get &&get, NanCheck &&nan_check)
+{
+    std::printf("\n");
+    if (conf.validate_result) {
+        std::printf("Beginning validation of variables[]\n");
+        for (int l = 0; l < levels; l++) {
+            int64_t bad = -1;
+            if (nan_check(l, &bad) != MGCFD_OK) {
+                std::printf("\nERROR: NaN detected!\nCell %ld\n", (long)bad);
+                return EXIT_FAILURE;
+            }
+        }
+        std::printf("  NaN check passed\n");
+        bool passed = true;
+        const std::string sol = solution_filepath(conf, "variables", 0);
+        std::ifstream file(sol);
+        if (!file.is_open()) {
+            std::printf("  could not open variables solution file:\n    %s\n  aborting validation\n", sol.c_str());
+            passed = false;
+        } else {
+            std::vector<double> variables(static_cast<size_t>(nel0) * MGCFD_NVAR), master(variables.size());
+            for (auto &v : master) file >> v;
+            if (get(MGCFD_ARR_VARIABLES, MGCFD_NVAR, variables.data()) != MGCFD_OK) return fail("reading back variables");
+            std::printf("  scanning variables[] on level 0 for errors\n");
+            int64_t first_bad = -1;
+            if (mgcfd_identify_differences(variables.data(), master.data(), nel0, mesh_variant, &first_bad) != MGCFD_OK) {
+                std::printf("ERROR: Unacceptable error detected at (i=%ld, v=%d)\n", (long)(first_bad / MGCFD_NVAR), int(first_bad % MGCFD_NVAR));
+                std::printf("       - incorrect value = %.23f\n", variables[static_cast<size_t>(first_bad)]);
+                std::printf("       - correct value =   %.23f\n", master[static_cast<size_t>(first_bad)]);
+                return EXIT_FAILURE;
+            }
+        }
+        if (passed) std::printf("PASS: variables[] validated successfully\n");
+        std::printf("\n");
+    }
+    // ---- dumps, level 0 only (src/euler3d_cpu_double.cpp:752-772) ----
+    auto dump = [&](int which, const char *name, int ncols) -> int {
+        std::vector<double> a(static_cast<size_t>(nel0) * ncols);
+        if (get(which, ncols, a.data()) != MGCFD_OK) return fail("reading back an array");
+        const std::string path = output_filepath(conf, name, 0);
+        if (which == MGCFD_ARR_VARIABLES) std::printf("Dumping variables[] to file: %s\n", path.c_str());
+        if (mgcfd_write_array(path.c_str(), a.data(), nel0, ncols) != MGCFD_OK) return fail("writing a dump");
+        return 0;
+    };
+    if (conf.output_variables && dump(MGCFD_ARR_VARIABLES, "variables", MGCFD_NVAR)) return EXIT_FAILURE;
+    if (conf.output_step_factors && dump(MGCFD_ARR_STEP_FACTORS, "step_factors", 1)) return EXIT_FAILURE;
+    if (conf.output_fluxes && dump(MGCFD_ARR_FLUXES, "fluxes", MGCFD_NVAR)) return EXIT_FAILURE;
+    if (conf.output_volumes && dump(MGCFD_ARR_VOLUMES, "volumes", 1)) return EXIT_FAILURE;
+    return 0;
+}
+
 // --gpus N (multi_gpu.cpp): the same outputs as the one-GPU run from N ranks of this process
 int run_on_several_gpus(const Config &conf, mgcfd_mesh *mesh, int levels, int mesh_variant, int problem_size)
 {
@@ -291,18 +347,14 @@ int run_on_several_gpus(const Config &conf, mgcfd_mesh *mesh, int levels, int me
             return EXIT_FAILURE;
         }
         if (rc != MGCFD_OK) return fail("running the cycles");
-        std::printf("Total runtime = %g\n\n", total_compute_time);
+        std::printf("Total runtime = %g\n", total_compute_time);
         mgcfd_level_desc d0;
         mgcfd_mesh_level(mesh, 0, &d0);
-        auto dump = [&](int which, const char *name, int ncols) {
-            std::vector<double> a(static_cast<size_t>(d0.nel) * ncols);
-            run.get_level0(which, ncols, a.data());
-            const std::string path = output_filepath(conf, name, 0);
-            if (which == MGCFD_ARR_VARIABLES) std::printf("Dumping variables[] to file: %s\n", path.c_str());
-            if (mgcfd_write_array(path.c_str(), a.data(), d0.nel, ncols) != MGCFD_OK) { fail("writing a dump"); std::exit(EXIT_FAILURE); }
-        };
-        if (conf.output_variables) dump(MGCFD_ARR_VARIABLES, "variables", MGCFD_NVAR);
-        if (conf.output_step_factors) dump(MGCFD_ARR_STEP_FACTORS, "step_factors", 1);
+        // -v and every dump as on one GPU (level 0 gathered from the ranks that own its nodes)
+        if (validate_and_dump(conf, levels, mesh_variant, d0.nel,
+                              [&](int which, int ncols, double *out) { run.get_level0(which, ncols, out); return MGCFD_OK; },
+                              [&](int level, int64_t *bad) { return run.check_invalid(level, bad); }))
+            return EXIT_FAILURE;
         std::string device_name = "unknown GPU";
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, conf.device) == hipSuccess) device_name = prop.name;
@@ -393,56 +445,11 @@ int main(int argc, char **argv)
     std::printf("Total runtime = %g\n", total_compute_time);
 
     const int64_t nel0 = mgcfd_level_nel(solver, 0);
-    std::vector<double> variables(static_cast<size_t>(nel0) * MGCFD_NVAR);
-
-    // ---- validate (src/euler3d_cpu_double.cpp:704-744) ----
-    std::printf("\n");
-    if (conf.validate_result) {
-        std::printf("Beginning validation of variables[]\n");
-        for (int l = 0; l < levels; l++) {
-            int64_t bad = -1;
-            if (mgcfd_check_for_invalid_variables(solver, l, &bad) != MGCFD_OK) {
-                std::printf("\nERROR: NaN detected!\nCell %ld\n", (long)bad);
-                return EXIT_FAILURE;
-            }
-        }
-        std::printf("  NaN check passed\n");
-        bool passed = true;
-        const std::string sol = solution_filepath(conf, "variables", 0);
-        std::ifstream file(sol);
-        if (!file.is_open()) {
-            std::printf("  could not open variables solution file:\n    %s\n  aborting validation\n", sol.c_str());
-            passed = false;
-        } else {
-            std::vector<double> master(variables.size());
-            for (auto &v : master) file >> v;
-            if (mgcfd_get_array(solver, 0, MGCFD_ARR_VARIABLES, variables.data()) != MGCFD_OK) return fail("reading back variables");
-            std::printf("  scanning variables[] on level 0 for errors\n");
-            int64_t first_bad = -1;
-            if (mgcfd_identify_differences(variables.data(), master.data(), nel0, mesh_variant, &first_bad) != MGCFD_OK) {
-                std::printf("ERROR: Unacceptable error detected at (i=%ld, v=%d)\n", (long)(first_bad / MGCFD_NVAR), int(first_bad % MGCFD_NVAR));
-                std::printf("       - incorrect value = %.23f\n", variables[static_cast<size_t>(first_bad)]);
-                std::printf("       - correct value =   %.23f\n", master[static_cast<size_t>(first_bad)]);
-                return EXIT_FAILURE;
-            }
-        }
-        if (passed) std::printf("PASS: variables[] validated successfully\n");
-        std::printf("\n");
-    }
-
-    // ---- dumps, level 0 only (src/euler3d_cpu_double.cpp:752-772) ----
-    auto dump = [&](int which, const char *name, int ncols) -> int {
-        std::vector<double> a(static_cast<size_t>(nel0) * ncols);
-        if (mgcfd_get_array(solver, 0, which, a.data()) != MGCFD_OK) return fail("reading back an array");
-        const std::string path = output_filepath(conf, name, 0);
-        if (which == MGCFD_ARR_VARIABLES) std::printf("Dumping variables[] to file: %s\n", path.c_str());
-        if (mgcfd_write_array(path.c_str(), a.data(), nel0, ncols) != MGCFD_OK) { fail("writing a dump"); std::exit(EXIT_FAILURE); }
-        return 0;
-    };
-    if (conf.output_variables && dump(MGCFD_ARR_VARIABLES, "variables", MGCFD_NVAR)) return EXIT_FAILURE;
-    if (conf.output_step_factors && dump(MGCFD_ARR_STEP_FACTORS, "step_factors", 1)) return EXIT_FAILURE;
-    if (conf.output_fluxes && dump(MGCFD_ARR_FLUXES, "fluxes", MGCFD_NVAR)) return EXIT_FAILURE;
-    if (conf.output_volumes && dump(MGCFD_ARR_VOLUMES, "volumes", 1)) return EXIT_FAILURE;
+    // ---- validate, dumps (src/euler3d_cpu_double.cpp:704-772) ----
+    if (validate_and_dump(conf, levels, mesh_variant, nel0,
+                          [&](int which, int ncols, double *out) { (void)ncols; return mgcfd_get_array(solver, 0, which, out); },
+                          [&](int level, int64_t *bad) { return mgcfd_check_for_invalid_variables(solver, level, bad); }))
+        return EXIT_FAILURE;
 
     // ---- performance data (src/euler3d_cpu_double.cpp:778-785) ----
     std::string ih, il;

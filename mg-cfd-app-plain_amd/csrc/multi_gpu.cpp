@@ -304,6 +304,23 @@ void Run::get_level0(int which, int ncols, double *out) const
     }
 }
 
+int Run::check_invalid(int level, int64_t *bad_cell) const
+{
+    // (validation.cpp:107-138 stops at the first bad cell in original order: the smallest global id over the ranks)
+    if (!p->partitioned) return mgcfd_check_for_invalid_variables(p->solvers[static_cast<size_t>(level % ranks())], level, bad_cell);
+    int rc_all = MGCFD_OK;
+    int64_t first = -1;
+    for (size_t r = 0; r < p->solvers.size(); r++) {
+        int64_t bad = -1;
+        const int rc = mgcfd_check_for_invalid_variables(p->solvers[r], 0, &bad);
+        if (rc == MGCFD_OK) continue;
+        const int64_t g = (bad >= 0 && bad < int64_t(p->parts[r].gids.size())) ? p->parts[r].gids[static_cast<size_t>(bad)] : bad;
+        if (first < 0 || g < first) { first = g; rc_all = rc; }
+    }
+    if (bad_cell) *bad_cell = first;
+    return rc_all;
+}
+
 void Run::loop_iters(int level, int cycles, int64_t out[MGCFD_NUM_LOOPS]) const
 {
     // what the reference's counters would hold for the whole mesh (src/Monitoring/loop_stats.cpp:48-81): a rank's own

@@ -24,6 +24,7 @@ public:
     bool partitioned() const;                              // true: one level split over the ranks; false: one multigrid level per rank
     int run_cycles(int cycles, double *rms_out);           // MGCFD_OK or MGCFD_ERR_NAN / NEG_*
     void get_level0(int which, int ncols, double *out) const;   // a level-0 array of the WHOLE mesh, original numbering
+    int check_invalid(int level, int64_t *bad_cell) const;      // check_for_invalid_variables on `level` of the whole mesh (original cell id)
     void loop_iters(int level, int cycles, int64_t out[MGCFD_NUM_LOOPS]) const;
 private:
     Impl *p;

@@ -935,4 +935,160 @@ void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge
     if (!P.pro_tiled) { P.pro_tile_n.clear(); P.pro_tile_ids.clear(); P.pro_s16.clear(); P.pro_own16.clear(); }
 }
 
+// ------------------------------------------------------------------------------------------
+// Bounds audit of a freshly built plan (before the solver drops the host copies): every index the kernels form from
+// the plan's tables — LDS slots, halo and overflow positions, half-row owners, list entries, children, staged coarse
+// nodes — against the size of what it indexes, as kernels.hip forms it (k_flux_tile and its role-5 form, k_flux_half,
+// k_flux_free, k_flux_edge_once, k_restrict, k_prolong_tile).  Returns "" when everything is in range, else one line
+// per kind of violation (the first few of each).  Host only: tests/test_host_plan_audit.py, tools/plan_stats.cpp.
+// ------------------------------------------------------------------------------------------
+std::string audit_level_plan(const mgcfd_level_desc &L, const LevelPlan &P, int64_t nel_coarse)
+{
+    std::string rep;
+    int shown[32] = {0};
+    auto bad = [&](int kind, const std::string &what) { if (shown[kind]++ < 3) rep += what + "\n"; };
+    const int64_t nel = L.nel;
+    auto S = [](int64_t v) { return std::to_string(v); };
+    if (P.nel != nel) bad(0, "plan.nel " + S(P.nel) + " != level nel " + S(nel));
+    if (int64_t(P.old_of_new.size()) != nel || int64_t(P.new_of_old.size()) != nel) { bad(0, "permutation arrays are not nel long"); return rep; }
+    for (int64_t n = 0; n < nel; n++) {
+        const int32_t o = P.old_of_new[size_t(n)];
+        if (o < 0 || o >= nel || P.new_of_old[size_t(o)] != n) { bad(1, "old_of_new / new_of_old are not inverse permutations at new id " + S(n)); break; }
+    }
+    if (P.n_tiles != int32_t((nel + kTile - 1) / kTile) || P.n_slices != P.n_tiles * (kTile / kSlice)) bad(2, "tile / slice counts do not cover the level");
+    if (int64_t(P.slice_row0.size()) != P.n_slices + 1 || int64_t(P.rows_int.size()) != P.n_slices || int64_t(P.rows_bnd.size()) != P.n_slices) { bad(2, "slice tables have the wrong length"); return rep; }
+    for (int32_t sl = 0; sl < P.n_slices; sl++)
+        if (P.slice_row0[size_t(sl) + 1] - P.slice_row0[size_t(sl)] != P.rows_int[size_t(sl)] + P.rows_bnd[size_t(sl)] || P.rows_int[size_t(sl)] < 0 || P.rows_bnd[size_t(sl)] < 0)
+            bad(3, "slice " + S(sl) + ": rows_int + rows_bnd != its share of slice_row0");
+    const int64_t rows = P.slice_row0.back();
+    if (int64_t(P.nbr16.size()) < rows * kSlice || int64_t(P.w.size()) < rows * kSlice || int64_t(P.nbr.size()) < rows * kSlice) { bad(3, "row arrays shorter than rows * 64"); return rep; }
+    if (int64_t(P.tile_halo_ptr.size()) != P.n_tiles + 1 || int64_t(P.tile_ovf_ptr.size()) != P.n_tiles + 1) { bad(4, "tile halo tables have the wrong length"); return rep; }
+    const bool tail_rows = P.has_tail;
+    for (int32_t t = 0; t < P.n_tiles; t++) {
+        const int64_t base = int64_t(t) * kTile;
+        const int32_t n_here = int32_t(std::min<int64_t>(kTile, nel - base));
+        const int32_t staged = P.tile_halo_ptr[size_t(t) + 1] - P.tile_halo_ptr[size_t(t)];
+        const int32_t n_ovf = P.tile_ovf_ptr[size_t(t) + 1] - P.tile_ovf_ptr[size_t(t)];
+        if (staged < 0 || staged > kHaloStride) bad(4, "tile " + S(t) + ": " + S(staged) + " staged halo nodes exceed the table's stride " + S(kHaloStride));
+        if (staged > P.halo_max && n_ovf == 0) bad(4, "tile " + S(t) + ": halo_max understates its halo");
+        for (int32_t k = P.tile_halo_ptr[size_t(t)]; k < P.tile_halo_ptr[size_t(t) + 1]; k++) {
+            const int32_t id = P.tile_halo[size_t(k)];
+            if (id < 0 || id >= nel) bad(5, "tile " + S(t) + ": halo id " + S(id) + " outside [0, nel)");
+            else if (id >= base && id < base + kTile) bad(5, "tile " + S(t) + ": its own node " + S(id) + " listed as halo");
+        }
+        for (int32_t k = P.tile_ovf_ptr[size_t(t)]; k < P.tile_ovf_ptr[size_t(t) + 1]; k++)
+            if (P.tile_ovf[size_t(k)] < 0 || P.tile_ovf[size_t(k)] >= nel) bad(5, "tile " + S(t) + ": overflow id outside [0, nel)");
+        // what a 16-bit code may name, and that it names the node the 32-bit table names
+        auto code_ok = [&](uint32_t c16, int32_t c32, const char *where) {
+            const uint32_t slot = c16 & kT16SlotMask;
+            if (slot == kT16Pad || slot == kT16Wall || slot == kT16Far) return;
+            int64_t id = -1;
+            if (slot < uint32_t(kTile)) { if (int32_t(slot) >= n_here) bad(6, std::string(where) + ": tile " + S(t) + " names own slot " + S(slot) + " of " + S(n_here)); id = base + slot; }
+            else if (slot < uint32_t(kTile + staged)) id = P.tile_halo[size_t(P.tile_halo_ptr[size_t(t)]) + slot - kTile];
+            else if (slot < uint32_t(kTileCap)) bad(6, std::string(where) + ": tile " + S(t) + " names LDS slot " + S(slot) + " beyond its " + S(staged) + " staged halo nodes");
+            else if (int32_t(slot) - kTileCap >= n_ovf) bad(6, std::string(where) + ": tile " + S(t) + " names overflow entry " + S(int32_t(slot) - kTileCap) + " of " + S(n_ovf));
+            else id = P.tile_ovf[size_t(P.tile_ovf_ptr[size_t(t)]) + slot - kTileCap];
+            if (c32 >= 0 && id >= 0 && id != (c32 & kIdMask)) bad(7, std::string(where) + ": tile " + S(t) + ": the 16-bit code and the 32-bit table name different nodes");
+        };
+        const int32_t s0 = t * (kTile / kSlice);
+        for (int32_t sl = s0; sl < s0 + kTile / kSlice; sl++) {
+            for (int64_t row = P.slice_row0[size_t(sl)]; row < P.slice_row0[size_t(sl) + 1]; row++)
+                for (int lane = 0; lane < kSlice; lane++) {
+                    const size_t e = size_t(row) * kSlice + lane;
+                    // (long rows: an entry moved to the workgroup's list is blanked in nbr16 and lives in tail_rec)
+                    if (!(tail_rows && (P.nbr16[e] & kT16SlotMask) == kT16Pad)) code_ok(P.nbr16[e], P.nbr[e], "nbr16");
+                }
+        }
+        if (P.has_tail) {
+            const int32_t b = P.tail_tile_ptr[size_t(t)], e = P.tail_tile_ptr[size_t(t) + 1];
+            if (b < 0 || e < b || e > P.tail_total || (b % 8) || (e % 8)) bad(8, "tile " + S(t) + ": list range [" + S(b) + ", " + S(e) + ") outside the list or not whole lines");
+            for (int32_t k = b; k < e && k < P.tail_total; k++) {
+                uint64_t word; std::memcpy(&word, &P.tail_rec[size_t(k) * 6 + 4], sizeof(word));
+                const uint32_t own = uint32_t(word & 0xFFFFu), code = uint32_t(word >> 16) & 0xFFFFu;
+                if (own == kT16Pad) continue;
+                if (int32_t(own) >= n_here) bad(8, "tile " + S(t) + ": list entry owned by thread " + S(own) + " of " + S(n_here));
+                code_ok(code, -1, "list entry");
+            }
+            for (int32_t k = 0; k < n_here; k++) {
+                const int32_t nb = P.tail_begin[size_t(base + k)], nc = P.tail_count[size_t(base + k)];
+                if (nc > 0 && (nb < b || nb + nc > e)) bad(8, "tile " + S(t) + ": a node's list entries leave its tile's range");
+            }
+        }
+        if (P.half) {
+            const int32_t r0 = P.hr_row0[size_t(s0)], r1 = P.hr_row0[size_t(s0) + kTile / kSlice];
+            if (r1 - r0 > kHalfTileRows) bad(9, "tile " + S(t) + ": " + S(r1 - r0) + " half rows exceed what the flux terms' LDS image holds");
+            if (staged != (P.tile_halo_ptr[size_t(t) + 1] - P.tile_halo_ptr[size_t(t)]) || n_ovf != 0) bad(9, "tile " + S(t) + ": half rows on a tile with unstaged halo nodes");
+            for (int32_t sl = s0; sl < s0 + kTile / kSlice; sl++) {
+                const int32_t n_h = P.hr_row0[size_t(sl) + 1] - P.hr_row0[size_t(sl)];
+                if (n_h < 0 || n_h > kHalfMaxRows) bad(9, "slice " + S(sl) + ": " + S(n_h) + " half rows per lane (a lane keeps " + S(kHalfMaxRows) + ")");
+                for (int64_t row = P.hr_row0[size_t(sl)]; row < P.hr_row0[size_t(sl) + 1]; row++)
+                    for (int lane = 0; lane < kSlice; lane++) {
+                        const uint32_t c = P.hr_code[size_t(row) * kSlice + lane];
+                        if ((c & kT16SlotMask) == kT16Pad) continue;
+                        code_ok(c & 0xFFFFu, -1, "half row");
+                        if ((c & kT16SlotMask) >= uint32_t(kTileCap)) bad(10, "half row names an overflow node");
+                        const uint32_t own = (c >> 16) & 0xFFu, host = uint32_t((sl - s0) * kSlice + lane);
+                        if (int32_t(own) >= n_here) bad(10, "tile " + S(t) + ": half row owned by thread " + S(own) + " of " + S(n_here));
+                        if (((c & kHalfForeign) != 0) != (own != host)) bad(10, "tile " + S(t) + ": the foreign flag of a half row disagrees with its owner");
+                        if ((c & kHalfMirror) && (c & kT16SlotMask) >= uint32_t(kTile)) bad(10, "tile " + S(t) + ": a half row hands -F to a node outside the tile");
+                    }
+                for (int64_t row = P.slice_row0[size_t(sl)]; row < P.slice_row0[size_t(sl)] + P.rows_int[size_t(sl)]; row++)
+                    for (int lane = 0; lane < kSlice; lane++) {
+                        const uint32_t g = P.hg16[size_t(row) * kSlice + lane] & kT16SlotMask;
+                        if (g != kT16Pad && int32_t(g) >= (r1 - r0) * kSlice) bad(11, "tile " + S(t) + ": a gather position beyond the tile's flux terms");
+                    }
+            }
+        }
+        if (P.edge_once) {
+            const int32_t n_te = P.te_count[size_t(t)];
+            const int32_t chunks = P.te_chunk_ptr[size_t(t) + 1] - P.te_chunk_ptr[size_t(t)];
+            if (n_te > chunks * kEdgeChunk || chunks > kMaxEdgeChunks) bad(12, "tile " + S(t) + ": " + S(n_te) + " listed edges in " + S(chunks) + " chunks");
+            for (int32_t pp = 0; pp < n_te; pp++) {
+                const size_t c = size_t(P.te_chunk_ptr[size_t(t)]) + size_t(pp / kEdgeChunk), ln = size_t(pp % kEdgeChunk);
+                code_ok(P.te_slots[(c * 2 + 0) * kEdgeChunk + ln], -1, "edge list (a)");
+                code_ok(P.te_slots[(c * 2 + 1) * kEdgeChunk + ln], -1, "edge list (b)");
+            }
+            for (int32_t sl = s0; sl < s0 + kTile / kSlice; sl++)
+                for (int64_t row = P.slice_row0[size_t(sl)]; row < P.slice_row0[size_t(sl)] + P.rows_int[size_t(sl)]; row++)
+                    for (int lane = 0; lane < kSlice; lane++) {
+                        const uint32_t g = P.gat16[size_t(row) * kSlice + lane] & kT16SlotMask;
+                        if (g != kT16Pad && int32_t(g) >= n_te) bad(12, "tile " + S(t) + ": a row refers to listed edge " + S(g) + " of " + S(n_te));
+                    }
+        }
+    }
+    // role 5 (k_flux_tile absorbing the first stage's time_step) reads old_variables / vin_flux / volumes at every staged node and
+    // never the second halo slot or the overflow table: the solver launches it only under this condition (solver.cpp: vin_ok)
+    const bool vin_ok = P.halo_overflow_refs == 0 && P.halo_max <= kTile;
+    if (vin_ok)
+        for (int32_t t = 0; t < P.n_tiles; t++)
+            if (P.tile_halo_ptr[size_t(t) + 1] - P.tile_halo_ptr[size_t(t)] > kTile || P.tile_ovf_ptr[size_t(t) + 1] != P.tile_ovf_ptr[size_t(t)])
+                bad(13, "tile " + S(t) + " violates what a role-5 launch assumes although the level claims it (vin_ok)");
+    if (!P.child_ptr.empty()) {
+        if (nel_coarse < 0 || int64_t(P.child_ptr.size()) != nel_coarse + 1) bad(14, "child_ptr is not nel_coarse + 1 long");
+        else {
+            for (int64_t c = 0; c < nel_coarse; c++) if (P.child_ptr[size_t(c) + 1] < P.child_ptr[size_t(c)]) bad(14, "child_ptr decreases at coarse node " + S(c));
+            if (P.child_ptr.back() != int32_t(P.child.size())) bad(14, "child_ptr does not end at the number of children");
+        }
+        for (int32_t c : P.child) if (c < 0 || c >= nel) { bad(14, "a child id outside the fine level"); break; }
+        for (int64_t n = 0; n < nel && n < int64_t(P.pro_parent.size()); n++) {
+            const int32_t pr = P.pro_parent[size_t(n)], id = pr < 0 ? ~pr : pr;
+            if (id < 0 || id >= nel_coarse) { bad(15, "node " + S(n) + ": parent outside the coarse level"); break; }
+        }
+        for (size_t e = 0; e < P.pro.size(); e++)
+            if ((P.pro[e].w_own != 0.0 || P.pro[e].w_other != 0.0) && (P.pro[e].p_other < 0 || P.pro[e].p_other >= nel_coarse || P.pro[e].p_own < 0 || P.pro[e].p_own >= nel_coarse)) { bad(15, "a prolongation entry's parent outside the coarse level"); break; }
+        if (P.pro_tiled)
+            for (int32_t t = 0; t < P.n_tiles; t++) {
+                const int32_t n_ids = P.pro_tile_n[size_t(t)];
+                if (n_ids < 0 || n_ids > kProCap) bad(16, "tile " + S(t) + ": " + S(n_ids) + " staged coarse nodes");
+                for (int32_t k = 0; k < n_ids; k++) if (P.pro_tile_ids[size_t(t) * kProCap + k] < 0 || P.pro_tile_ids[size_t(t) * kProCap + k] >= nel_coarse) bad(16, "tile " + S(t) + ": a staged coarse id outside the coarse level");
+                const int64_t n0 = int64_t(t) * kTile, n1 = std::min<int64_t>(nel, n0 + kTile);
+                for (int64_t n = n0; n < n1; n++) if (P.pro_own16[size_t(n)] >= n_ids) bad(16, "node " + S(n) + ": own parent's position beyond the tile's list");
+                for (int32_t sl = t * (kTile / kSlice); sl < (t + 1) * (kTile / kSlice); sl++)
+                    for (int64_t e = int64_t(P.slice_row0[size_t(sl)]) * kSlice; e < (int64_t(P.slice_row0[size_t(sl)]) + P.rows_int[size_t(sl)]) * kSlice; e++)
+                        if ((P.pro[size_t(e)].w_own != 0.0 || P.pro[size_t(e)].w_other != 0.0) && P.pro_s16[size_t(e)] >= n_ids) bad(16, "tile " + S(t) + ": an entry's parent position beyond the tile's list");
+            }
+    }
+    return rep;
+}
+
 } // namespace mgcfd

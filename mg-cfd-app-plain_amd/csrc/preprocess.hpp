@@ -12,6 +12,7 @@
 #pragma once
 
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "mgcfd.h"
@@ -177,6 +178,10 @@ void build_transfer_plan(const mgcfd_level_desc &fine, const std::vector<mgcfd_e
                          const double *coarse_coords, int64_t nel_coarse,
                          const std::vector<int32_t> &coarse_new_of_old, LevelPlan &fine_plan,
                          const int64_t *child_order_key = nullptr, int64_t n_owned_fine = -1);
+
+// Every index the kernels form from a freshly built plan against the size of what it indexes ("" = all in range);
+// nel_coarse: size of the next-coarser level when a transfer plan was built into P, else -1.
+std::string audit_level_plan(const mgcfd_level_desc &lvl, const LevelPlan &plan, int64_t nel_coarse = -1);
 
 // Edge-weight preconditioning exactly as the reference does before its loop
 // (src/Kernels/validation.cpp:28-75, src/euler3d_cpu_double.cpp:337-352).

@@ -75,10 +75,16 @@ struct HaloExchange {
     hipEvent_t packed[kSets] = {nullptr, nullptr, nullptr}, arrived[kSets] = {nullptr, nullptr, nullptr};
     hipEvent_t reduced = nullptr, gathered = nullptr, joined = nullptr;   // the in-process all-reduce of the time step; graph capture joins
     double *gmin = nullptr;                              // device [world]: [0] = the group's minimum time step (in-process groups)
-    const double **peer_scalars = nullptr;               // device [world]: where every rank of the group keeps its minimum
+    // in-process groups: every rank reads the others' minima IN PLACE (k_min_over_peers), so a rank's minimum of sweep k must not
+    // be overwritten by its reduction of sweep k + 1 while a rank that is no halo neighbour — nothing on the device orders the two —
+    // may still be reading it: the minima alternate between two words by sweep parity (a reader two sweeps behind cannot exist:
+    // the writer's gather of sweep k + 1 waits for the reader's reduction event of sweep k + 1, which lies behind its read of sweep k)
+    double *min_par = nullptr;                           // device [2]: this rank's minimum of even / odd sweeps
+    int min_parity = 0;                                  // ... and which of them the NEXT sweep writes
+    const double **peer_scalars[2] = {nullptr, nullptr}; // device [world] per parity: where every rank of the group keeps that minimum
     // the sweep as a captured graph per buffer rotation (one host call per sweep instead of ~25): RCCL ranks
-    hipGraphExec_t sweep_graph[3] = {nullptr, nullptr, nullptr};
-    int64_t graph_iters[3][MGCFD_NUM_LOOPS] = {{0}};
+    hipGraphExec_t sweep_graph[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [rotation (+ 3 x parity of the minima: in-process groups)]
+    int64_t graph_iters[6][MGCFD_NUM_LOOPS] = {{0}};
     bool graph_failed = false;
     // in-process groups, direct mode: a rank's message is stored by ONE launch straight into its peers' ghost slots
     // (k_halo_push) — no message buffers, no second stream, no unpack; a stage's boundary tiles wait for the peers'
@@ -97,6 +103,7 @@ struct HaloExchange {
     unsigned long long *all_flag[kMaxIpcRanks] = {};     // opened: rank r's flag word [this rank][3]
     unsigned *ticket = nullptr;                          // device: workgroups of the running push that are done
     int *ipc_timeouts = nullptr;                         // device: waits that gave up (a peer that never arrived)
+    bool ipc_unacknowledged = false;                     // a synchronising call has found ipc_timeouts != 0 and nobody has asked mgcfd_rank_ipc_status since
     unsigned long long seq = 0;                          // messages pushed so far (all ranks push in lockstep)
     double *peer_state[kMaxPushPeers][3] = {};           // opened: peer k's three state buffers, as the peer numbers them
     int64_t peer_stride[kMaxPushPeers] = {};
@@ -491,6 +498,23 @@ struct mgcfd_solver {
     }
 };
 
+// Ranks in different processes, direct stores (mgcfd_rank_ipc_*): a wait for a neighbour's message that gave up (k_flags_wait,
+// about two seconds) let the stages behind it run on stale ghosts.  Every call that synchronises looks at the counter and
+// FAILS while it is not zero; mgcfd_rank_ipc_status reads it and thereby acknowledges.  Call with the stream idle.
+static void fail_on_ipc_timeouts(mgcfd_solver *s)
+{
+    for (DeviceLevel &lv : s->L) {
+        if (!lv.hx || !lv.hx->ipc || !lv.hx->ipc_timeouts) continue;
+        int n = 0;
+        HIP_CHECK(hipMemcpy(&n, lv.hx->ipc_timeouts, sizeof(int), hipMemcpyDeviceToHost));
+        if (n != 0) {
+            lv.hx->ipc_unacknowledged = true;
+            throw HipError(std::to_string(n) + " wait(s) for a neighbouring rank's message gave up: the state of this rank was computed from stale ghosts "
+                           "(mgcfd_rank_ipc_status acknowledges; mgcfd_rank_ipc_detach returns to the buffered exchange)");
+        }
+    }
+}
+
 mgcfd_solver::~mgcfd_solver()
 {
     (void)hipSetDevice(device);
@@ -515,7 +539,7 @@ mgcfd_solver::~mgcfd_solver()
         if (lv.hx) {
             HaloExchange &hx = *lv.hx;
             for (void *m : hx.ipc_opened) (void)hipIpcCloseMemHandle(m);
-            void *hp[] = {hx.node_send_ptr, hx.node_send_target, hx.node_send_peer, hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.tiles_all, hx.gmin, hx.peer_scalars, hx.push_target, hx.flags, hx.ticket, hx.ipc_timeouts, hx.gmins};
+            void *hp[] = {hx.node_send_ptr, hx.node_send_target, hx.node_send_peer, hx.send_idx, hx.recv_idx, hx.tiles_boundary, hx.tiles_interior, hx.tiles_all, hx.gmin, hx.peer_scalars[0], hx.peer_scalars[1], hx.min_par, hx.push_target, hx.flags, hx.ticket, hx.ipc_timeouts, hx.gmins};
             for (hipEvent_t e : hx.bdone) if (e) (void)hipEventDestroy(e);
             for (void *p : hp) if (p) (void)hipFree(p);
             for (int b = 0; b < HaloExchange::kSets; b++) {
@@ -523,8 +547,8 @@ mgcfd_solver::~mgcfd_solver()
                 if (hx.recv_buf[b]) (void)hipFree(hx.recv_buf[b]);
                 if (hx.packed[b]) (void)hipEventDestroy(hx.packed[b]);
                 if (hx.arrived[b]) (void)hipEventDestroy(hx.arrived[b]);
-                if (hx.sweep_graph[b]) (void)hipGraphExecDestroy(hx.sweep_graph[b]);
             }
+            for (hipGraphExec_t ge : hx.sweep_graph) if (ge) (void)hipGraphExecDestroy(ge);
             for (hipEvent_t e : {hx.reduced, hx.gathered, hx.joined}) if (e) (void)hipEventDestroy(e);
             if (hx.comm_stream) (void)hipStreamDestroy(hx.comm_stream);
         }
@@ -880,6 +904,43 @@ int mgcfd_identify_differences(const double *t, const double *m, int64_t nel, in
     return MGCFD_OK;
 }
 
+// Host only: the gather plans mgcfd_create[_partitioned[_mg]] would build for these levels, audited (preprocess.cpp:
+// audit_level_plan).  No device is touched.
+int mgcfd_plan_audit(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, const int64_t *n_owned,
+                     const int64_t *const *order_keys, char *report, int64_t report_cap)
+{
+    REQUIRE(levels);
+    std::string rep;
+    const int rc = guarded([&] {
+        if (nlevels <= 0) throw std::invalid_argument("no levels given");
+        std::vector<LevelPlan> plans(static_cast<size_t>(nlevels));
+        std::vector<std::vector<mgcfd_edge>> edges(static_cast<size_t>(nlevels));
+        for (int l = 0; l < nlevels; l++) {
+            const mgcfd_level_desc &d = levels[l];
+            if (!d.volumes || !d.edges) throw std::invalid_argument("level is missing volumes/edges");
+            edges[static_cast<size_t>(l)].assign(d.edges, d.edges + d.n_edges);
+            adjust_and_dampen(d, mesh_variant, edges[static_cast<size_t>(l)]);
+            PlanOptions popt;
+            if (n_owned && n_owned[l] >= 0 && n_owned[l] < d.nel) popt.n_owned = n_owned[l];
+            build_level_plan(d, edges[static_cast<size_t>(l)], popt, plans[static_cast<size_t>(l)]);
+        }
+        for (int l = 0; l + 1 < nlevels; l++) {
+            if (!levels[l].mg_map) throw std::invalid_argument("multigrid map missing between levels");
+            build_transfer_plan(levels[l], edges[static_cast<size_t>(l)], levels[l + 1].coords, levels[l + 1].nel,
+                                plans[static_cast<size_t>(l) + 1].new_of_old, plans[static_cast<size_t>(l)],
+                                order_keys ? order_keys[l] : nullptr, (n_owned && n_owned[l] >= 0) ? n_owned[l] : -1);
+        }
+        for (int l = 0; l < nlevels; l++) {
+            const std::string r = audit_level_plan(levels[l], plans[static_cast<size_t>(l)], l + 1 < nlevels ? levels[l + 1].nel : -1);
+            if (!r.empty()) rep += "level " + std::to_string(l) + ":\n" + r;
+        }
+    });
+    if (rc != MGCFD_OK) return rc;
+    if (report && report_cap > 0) { std::snprintf(report, static_cast<size_t>(report_cap), "%s", rep.c_str()); }
+    if (!rep.empty()) { g_last_error = "plan audit: " + rep; return MGCFD_ERR_ARG; }
+    return MGCFD_OK;
+}
+
 // ---- life cycle ----
 int mgcfd_create(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device, mgcfd_solver **out)
 {
@@ -987,7 +1048,7 @@ int mgcfd_set_stream(mgcfd_solver *s, void *hip_stream)
 int mgcfd_synchronize(mgcfd_solver *s)
 {
     REQUIRE(s);
-    return guarded([&] { s->use_device(); HIP_CHECK(hipStreamSynchronize(s->stream)); HIP_CHECK(hipGetLastError()); });
+    return guarded([&] { s->use_device(); HIP_CHECK(hipStreamSynchronize(s->stream)); HIP_CHECK(hipGetLastError()); fail_on_ipc_timeouts(s); });
 }
 int mgcfd_num_levels(const mgcfd_solver *s) { return s ? static_cast<int>(s->L.size()) : 0; }
 int64_t mgcfd_level_nel(const mgcfd_solver *s, int l)
@@ -1501,6 +1562,7 @@ int mgcfd_get_array(mgcfd_solver *s, int level, int which, double *out)
         std::vector<double> tmp(static_cast<size_t>(stride) * nc);
         HIP_CHECK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         HIP_CHECK(hipStreamSynchronize(s->stream));
+        fail_on_ipc_timeouts(s);                             // (an array computed from stale ghosts is not handed out as if it were good)
         for (int64_t n = 0; n < lv.info.nel; n++) {          // device: [field][new id]  ->  caller: [old id][field]
             const int64_t o = lv.plan.old_of_new[static_cast<size_t>(n)];
             for (int c = 0; c < nc; c++) out[o * nc + c] = tmp[static_cast<size_t>(c * stride + n)];
@@ -1967,7 +2029,7 @@ static void stage_interior(mgcfd_solver *s, int level, int j, int apply_min, con
     }
 }
 
-static void sweep_first_half(mgcfd_solver *s, int level)
+static void sweep_first_half(mgcfd_solver *s, int level, double *min_out = nullptr)
 {
     DeviceLevel &lv = s->level(level);
     if (!lv.hx) throw std::invalid_argument("the level has no halo lists: call mgcfd_rank_set_halo first");
@@ -1975,7 +2037,7 @@ static void sweep_first_half(mgcfd_solver *s, int level)
     const bool global_dt = s->mesh_variant != MGCFD_MESH_FVCORR;
     if (global_dt && lv.min_ahead) lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;      // the previous sweep's last stage looked ahead
     else s->op_step_factor(level, true, false);             // first half of compute_step_factor (a ghost's factor is its owner's business)
-    if (global_dt) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
+    if (global_dt) exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, min_out ? min_out : lv.min_dt);
 }
 
 // one sweep of an RCCL rank, as issued (and as captured): every exchange it starts it also finishes
@@ -2150,16 +2212,18 @@ static void group_sweeps_threaded(mgcfd_group *g, int level, int sweeps, bool wi
         DeviceLevel &lv = s->level(level);
         HaloExchange &hx = *lv.hx;
         for (int k = 0; k < sweeps; k++) {
+            const int par = hx.min_parity;
             step([&] {
-                sweep_first_half(s, level);
+                sweep_first_half(s, level, hx.min_par + par);
                 if (global_dt) HIP_CHECK(hipEventRecord(hx.reduced, s->stream));
             });
+            hx.min_parity = par ^ 1;
             bar.wait();
             PushPeers to[MGCFD_RK];
             step([&] {
                 if (global_dt) {
                     for (mgcfd_solver *src : g->ranks) if (src != s) HIP_CHECK(hipStreamWaitEvent(s->stream, src->level(level).hx->reduced, 0));
-                    exact::launch_min_over_peers(s->stream, hx.peer_scalars, n, hx.gmin);
+                    exact::launch_min_over_peers(s->stream, hx.peer_scalars[par], n, hx.gmin);
                 }
                 // the peers' buffers of this sweep's three stages, read while nobody rotates (a rank rotates in its last stage's
                 // second part, two barriers from here; its previous rotation lies before the barrier just passed)
@@ -2192,7 +2256,8 @@ static void group_sweep_once(mgcfd_group *g, int level)
 {
     const int n = static_cast<int>(g->ranks.size());
     const bool global_dt = g->ranks[0]->mesh_variant != MGCFD_MESH_FVCORR;
-    for (mgcfd_solver *s : g->ranks) { s->use_device(); sweep_first_half(s, level); }
+    const int par = g->ranks[0]->level(level).hx->min_parity;       // (the ranks of a group sweep in step)
+    for (mgcfd_solver *s : g->ranks) { s->use_device(); HaloExchange &hx = *s->level(level).hx; sweep_first_half(s, level, hx.min_par + par); hx.min_parity = par ^ 1; }
     if (global_dt) {
         // all-reduce(MIN) of one fp64 over the group: behind every rank's reduction event each rank reads the others'
         // scalars itself (k_min_over_peers: 8-byte loads over xGMI) — no message, no second stream
@@ -2201,7 +2266,7 @@ static void group_sweep_once(mgcfd_group *g, int level)
             dst->use_device();
             HaloExchange &hd = *dst->level(level).hx;
             for (mgcfd_solver *src : g->ranks) if (src != dst) HIP_CHECK(hipStreamWaitEvent(dst->stream, src->level(level).hx->reduced, 0));
-            exact::launch_min_over_peers(dst->stream, hd.peer_scalars, n, hd.gmin);
+            exact::launch_min_over_peers(dst->stream, hd.peer_scalars[par], n, hd.gmin);
         }
     }
     const bool direct = g->ranks[0]->level(level).hx->direct;
@@ -2566,6 +2631,8 @@ int mgcfd_rank_ipc_detach(mgcfd_solver *s, int level)
         hx.ipc_opened.clear();
         hx.ipc = false;
         hx.ipc_all = false;
+        hx.ipc_unacknowledged = false;
+        if (hx.ipc_timeouts) HIP_CHECK(hipMemset(hx.ipc_timeouts, 0, sizeof(int)));
     });
 }
 
@@ -2581,6 +2648,7 @@ int mgcfd_rank_ipc_status(mgcfd_solver *s, int level, int *timed_out)
         HIP_CHECK(hipMemcpyAsync(timed_out, lv.hx->ipc_timeouts, sizeof(int), hipMemcpyDeviceToHost, s->stream));
         HIP_CHECK(hipMemsetAsync(lv.hx->ipc_timeouts, 0, sizeof(int), s->stream));
         HIP_CHECK(hipStreamSynchronize(s->stream));
+        lv.hx->ipc_unacknowledged = false;
     });
 }
 
@@ -2655,6 +2723,7 @@ int mgcfd_rank_sweeps(mgcfd_solver *s, int level, int sweeps)
         HaloExchange &hx = *lv.hx;
         s->settle_fluxes(lv);                               // (outside any capture: a lazy zero is not part of a sweep)
         if (hx.ipc) {
+            if (hx.ipc_unacknowledged) throw HipError("a wait for a neighbouring rank's message gave up earlier and nobody has asked mgcfd_rank_ipc_status since: no further sweeps on stale ghosts");
             for (int k = 0; k < sweeps; k++) rank_sweep_once_ipc(s, level);
             ipc_wait(s, hx, 2);                             // (the ghosts of `variables` are complete in this rank's stream order)
             return;
@@ -2793,11 +2862,19 @@ static int group_sweeps_impl(mgcfd_group *g, int level, int sweeps, double *rms_
         }
         for (mgcfd_solver *s : g->ranks) {                  // (allocations and uploads: never inside a capture)
             HaloExchange &hx = *s->level(level).hx;
-            if (hx.peer_scalars) continue;
+            if (hx.min_par) continue;
             s->use_device();
-            std::vector<const double *> ptrs;
-            for (mgcfd_solver *src : g->ranks) ptrs.push_back(src->level(level).min_dt);
-            hx.peer_scalars = dev_upload(ptrs);
+            hx.min_par = dev_alloc<double>(2);
+        }
+        for (mgcfd_solver *s : g->ranks) {
+            HaloExchange &hx = *s->level(level).hx;
+            if (hx.peer_scalars[0]) continue;
+            s->use_device();
+            for (int par = 0; par < 2; par++) {
+                std::vector<const double *> ptrs;
+                for (mgcfd_solver *src : g->ranks) ptrs.push_back(src->level(level).hx->min_par + par);
+                hx.peer_scalars[par] = dev_upload(ptrs);
+            }
         }
         group_prepare_direct(g, level);
         HaloExchange &h0 = *s0->level(level).hx;
@@ -2879,7 +2956,7 @@ static int group_sweeps_impl(mgcfd_group *g, int level, int sweeps, double *rms_
         }
         bool replayed = false;
         for (int k = 0; k < sweeps; k++) {
-            const int rot = s0->level(level).rot % 3;
+            const int rot = s0->level(level).rot % 3 + 3 * h0.min_parity;     // (the captured launches name the minima's word of this parity)
             const bool steady = s0->mesh_variant == MGCFD_MESH_FVCORR || s0->level(level).min_ahead || !part_look_ahead();   // (as in mgcfd_rank_sweeps)
             if (graphs && !h0.graph_failed && steady) {
                 if (!h0.sweep_graph[rot]) {
@@ -2902,6 +2979,7 @@ static int group_sweeps_impl(mgcfd_group *g, int level, int sweeps, double *rms_
                         s->force_check = -1;
                         for (int q = 0; q < MGCFD_NUM_LOOPS; q++) { lv.hx->graph_iters[rot][q] = lv.iters[q] - before[r][static_cast<size_t>(q)]; lv.iters[q] = before[r][static_cast<size_t>(q)]; }
                         lv.rot = rot_before[r]; lv.apply_rot();
+                        lv.hx->min_parity = rot / 3;        // (the capture advanced the host state without running anything)
                         lv.min_ahead = ahead_before;
                     }
                     if (!ok) { h0.graph_failed = true; group_sweep_once(g, level); continue; }
@@ -2909,7 +2987,7 @@ static int group_sweeps_impl(mgcfd_group *g, int level, int sweeps, double *rms_
                 s0->use_device();
                 HIP_CHECK(hipGraphLaunch(h0.sweep_graph[rot], s0->stream));
                 replayed = true;
-                for (mgcfd_solver *s : g->ranks) after_replayed_sweep(s, level, s->level(level).hx->graph_iters[rot]);
+                for (mgcfd_solver *s : g->ranks) { after_replayed_sweep(s, level, s->level(level).hx->graph_iters[rot]); s->level(level).hx->min_parity ^= 1; }
             } else {
                 group_sweep_once(g, level);
             }

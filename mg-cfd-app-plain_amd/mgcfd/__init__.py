@@ -5,4 +5,4 @@
 """
 from . import meshgen  # noqa: F401
 from .api import (EXPORTED_SYMBOLS, LIB_PATH, LOOPS, Group, MgcfdError, Mesh, Solver,  # noqa: F401
-                  generated_to_levels, load_library, rccl_unique_id)
+                  generated_to_levels, load_library, plan_audit, rccl_unique_id)

@@ -58,6 +58,7 @@ _SIGNATURES = [
     ("mgcfd_write_array", C.c_int, [C.c_char_p, _vp, _i64, C.c_int]),
     ("mgcfd_identify_differences", C.c_int, [_vp, _vp, _i64, C.c_int, C.POINTER(_i64)]),
     ("mgcfd_create", C.c_int, [C.POINTER(LevelDesc), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("mgcfd_plan_audit", C.c_int, [C.POINTER(LevelDesc), C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(C.POINTER(_i64)), C.c_char_p, _i64]),
     ("mgcfd_create_partitioned_mg", C.c_int, [C.POINTER(LevelDesc), C.c_int, C.c_int, C.c_int, C.POINTER(_i64),
                                                  C.POINTER(C.POINTER(_i64)), C.POINTER(_vp)]),
     ("mgcfd_create_from_mesh", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
@@ -233,6 +234,49 @@ class Mesh:
             pass
 
 
+def _level_descs(levels: Sequence[dict]):
+    """LevelDesc array over in-memory level dicts + the arrays that must stay alive while it is used."""
+    descs = (LevelDesc * len(levels))()
+    keep = []
+    for l, L in enumerate(levels):
+        vol = np.ascontiguousarray(L["volumes"], dtype=np.float64)
+        edges = np.ascontiguousarray(L["edges"], dtype=EDGE_DTYPE)
+        crd = None if L.get("coords") is None else np.ascontiguousarray(L["coords"], dtype=np.float64)
+        mp = None if L.get("mg_map") is None else np.ascontiguousarray(L["mg_map"], dtype=np.int64)
+        keep += [vol, edges, crd, mp]
+        d = descs[l]
+        d.nel = int(L["nel"])
+        d.n_edges = len(edges)
+        d.n_internal, d.n_boundary, d.n_wall = int(L["n_internal"]), int(L["n_boundary"]), int(L["n_wall"])
+        d.internal_start = int(L.get("internal_start", 0))
+        d.boundary_start = int(L.get("boundary_start", d.n_internal))
+        d.wall_start = int(L.get("wall_start", d.n_internal + d.n_boundary))
+        d.volumes = _ptr(vol)
+        d.coords = _ptr(crd) if crd is not None else None
+        d.edges = _ptr(edges)
+        d.mg_map = _ptr(mp) if mp is not None else None
+        d.mgc = len(mp) if mp is not None else 0
+    return descs, keep
+
+
+def plan_audit(levels: Sequence[dict], mesh_variant: int, n_owned=None, order_keys=None) -> str:
+    """Host only (no GPU): build the gather plans mgcfd_create would build for `levels` and check every index the kernels
+    form from them against the size of what it indexes (mgcfd_plan_audit).  Returns "" when all is in range, else the report."""
+    lib = load_library()
+    descs, keep = _level_descs(levels)
+    owned = None if n_owned is None else (_i64 * len(levels))(*[int(v) for v in n_owned])
+    kp = None
+    if order_keys is not None:
+        keys = [None if k is None else np.ascontiguousarray(k, dtype=np.int64) for k in order_keys]
+        keep += keys
+        kp = (C.POINTER(_i64) * len(levels))(*[C.cast(_ptr(k), C.POINTER(_i64)) if k is not None else C.POINTER(_i64)() for k in keys])
+    buf = C.create_string_buffer(1 << 16)
+    rc = lib.mgcfd_plan_audit(descs, len(levels), mesh_variant, owned, kp, buf, len(buf))
+    if rc not in (0, 1):
+        _check(lib, rc)
+    return buf.value.decode()
+
+
 class Solver:
     """Device-resident solver.  Construct from a :class:`Mesh`, from a generated
     :class:`~mgcfd.meshgen.MultigridMesh`, or from raw per-level arrays."""
@@ -256,26 +300,7 @@ class Solver:
         mg_map|None) — the reference's read_grid()/read_mg_connectivity() outputs.  n_owned / order_keys: a partitioned
         level or hierarchy (mgcfd_create_partitioned / _mg)."""
         lib = load_library()
-        descs = (LevelDesc * len(levels))()
-        keep = []
-        for l, L in enumerate(levels):
-            vol = np.ascontiguousarray(L["volumes"], dtype=np.float64)
-            edges = np.ascontiguousarray(L["edges"], dtype=EDGE_DTYPE)
-            crd = None if L.get("coords") is None else np.ascontiguousarray(L["coords"], dtype=np.float64)
-            mp = None if L.get("mg_map") is None else np.ascontiguousarray(L["mg_map"], dtype=np.int64)
-            keep += [vol, edges, crd, mp]
-            d = descs[l]
-            d.nel = int(L["nel"])
-            d.n_edges = len(edges)
-            d.n_internal, d.n_boundary, d.n_wall = int(L["n_internal"]), int(L["n_boundary"]), int(L["n_wall"])
-            d.internal_start = int(L.get("internal_start", 0))
-            d.boundary_start = int(L.get("boundary_start", d.n_internal))
-            d.wall_start = int(L.get("wall_start", d.n_internal + d.n_boundary))
-            d.volumes = _ptr(vol)
-            d.coords = _ptr(crd) if crd is not None else None
-            d.edges = _ptr(edges)
-            d.mg_map = _ptr(mp) if mp is not None else None
-            d.mgc = len(mp) if mp is not None else 0
+        descs, keep = _level_descs(levels)
         h = _vp()
         if n_owned is None:
             _check(lib, lib.mgcfd_create(descs, len(levels), mesh_variant, device, C.byref(h)))

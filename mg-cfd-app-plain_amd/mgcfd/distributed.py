@@ -131,28 +131,15 @@ class ShardedSweep:
                 # The first stage's fluxes do not depend on the time step: run them while the all-reduce
                 # (latency bound, tens of microseconds over xGMI) is in flight.
                 t = s.partial_min_tensor(level) if partials else s.min_tensor(level)
-                stage = None
-                if not self._staged:
-                    try:
-                        # in place on the library's own device memory (the tensor aliases it)
-                        work = self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, async_op=True)
-                    except RuntimeError:
-                        # a backend that refuses memory torch did not allocate: go through a torch-owned copy from
-                        # now on (two small device copies per sweep; same values)
-                        self._staged = True
-                if self._staged:
-                    stage = t.clone()
-                    work = self.dist.all_reduce(stage, op=self.dist.ReduceOp.MIN, async_op=True)
+                # in place on the library's own device memory (the tensor aliases it), or — MGCFD_ALLREDUCE_STAGED=1, chosen
+                # up front and therefore by every rank alike — through a torch-owned copy (two small device copies per sweep,
+                # same values) for a backend that refuses memory torch did not allocate.  A failure of the collective itself is
+                # NOT retried here: one rank re-issuing a collective the others never issue leaves the ranks out of step for
+                # good, and after an asynchronous RCCL error the communicator is unusable anyway — the error propagates.
+                stage = t.clone() if self._staged else None
+                work = self.dist.all_reduce(stage if self._staged else t, op=self.dist.ReduceOp.MIN, async_op=True)
                 s.sweep_flux0(level)
-                try:
-                    work.wait()      # stream-level wait: later kernels are ordered after the collective
-                except RuntimeError:
-                    # RCCL reports most failures here, not at the call: fall back to a torch-owned copy for good
-                    if stage is not None:
-                        raise
-                    self._staged = True
-                    stage = t.clone()
-                    self.dist.all_reduce(stage, op=self.dist.ReduceOp.MIN)
+                work.wait()          # stream-level wait: later kernels are ordered after the collective
                 if stage is not None:
                     t.copy_(stage)
             elif self.overlap_even_alone:

@@ -1527,6 +1527,39 @@ def test_driver_on_several_gpus_reproduces_reference_binary(case, gpus, tmp_path
     assert f"{int(got['Num threads'])} ranks" in r.stderr
 
 
+@pytest.mark.parametrize("case,gpus", [("fvcorr_1lvl", 3), ("m6_3lvl", 2)])
+def test_driver_on_several_gpus_validates_and_dumps_as_on_one(case, gpus, tmp_path):
+    """--gpus N honours -v and every dump flag (the one-GPU path and the reference do, src/euler3d_cpu_double.cpp:704-772):
+    PASS against the reference binary's own dump as the solution file, exit 1 with the reference's message against a
+    spoiled one, and variables / fluxes / step-factor dumps equal to the one-GPU run's byte for byte."""
+    import shutil
+    d, cycles, dup = _case(case)
+    work = tmp_path / "in"
+    shutil.copytree(os.path.join(d, "input"), work)
+    sol = work / f"solution.variables.size={dup}x.cycles={cycles}.level=0"
+    shutil.copy(os.path.join(d, "variables.level0.txt"), sol)
+    exe = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
+    outs = {}
+    for name, extra in (("one", []), ("many", ["--gpus", str(gpus), "--gpus-share-device"])):
+        out = tmp_path / name
+        out.mkdir()
+        r = subprocess.run([exe, "-i", "input.dat", "-d", str(work), "-o", str(out) + "/", "-g", str(cycles), "-m", str(dup), "-v",
+                            "--output-variables", "--output-fluxes", "--output-step-factors"] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "NaN check passed" in r.stdout and "PASS: variables[] validated successfully" in r.stdout, r.stdout
+        outs[name] = out
+    for arr in ("variables", "fluxes", "step_factors"):
+        f = f"{arr}.size={dup}x.cycles={cycles}.level=0"
+        assert (outs["many"] / f).read_bytes() == (outs["one"] / f).read_bytes(), arr
+    vals = np.loadtxt(sol)
+    vals[7, 1] += 1e-6
+    np.savetxt(sol, vals, fmt="%.17e")
+    r = subprocess.run([exe, "-i", "input.dat", "-d", str(work), "-o", str(tmp_path) + "/", "-g", str(cycles), "-m", str(dup), "-v",
+                        "--gpus", str(gpus), "--gpus-share-device"], capture_output=True, text=True)
+    assert r.returncode != 0 and "ERROR: Unacceptable error detected at (i=7, v=1)" in r.stdout, r.stdout + r.stderr
+
+
 def test_driver_refuses_more_gpus_than_there_are(tmp_path):
     d, cycles, dup = _case("fvcorr_1lvl")
     exe = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")

@@ -1,0 +1,65 @@
+"""Host-only bounds audit of the gather plans (mgcfd_plan_audit, preprocess.cpp: audit_level_plan): for every kind of level
+the generators make — lattices with cavities, the 13^3 level of the sharded-sweep test (9 tiles, a 130-node last tile:
+the level of round 1's abort), random graphs, Delaunay tetrahedra, a hub, partitioned levels with ghosts,
+whole hierarchies with their transfer plans — every index a kernel forms from the plan's tables must lie inside the array
+it indexes.  No GPU."""
+import numpy as np
+import pytest
+
+import mgcfd
+from mgcfd import meshgen
+
+
+def _levels(mg):
+    return mgcfd.generated_to_levels(mg)
+
+
+def _single(level, name="m6wing"):
+    mg = meshgen.MultigridMesh(mesh_name=name)
+    mg.levels.append(level)
+    return mg
+
+
+CASES = {
+    "lattice 13^3 with a cavity (the sharded-sweep level)": lambda: meshgen.make_multigrid((13,), "m6wing", seed=7, cavity_radius=0.12, jitter=0.2, area_noise=0.05, volume_noise=0.05),
+    "three lattice levels": lambda: meshgen.make_multigrid((13, 9, 6), "m6wing", seed=11, cavity_radius=0.12, jitter=0.25, area_noise=0.08, volume_noise=0.1),
+    "fvcorr box": lambda: meshgen.make_multigrid((12,), "fvcorr", seed=5, cavity_radius=0.01, volume_noise=0.02),
+    "random graph, degree 10 (long rows)": lambda: _single(meshgen.make_random_graph_level(3000, degree=10, seed=4)),
+    "tetrahedra, two levels": lambda: meshgen.make_tet_multigrid((4000, 700), "m6wing", seed=3),
+    "hub of 700 spokes": lambda: _single(meshgen.make_hub_level(700, scale=1e-4, seed=6)),
+    "lattice 24^3 (54 tiles)": lambda: meshgen.make_multigrid((24,), "m6wing", seed=0, jitter=0.2, area_noise=0.02, volume_noise=0.02, permute=True),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_every_plan_index_is_in_range(name):
+    mg = CASES[name]()
+    report = mgcfd.plan_audit(_levels(mg), mg.mesh_variant)
+    assert report == "", f"{name}:\n{report}"
+
+
+def test_partitioned_levels_and_hierarchies_are_in_range():
+    from mgcfd.partition import partition_hierarchy, partition_level, rcb_partition
+    mg = meshgen.make_multigrid((14, 9), "m6wing", seed=2, cavity_radius=0.1, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    levels = _levels(mg)
+    part = rcb_partition(np.asarray(levels[0]["coords"]), 3)
+    for P in partition_level(levels[0], part):
+        report = mgcfd.plan_audit([P.level], mg.mesh_variant, n_owned=[P.n_owned])
+        assert report == "", report
+    for H in partition_hierarchy(levels, part):
+        lv, owned, keys = H.solver_args()
+        report = mgcfd.plan_audit(lv, mg.mesh_variant, n_owned=owned, order_keys=keys)
+        assert report == "", report
+
+
+def test_the_audit_sees_a_broken_plan():
+    """A multigrid map that points outside the coarse level is refused when the plan is built; an internal edge that names a
+    node outside the level must not pass silently either."""
+    mg = meshgen.make_multigrid((9, 5), "m6wing", seed=3, cavity_radius=0.15, jitter=0.2)
+    levels = _levels(mg)
+    bad = [dict(L) for L in levels]
+    m = np.array(bad[0]["mg_map"], dtype=np.int64).copy()
+    m[5] = bad[1]["nel"] + 3
+    bad[0]["mg_map"] = m
+    with pytest.raises(mgcfd.MgcfdError):
+        mgcfd.plan_audit(bad, mg.mesh_variant)

@@ -68,8 +68,8 @@ def rank_main(a):
             s.rank_sweeps(0, 1)
     else:
         s.rank_sweeps(0, a.sweeps)
+    late = s.rank_ipc_status(0)                             # (first: the library refuses the state while timeouts are unacknowledged)
     got = s.get(0, "variables")
-    late = s.rank_ipc_status(0)
     own, gh = P.global_ids[:P.n_owned], P.global_ids[P.n_owned:]
     ok_own = bool(np.array_equal(got[:P.n_owned].view(np.int64), want[own].view(np.int64)))
     ok_gh = bool(np.array_equal(got[P.n_owned:].view(np.int64), want[gh].view(np.int64)))

@@ -1,6 +1,7 @@
 // Host-only diagnostic: build the gather plan of level 0 of an input.dat and print what the half-row plan looks like.
 //   g++ -O2 -std=c++17 -Iinclude -Img-cfd-app-plain_amd/csrc tools/plan_stats.cpp -Lmg-cfd-app-plain_amd/csrc -lmgcfd_hip -Wl,-rpath,$PWD/mg-cfd-app-plain_amd/csrc -o /tmp/plan_stats
 #include <cstdio>
+#include <string>
 #include <vector>
 #include <algorithm>
 #include "mgcfd.h"
@@ -32,6 +33,14 @@ int main(int argc, char **argv)
             }
         }
         std::printf("halo gathers: %.1f nodes per tile in %.1f blocks of 16 ids (%.2f nodes per block)\n", double(nodes) / P.n_tiles, double(blocks) / P.n_tiles, double(nodes) / blocks);
+    }
+    {   // every index the kernels form from this plan against the size of what it indexes (preprocess.cpp)
+        const std::string rep = mgcfd::audit_level_plan(d, P, -1);
+        std::printf("bounds audit: %s\n", rep.empty() ? "every index in range (LDS slots, halo / overflow positions, half-row owners, list entries; role-5 precondition)" : rep.c_str());
+        const long stride = long(P.n_slices) * 64;
+        std::printf("  arrays a stage launch indexes by node: stride %ld (state, fluxes, residuals 5 x stride; volumes, step factors stride); largest node index formed %ld; "
+                    "tile_halo %d x %d ids, largest position %d; step-factor partials %d, index clamped to %d\n", stride, stride - 1, P.n_tiles, mgcfd::kHaloStride,
+                    (P.n_tiles - 1) * mgcfd::kHaloStride + mgcfd::kHaloStride - 1, P.n_tiles, P.n_tiles - 1);
     }
     if (!P.hr_row0.empty()) {
         int hist[16] = {0};

@@ -59,8 +59,14 @@ enum {
     MGCFD_OPT_EXACT = 0,       /* 1 (default): kernels compiled without FMA contraction and summing in the
                                   reference's order => bit-identical to the reference built with
                                   -ffp-contract=off.  0: contraction allowed (faster, ~1e-16 relative). */
-    MGCFD_OPT_TIMING = 1,      /* 1: bracket every loop with hipEvents (Times.csv columns); 2: only the flux launches of every 8th sweep;
-                                  3: as 2 for every sweep (reads back as 2) */
+    MGCFD_OPT_TIMING = 1,      /* 1: bracket every loop with hipEvents (Times.csv columns; every loop its own launch, as the
+                                  reference's -DTIME build brackets them, src/Monitoring/timer.cpp:58-195); 2: only the flux launches
+                                  of every 8th sweep; 3: as 2 for every sweep (reads back as 2);
+                                  4: per-loop times by ATTRIBUTION — the cycles run the fused stages; every 32nd sweep and every 32nd
+                                  restriction / prolongation of a level runs per loop under events (the indirect_rw probe in
+                                  every fourth of those, its column extrapolated at the measured rate), one event pair brackets each batch of cycles, and mgcfd_get_loop_times apportions the
+                                  batches' GPU time to (level, loop) by the sampled launches' ratios: all seven columns at
+                                  ~1.05x the fused cycle time instead of 2.7x (what euler3d_gpu_double runs by default) */
     MGCFD_OPT_INDIRECT_RW = 2, /* 1: also run the indirect_rw probe each RK stage, as the reference's main() does */
     MGCFD_OPT_CHECK_INVALID = 3, /* 1 (default): NaN / negativity check every RK stage (validation.cpp:107-138) */
     MGCFD_OPT_FLUX_VARIANT = 4, /* -1 (default): automatic — 1 (the edge-length factor recomputed: never slower on an

@@ -160,6 +160,9 @@ struct DeviceLevel {
     double times[MGCFD_NUM_LOOPS] = {0};
     double flux_time = 0.0;
     int64_t flux_launches = 0;
+    // MGCFD_OPT_TIMING = 4 (per-loop times by attribution): how often each loop ran on this level and how often under events
+    int64_t att_sweeps = 0, att_sweeps_sampled = 0;      // smoothing sweeps (flux, compute_step, time_step, indirect_rw run together)
+    int64_t att_calls[MGCFD_NUM_LOOPS] = {0}, att_calls_sampled[MGCFD_NUM_LOOPS] = {0};   // restrict (booked on the coarse level) and prolong
 };
 
 } // namespace mgcfd
@@ -186,7 +189,9 @@ struct mgcfd_solver {
     int64_t invalid_cell = -1; int invalid_cycle = -1;                     // where the last reported invalid state was found
     int next_check() { if (!opt_check) return 0; if (check_seq < (1 << 22)) check_seq++; return check_seq; }
     int force_check = -1;                    // >= 0: the sequence number the next fused stage carries (a stage launched in two parts)
-    int timing_stride = 8;                  // OPT_TIMING == 2: bracket the flux launches of every Nth sweep
+    int timing_stride = 8;                  // OPT_TIMING == 2: bracket the flux launches of every Nth sweep; == 4: every Nth sweep / transfer of a level runs unfused under events
+    double att_total = 0.0;                 // OPT_TIMING == 4: GPU seconds of the cycle batches (one event pair around each)
+    bool probe_first_stage_only = false;    // (a sampled sweep of OPT_TIMING == 4 runs the indirect_rw probe behind its first stage only)
     int64_t sweep_counter = 0;
     bool in_timed_group = false;
     struct SweepGraph { hipGraphExec_t exec = nullptr; int64_t iters[MGCFD_NUM_LOOPS] = {0}; bool ahead_after = false; int rot_after = 0; int sf_par_after = 0; bool sumsq_after = false, res_stale_after = false; };
@@ -976,7 +981,11 @@ int mgcfd_set_option(mgcfd_solver *s, int option, int value)
     return guarded([&] {
         switch (option) {
             case MGCFD_OPT_EXACT: s->opt_exact = value != 0; break;
-            case MGCFD_OPT_TIMING: s->use_device(); s->fold_events(); s->opt_timing = value == 3 ? 2 : value; s->timing_stride = value == 3 ? 1 : 8; break;
+            case MGCFD_OPT_TIMING:
+                if (value < 0 || value > 4) throw std::invalid_argument("MGCFD_OPT_TIMING is 0 ... 4");
+                s->use_device(); s->fold_events(); s->opt_timing = value == 3 ? 2 : value; s->timing_stride = value == 3 ? 1 : (value == 4 ? 32 : 8);
+                if (const char *e = std::getenv("MGCFD_TIMING_STRIDE")) if (std::atoi(e) > 0 && value != 3) s->timing_stride = std::atoi(e);
+                break;
             case MGCFD_OPT_INDIRECT_RW: s->opt_indirect_rw = value != 0; break;
             case MGCFD_OPT_CHECK_INVALID: s->opt_check = value != 0; break;
             case MGCFD_OPT_FLUX_VARIANT: s->opt_variant = value; break;
@@ -1195,7 +1204,7 @@ static void smooth_once(mgcfd_solver *s, int level)
         s->op_flux(level, 7);
         // the indirect_rw probe reads fluxes[] right after, so zero for real when it is on
         s->op_time_step(level, j, j == 0 ? apply0 : 0, j == MGCFD_RK - 1, !s->opt_indirect_rw);   // + :508 on the last stage
-        if (s->opt_indirect_rw) { s->op_indirect_rw(level); s->op_zero_fluxes(level); }
+        if (s->opt_indirect_rw && (j == 0 || !s->probe_first_stage_only)) { s->op_indirect_rw(level); s->op_zero_fluxes(level); }
     }
 }
 
@@ -1207,7 +1216,30 @@ static void run_sweep(mgcfd_solver *s, int level)
 {
     DeviceLevel &lv = s->level(level);
     const int64_t n = s->sweep_counter++;
-    const bool timed = s->opt_timing == 1 || (s->opt_timing == 2 && (n % s->timing_stride) == 0);     // (stride 1 when MGCFD_OPT_TIMING was set to 3)
+    bool timed = s->opt_timing == 1 || (s->opt_timing == 2 && (n % s->timing_stride) == 0);     // (stride 1 when MGCFD_OPT_TIMING was set to 3)
+    if (s->opt_timing == 4) {
+        // Per-loop times by ATTRIBUTION (src/Monitoring/timer.cpp:58-195 wants a time per loop; bracketing every loop means
+        // un-fusing every stage: 0.80 ms per cycle against 0.29).  Every Nth sweep of a level runs one launch per loop under
+        // events — flux, compute_step, time_step and the indirect_rw probe as the reference's -DTIME build brackets them —
+        // all others run fused and un-bracketed; mgcfd_get_loop_times apportions the batches' measured GPU time to the
+        // loops by the sampled sweeps' ratios.  Same results either way (the fused stages are the same operations).
+        const bool sampled = (lv.att_sweeps % s->timing_stride) == 0;
+        // (the indirect_rw probe — not part of the solution — runs in every fourth sampled sweep only; LoopNumIters books it per
+        //  stage, as the reference's loop structure has it, and its time is extrapolated at the measured rate)
+        const bool probe = sampled && s->opt_indirect_rw && (lv.att_sweeps_sampled % 4) == 0;
+        lv.att_sweeps++;
+        if (sampled) lv.att_sweeps_sampled++;
+        if (probe) lv.att_calls_sampled[MGCFD_LOOP_INDIRECT_RW]++;
+        const int keep_t = s->opt_timing, keep_p = s->opt_indirect_rw;
+        s->opt_timing = sampled ? 1 : 0;
+        // (... and there behind the first Runge-Kutta stage only: the three stages' probes move the same bytes)
+        if (keep_p) lv.iters[MGCFD_LOOP_INDIRECT_RW] += int64_t(probe ? MGCFD_RK - 1 : MGCFD_RK) * lv.info.n_internal;
+        if (!probe) s->opt_indirect_rw = 0;
+        s->probe_first_stage_only = true;
+        try { smooth_once(s, level); } catch (...) { s->opt_timing = keep_t; s->opt_indirect_rw = keep_p; s->probe_first_stage_only = false; throw; }
+        s->opt_timing = keep_t; s->opt_indirect_rw = keep_p; s->probe_first_stage_only = false;
+        return;
+    }
     // (only the fused launches are replayed: the unfused ones — the two-phase flux variant — leave host-side flags
     //  behind, fluxes_stale, that a replay would not set)
     const bool graphable = s->opt_graph && s->opt_fuse && !(s->variant_for(lv) & 4) && !s->opt_indirect_rw && !timed && lv.fluxes_zero && !lv.fluxes_stale;
@@ -1381,6 +1413,20 @@ static void cycle_once(mgcfd_solver *s, bool capturing)
     auto sweep = [&](int l) { if (capturing) smooth_once(s, l); else run_sweep(s, l); };
     SumTask rms_task;
     bool rms_pending = false;
+    // (MGCFD_OPT_TIMING = 4: every Nth restriction / prolongation of a level pair is bracketed with events, see run_sweep)
+    auto transfer = [&](bool restriction, int fine, const SumTask *task) {
+        const int keep = s->opt_timing;
+        if (keep == 4) {
+            DeviceLevel &book = s->L[static_cast<size_t>(restriction ? fine + 1 : fine)];     // (the reference books restrict on the coarse level)
+            const int loop = restriction ? MGCFD_LOOP_RESTRICT : MGCFD_LOOP_PROLONG;
+            const bool sampled = (book.att_calls[loop] % s->timing_stride) == 0;
+            book.att_calls[loop]++;
+            if (sampled) book.att_calls_sampled[loop]++;
+            s->opt_timing = sampled ? 1 : 0;
+        }
+        try { if (restriction) s->op_restrict(fine, task); else s->op_prolong(fine); } catch (...) { s->opt_timing = keep; throw; }
+        s->opt_timing = keep;
+    };
     for (int l = 0; l < n; l++) {
         if (l == 0) { s->L[0].want_sumsq = true; s->L[0].have_sumsq = false; }
         sweep(l);                                                          // :383-508
@@ -1401,10 +1447,10 @@ static void cycle_once(mgcfd_solver *s, bool capturing)
                 exact::launch_append_scalar(s->stream, l0.sumsq, s->rms_ring, s->rms_count, mgcfd_solver::kRmsRing);
             }
         }
-        if (l + 1 < n) { s->op_restrict(l, (l == 0 && rms_pending) ? &rms_task : nullptr); rms_pending = false; }   // :527-559
+        if (l + 1 < n) { transfer(true, l, (l == 0 && rms_pending) ? &rms_task : nullptr); rms_pending = false; }   // :527-559
     }
     for (int l = n - 2; l >= 0; l--) {
-        s->op_prolong(l);                                                  // :560-688
+        transfer(false, l, nullptr);                                       // :560-688
         if (l > 0) sweep(l);
     }
 }
@@ -1426,6 +1472,8 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
         for (int done = 0; done < cycles;) {
             const int chunk = std::min(cycles - done, mgcfd_solver::kRmsRing);
             HIP_CHECK(hipMemsetAsync(s->rms_count, 0, sizeof(int), s->stream));
+            hipEvent_t att0 = nullptr, att1 = nullptr;
+            if (s->opt_timing == 4) { att0 = s->get_event(); att1 = s->get_event(); HIP_CHECK(hipEventRecord(att0, s->stream)); }
             bool graphable = s->opt_graph && s->opt_fuse && !s->opt_indirect_rw && s->opt_timing == 0;
             for (auto &lv : s->L) graphable = graphable && lv.fluxes_zero && !lv.fluxes_stale && !(s->variant_for(lv) & 4);
             graphable = graphable && nl <= 8;               // the graph key holds 8 levels' buffer rotations
@@ -1497,11 +1545,18 @@ int mgcfd_run_cycles(mgcfd_solver *s, int cycles, double *rms_out)
                     if (c == 0) seq_per_cycle = s->check_seq - seq_before;
                 }
             }
+            if (att1) HIP_CHECK(hipEventRecord(att1, s->stream));
             const size_t at = sums.size();
             sums.resize(at + static_cast<size_t>(chunk));
             HIP_CHECK(hipMemcpyAsync(sums.data() + at, s->rms_ring, sizeof(double) * chunk, hipMemcpyDeviceToHost, s->stream));
             int seq = 0;
             code = s->read_error(nullptr, &seq);                           // synchronises
+            if (att1) {
+                float ms = 0.f;
+                HIP_CHECK(hipEventElapsedTime(&ms, att0, att1));
+                s->att_total += double(ms) * 1e-3;
+                s->free_events.push_back(att0); s->free_events.push_back(att1);
+            }
             if (code != MGCFD_OK) {
                 // the reference exits inside the failing time_step: stop here, and say in which cycle it was when
                 // the launches were numbered one by one (a replayed graph repeats its numbers)
@@ -1693,6 +1748,26 @@ int mgcfd_get_loop_times(mgcfd_solver *s, int level, double out[MGCFD_NUM_LOOPS]
         s->use_device();
         s->fold_events();
         std::memcpy(out, s->level(level).times, sizeof(double) * MGCFD_NUM_LOOPS);
+        if (s->opt_timing != 4 || s->att_total <= 0.0) return;
+        // attribution (see run_sweep): what the un-bracketed launches of every level and loop would have taken at the sampled
+        // rate, scaled so that everything adds up to the GPU time the cycle batches really took
+        auto estimate = [&](const DeviceLevel &lv, int k) {
+            if (k == MGCFD_LOOP_RESTRICT || k == MGCFD_LOOP_PROLONG)
+                return lv.att_calls_sampled[k] > 0 ? lv.times[k] / double(lv.att_calls_sampled[k]) * double(lv.att_calls[k] - lv.att_calls_sampled[k]) : 0.0;
+            if (k == MGCFD_LOOP_INDIRECT_RW) return 0.0;        // (the probe does not run in the fused sweeps: none of their time is its)
+            return lv.att_sweeps_sampled > 0 ? lv.times[k] / double(lv.att_sweeps_sampled) * double(lv.att_sweeps - lv.att_sweeps_sampled) : 0.0;
+        };
+        double measured = 0.0, estimated = 0.0;
+        for (const DeviceLevel &lv : s->L)
+            for (int k = 0; k < MGCFD_NUM_LOOPS; k++) { measured += lv.times[k]; estimated += estimate(lv, k); }
+        const double rest = std::max(0.0, s->att_total - measured);
+        const double scale = estimated > 0.0 ? rest / estimated : 0.0;
+        const DeviceLevel &lv = s->level(level);
+        for (int k = 0; k < MGCFD_NUM_LOOPS; k++) out[k] = lv.times[k] + scale * estimate(lv, k);
+        // indirect_rw: the measured probes' rate applied to every sweep LoopNumIters books (a rate column: iterations / time
+        // stays the probe's measured rate; this time is NOT part of the batches' total)
+        if (lv.att_calls_sampled[MGCFD_LOOP_INDIRECT_RW] > 0)
+            out[MGCFD_LOOP_INDIRECT_RW] = lv.times[MGCFD_LOOP_INDIRECT_RW] / double(lv.att_calls_sampled[MGCFD_LOOP_INDIRECT_RW]) * double(MGCFD_RK) * double(lv.att_sweeps);
     });
 }
 int mgcfd_reset_monitoring(mgcfd_solver *s)
@@ -1706,7 +1781,11 @@ int mgcfd_reset_monitoring(mgcfd_solver *s)
             std::memset(lv.times, 0, sizeof(lv.times));
             lv.flux_time = 0.0;
             lv.flux_launches = 0;
+            lv.att_sweeps = lv.att_sweeps_sampled = 0;
+            std::memset(lv.att_calls, 0, sizeof(lv.att_calls));
+            std::memset(lv.att_calls_sampled, 0, sizeof(lv.att_calls_sampled));
         }
+        s->att_total = 0.0;
     });
 }
 int mgcfd_get_flux_kernel_time(mgcfd_solver *s, int level, double *avg_seconds, int64_t *launches)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The drop-in binary end to end at BASELINE size: write the 4-level M6-like hierarchy in the reference's file
-formats, run euler3d_gpu_double on it (default = per-loop timers as the reference's -DTIME build, and --no-timers),
+formats, run euler3d_gpu_double on it (default = fused stages with the per-loop times attributed, --loop-timers = every
+loop bracketed as the reference's -DTIME build does, and --no-timers),
 print its own 'Total runtime' line and the wall time of the whole process (file parsing and plan building included)."""
 import os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +13,7 @@ t0 = time.time()
 mg = meshgen.make_multigrid((67, 55, 48, 43), "m6wing", seed=0, jitter=0.2, area_noise=0.02, volume_noise=0.02)
 meshgen.write_input(mg, d)
 print(f"generated + wrote the input files in {time.time() - t0:.1f} s ({sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)) / 1e6:.0f} MB)")
-for extra in ([], ["--no-timers"]):
+for extra in ([], ["--loop-timers"], ["--no-timers"]):
     t0 = time.time()
     r = subprocess.run([exe, "-i", "input.dat", "-d", d, "-o", d + "/", "-g", "25"] + extra, capture_output=True, text=True)
     wall = time.time() - t0
@@ -20,3 +21,8 @@ for extra in ([], ["--no-timers"]):
     print(" ".join(["euler3d_gpu_double -g 25"] + extra), "-> rc", r.returncode, f"process wall {wall:.2f} s;", lines[-1] if lines else r.stdout[-200:], "|", (lines[-2] if len(lines) > 1 else ""))
     if r.returncode != 0:
         print(r.stdout[-500:], r.stderr[-500:])
+    elif extra != ["--no-timers"]:
+        rows = [l.rstrip(",\n").split(",") for l in open(os.path.join(d, "Times.csv")) if l.strip()]
+        t = dict(zip(rows[0], rows[1]))
+        print("   Times.csv:", " ".join(f"{k}={float(v) * 1e3:.3f}ms" for k, v in t.items() if k[:-1] in ("flux", "compute_step", "time_step", "restrict", "prolong", "indirect_rw") and float(v) > 0),
+              f"| Total={float(t['Total']) * 1e3:.3f}ms = {float(t['Total']) / 25 * 1e3:.4f} ms per cycle | Flux options: {t['Flux options']!r}")

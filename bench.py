@@ -63,6 +63,7 @@ HBM_COPY_GBS = 6290.0        # ... and what a device-to-device copy measures the
 LATTICE = 67                 # 67^3 = 300,763 nodes, 888,822 internal edges
 LATTICE_8X = 134             # the level tiled 8x (connected): 2,406,104 nodes / 7,164,444 internal edges
 HIERARCHY = (67, 55, 48, 43) # 300,763 / 166,375 / 110,592 / 79,507 nodes
+HIERARCHY_8X = (134, 110, 96, 86)   # the same hierarchy tiled 8x (connected): 2,406,104 / 1,331,000 / 884,736 / 636,056 nodes
 TRAFFIC_PROFILE = os.path.join("profiles", "r2_traffic.json")
 ROOFLINE_LAUNCHES = 1000     # back-to-back launches of the standalone flux kernel / of its data-movement probe per measurement
 
@@ -74,9 +75,9 @@ def build_workload(lattice: int, seed: int = 0):
     return mg, generated_to_levels(mg)
 
 
-def build_hierarchy():
+def build_hierarchy(sizes=HIERARCHY):
     from mgcfd import meshgen, generated_to_levels
-    mg = meshgen.make_multigrid(HIERARCHY, "m6wing", seed=0, jitter=0.2, area_noise=0.02, volume_noise=0.02)
+    mg = meshgen.make_multigrid(sizes, "m6wing", seed=0, jitter=0.2, area_noise=0.02, volume_noise=0.02)
     return mg, generated_to_levels(mg)
 
 
@@ -196,6 +197,116 @@ def vcycle_wall(fast: bool, cycles: int = 25, device: int = 0):
     return out
 
 
+def vcycle_partitioned(args, dist, world, rank, dev, stream, rehearsal, sizes, cycles=25):
+    """The V-cycle half of BASELINE's metric on N GPUs: the 4-level hierarchy (tiled 8x by default: per-rank work as on one GPU)
+    with EVERY level partitioned over the ranks (mgcfd.partition.partition_hierarchy, level 0 by recursive coordinate bisection),
+    the whole cycle swept inside the library (mgcfd_rank_cycles: the partitioned sweeps of `partitioned` on every level, halo
+    messages of the coarse `variables` after mg_restrict, of the coarse `residuals` before the prolongation and of the fine
+    `variables` after it, over RCCL send / receive).  Before it is timed it must reproduce, on every rank and bit for bit, two
+    cycles of the torch.distributed orchestration (mgcfd.distributed.PartitionedCycle) from the same state; otherwise — and in the
+    one-GPU rehearsal, where RCCL cannot form a communicator — the torch path is what is timed, and the line says so."""
+    import torch
+    import mgcfd
+    from mgcfd.distributed import HipSolverAdapter, PartitionedCycle
+    from mgcfd.partition import partition_hierarchy, rcb_partition
+    t0 = time.perf_counter()
+    mg, levels = build_hierarchy(sizes)
+    H = partition_hierarchy(levels, rcb_partition(np.asarray(levels[0]["coords"]), world))[rank]
+    lv, owned, keys = H.solver_args()
+    nels, n_ints = [int(L["nel"]) for L in levels], [int(L["n_internal"]) for L in levels]
+    del levels
+    s = mgcfd.Solver.from_arrays(lv, mg.mesh_variant, device=dev.index, n_owned=owned, order_keys=keys)
+    s.set_stream(stream.cuda_stream)
+    s.set_option("exact", 0 if args.fast else 1)
+    setup_s = time.perf_counter() - t0
+    nlev = len(lv)
+    ff = s.far_field()[:5]
+    cyc = PartitionedCycle(HipSolverAdapter(s, dev), H, dist, make_buffer=lambda n: torch.empty(max(n, 1), dtype=torch.float64, device=dev), fused=True)
+    notes = []
+    use_library = False
+
+    def reset(exchange):
+        torch.cuda.synchronize(); dist.barrier()
+        for l in range(nlev):
+            s.set(l, "variables", np.tile(ff, (int(lv[l]["nel"]), 1)))
+        for l in range(nlev):
+            exchange(l)
+
+    def agree(ok):
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item()) == 1.0
+
+    torch_exchange = lambda l: cyc.exchange(l, "variables")
+    if rehearsal:
+        notes.append("rehearsal on one GPU: RCCL cannot form a communicator there, the torch.distributed orchestration is timed")
+    else:
+        err = None
+        uid = [None]
+        try:
+            uid = [mgcfd.rccl_unique_id() if rank == 0 else None]
+        except Exception as e:
+            err = e
+        dist.broadcast_object_list(uid, src=0)
+        try:
+            if err:
+                raise err
+            s.rank_attach_rccl(rank, world, uid[0])
+            for l in range(nlev):
+                s.rank_set_halo(l, H.levels[l])
+        except Exception as e:
+            err = e
+        if not agree(err is None):
+            notes.append(f"the library's cycle loop not used: {err or 'its set-up failed on another rank'}")
+        else:
+            # two cycles of each form from the far field: level 0's owned nodes and ghosts must be the same bits
+            reset(torch_exchange)
+            for _ in range(2):
+                cyc.cycle()
+            torch.cuda.synchronize()
+            want = [s.get(l, "variables") for l in range(nlev)]
+            reset(lambda l: s.rank_exchange(l))
+            err = None
+            try:
+                s.rank_cycles(2, rms=False)
+                same = all(np.array_equal(s.get(l, "variables").view(np.int64), want[l].view(np.int64)) for l in range(nlev))
+            except Exception as e:
+                err, same = e, False
+            use_library = agree(same)
+            if not use_library:
+                notes.append(f"mgcfd_rank_cycles not used: {err or 'its two cycles differ from the torch orchestration on some rank'}")
+    step = (lambda n: s.rank_cycles(n, rms=False)) if use_library else (lambda n: [cyc.cycle() for _ in range(n)])
+    reset((lambda l: s.rank_exchange(l)) if use_library else torch_exchange)
+    step(cycles)                                            # (untimed: clocks up, every buffer and graph in place)
+    best = float("inf")
+    for _ in range(3):
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        step(cycles)
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        best = min(best, float(t.item()))
+    rc, bad = s.check_for_invalid_variables(0)
+    edge_iters = 3 * (n_ints[0] + n_ints[-1] + 2 * sum(n_ints[1:-1]))
+    out = {"workload": f"4-level M6-like synthetic hierarchy {nels} nodes, every level partitioned over {world} ranks (level 0 by recursive coordinate "
+                       f"bisection, a coarse node with its first child), {cycles} cycles, best of 3 after {cycles} untimed",
+           "wall_s_per_cycle": round(best / cycles, 9), "flux_edge_iterations_per_cycle": edge_iters,
+           "medges_per_s_whole_cycle": round(edge_iters * cycles / best / 1e6, 1),
+           "form": ("libmgcfd_hip (mgcfd_rank_cycles): the cycle's state machine and every exchange inside the library over RCCL; two cycles checked against the "
+                    "torch.distributed orchestration bit for bit on every rank before timing") if use_library else
+                   "torch.distributed orchestration from Python (mgcfd.distributed.PartitionedCycle): fused stage launches, pack / batch_isend_irecv / unpack per peer",
+           "owned_nodes_rank0": [int(v) for v in owned], "local_nodes_rank0": [int(L["nel"]) for L in lv],
+           "state_valid": rc == 0, "setup_s_rank0": round(setup_s, 1), "notes": notes}
+    try:
+        if use_library:
+            s.rank_detach()
+    except Exception:
+        pass
+    s.close()
+    return out
+
+
 # --------------------------------------------------------------------------------------------------------------
 # process plumbing
 # --------------------------------------------------------------------------------------------------------------
@@ -256,7 +367,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)        # 0.13 s of GPU time: past the clock ramp of the first ms
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="auto", choices=["auto", "level0", "partitioned", "copies", "level-per-gpu"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "level0", "partitioned", "partitioned-mg", "copies", "level-per-gpu"])
+    ap.add_argument("--vcycle-hierarchy", default="8x", choices=["8x", "base", "tiny"],
+                    help="N > 1: the hierarchy of the V-cycle leg — the 4-level hierarchy tiled 8x (per-rank work as on one GPU), the "
+                         "one-GPU hierarchy itself (strong scaling of a 0.3 ms cycle), or a (20, 12, 8, 6)^3 one for functional rehearsals")
     ap.add_argument("--lattice", type=int, default=0, help="nodes per side of the synthetic level (default 67; 134 for `partitioned`)")
     ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
     ap.add_argument("--variant", type=int, default=-1, help="MGCFD_OPT_FLUX_VARIANT (see include/mgcfd.h)")
@@ -296,6 +410,9 @@ def main():
         workload = "level0" if world == 1 else "partitioned"
     if workload == "copies" and world == 1:
         workload = "level0"
+    if workload == "partitioned-mg":
+        # (the sweep leg is `partitioned`'s; the V-cycle leg on the partitioned hierarchy follows it for every N > 1 anyway)
+        workload = "partitioned" if world > 1 else "level0"
     lattice = args.lattice or (LATTICE_8X if workload == "partitioned" else LATTICE)
     # rehearsal of the N > 1 code path on a one-GPU box (not a measurement): every rank on device 0, collectives over gloo
     rehearsal = os.environ.get("MGCFD_BENCH_REHEARSAL") == "1"
@@ -746,6 +863,12 @@ def main():
     solver.close()
     if world > 1:
         dist.barrier()
+    if world > 1 and workload in ("partitioned", "partitioned-mg") and not args.no_vcycle:
+        # the second half of BASELINE's metric on N GPUs: every level of the hierarchy partitioned, the cycle inside the library
+        vc = vcycle_partitioned(args, dist, world, rank, dev, stream, rehearsal, {"8x": HIERARCHY_8X, "base": HIERARCHY, "tiny": (20, 12, 8, 6)}[args.vcycle_hierarchy])
+        if rank == 0:
+            out["vcycle"] = vc
+            out["metric"] = "Medges/s (compute_flux_edge) + MG V-cycle wall-s"
     if rank == 0:
         if world == 1 and workload == "level0" and not args.no_vcycle:
             out["vcycle"] = vcycle_wall(args.fast, device=local_rank)

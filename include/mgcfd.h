@@ -430,6 +430,17 @@ int mgcfd_group_sweeps(mgcfd_group *g, int level, int sweeps);   /* asynchronous
  * sweep k.  At most 4096 sweeps per call.  Synchronises. */
 int mgcfd_group_sweeps_rms(mgcfd_group *g, int level, int sweeps, double *rms_of_each);
 int mgcfd_group_rms(mgcfd_group *g, int level, double *rms);
+/* V-cycles on a PARTITIONED HIERARCHY (mgcfd_create_partitioned_mg; mgcfd_rank_set_halo on EVERY level, ghosts current:
+ * mgcfd_group_exchange / mgcfd_rank_exchange on every level once): the reference's cycle — sweeps on levels 0 .. n-1, n-2 .. 1,
+ * mg_restrict on the way up, prolong_residuals_interpolate_proper on the way down, src/euler3d_cpu_double.cpp:371-694 — with
+ * the ghost values moved where the next loop reads them: `variables` after every time_step (one message per Runge-Kutta stage,
+ * as in mgcfd_group_sweeps), after mg_restrict (coarse ghosts) and after the prolongation (fine ghosts), the coarse `residuals`
+ * before the prolongation; one all-reduce(MIN) of the time step per sweep.  Every level equals mgcfd_run_cycles on the whole
+ * hierarchy bit for bit on owned nodes.  rms_out (may be NULL): the level-0 RMS after the level-0 sweep of each cycle, as the
+ * reference prints it.  Returns MGCFD_OK or MGCFD_ERR_NAN / NEG_* (check_for_invalid_variables inside every time_step).
+ * At most 4096 cycles per call.  Synchronises. */
+int mgcfd_group_cycles(mgcfd_group *g, int cycles, double *rms_out);
+int mgcfd_rank_cycles(mgcfd_solver *s, int cycles, double *rms_out);      /* one rank per process over RCCL (mgcfd_rank_attach_rccl) */
 int mgcfd_group_synchronize(mgcfd_group *g);
 
 #ifdef __cplusplus

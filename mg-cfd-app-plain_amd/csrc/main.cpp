@@ -42,6 +42,7 @@ struct Config {                       // the reference's `config` (src/Base/conf
     int device = 0;
     int gpus = 1;                     // --gpus N: a single-level input partitioned over N GPUs, a multigrid input one level per GPU
     bool gpus_share_device = false;   // --gpus-share-device: all N ranks on --device (rehearsal on a one-GPU box)
+    bool gpus_partition = false;      // --gpus-partition: split every level of a multigrid input over the N GPUs (the default when N > levels)
 };
 
 std::string trim(const std::string &s)
@@ -121,6 +122,8 @@ void print_help()
         "                                   (halo messages after every Runge-Kutta stage), a multigrid input runs one\n"
         "                                   level per GPU; fused path (as --no-timers)\n"
         "  --gpus-share-device              With --gpus: every rank on the one device (functional rehearsal)\n"
+        "  --gpus-partition                 With --gpus on a multigrid input: split EVERY level over the N GPUs and run the\n"
+        "                                   whole V-cycle inside the library (the default when N exceeds the number of levels)\n"
         "  --no-timers                      One fused launch per Runge-Kutta stage; no per-loop times\n"
         "  --loop-timers                    Every loop its own launch between two events (2.7x slower cycles); default: fused\n"
         "                                   stages, per-loop times attributed from every 32nd sweep, which runs per loop\n"
@@ -155,6 +158,7 @@ bool parse_arguments(int argc, char **argv, Config &c)
         {"gpus", required_argument, nullptr, 1009},
         {"gpus-share-device", no_argument, nullptr, 1010},
         {"loop-timers", no_argument, nullptr, 1011},
+        {"gpus-partition", no_argument, nullptr, 1012},
         {nullptr, 0, nullptr, 0}};
     int optc;
     while ((optc = getopt_long(argc, argv, "hc:i:d:p:o:m:g:v", long_opts, nullptr)) != -1) {
@@ -179,6 +183,7 @@ bool parse_arguments(int argc, char **argv, Config &c)
             case 1009: c.gpus = std::atoi(optarg); break;
             case 1010: c.gpus_share_device = true; break;
             case 1011: c.loop_timers = true; break;
+            case 1012: c.gpus_partition = true; break;
             default: std::printf("Unknown command line parameter '%c'\n", optc);
         }
     }
@@ -338,9 +343,11 @@ int run_on_several_gpus(const Config &conf, mgcfd_mesh *mesh, int levels, int me
     try {
         multi_gpu::Options o;
         o.gpus = conf.gpus; o.first_device = conf.device; o.share_device = conf.gpus_share_device; o.fast_math = conf.fast_math;
+        o.partition_levels = conf.gpus_partition;
         const auto tb = std::chrono::steady_clock::now();
         multi_gpu::Run run(mesh, o);
         std::fprintf(stderr, "[euler3d_gpu_double] %d ranks (%s), set up in %.2f s\n", run.ranks(),
+                     run.partitioned_hierarchy() ? "every level partitioned, level 0 by recursive coordinate bisection; the V-cycle inside the library" :
                      run.partitioned() ? "level 0 partitioned by recursive coordinate bisection" : "one multigrid level per GPU",
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count());
         std::vector<double> rms(static_cast<size_t>(conf.num_cycles > 0 ? conf.num_cycles : 0));

@@ -6,9 +6,14 @@
 //                        the sweep loop runs inside the library (mgcfd_group_sweeps: one all-reduce(MIN) of the time step
 //                        per sweep, a halo message per neighbour after every Runge-Kutta stage, hidden under the
 //                        interior tiles).  Owned nodes equal the one-GPU run bit for bit.
-//   multigrid input      level l lives on GPU l % N (BASELINE configs[3]); the restricted variables go up and the coarse
-//                        residuals come down as whole-array device-to-device copies (hipMemcpyPeerAsync over xGMI).
+//   multigrid input      N <= levels: level l lives on GPU l % N (BASELINE configs[3]); the restricted variables go up and the
+//                        coarse residuals come down as whole-array device-to-device copies (hipMemcpyPeerAsync over xGMI).
 //                        The V-cycle is sequential in levels: this is placement, not concurrency.
+//                        N > levels (or --gpus-partition): EVERY level is split over the N GPUs — level 0 by recursive
+//                        coordinate bisection, a coarse node with its first child — and the whole V-cycle runs inside the
+//                        library (mgcfd_group_cycles): the partitioned sweeps on every level, halo messages of the coarse
+//                        variables after mg_restrict, of the coarse residuals before the prolongation and of the fine
+//                        variables after it.  Every level equals the one-GPU run bit for bit on owned nodes.
 //
 // The reference has no multi-device path; its cycle loop (src/euler3d_cpu_double.cpp:371-694) fixes what has to move.
 #include "multi_gpu.hpp"
@@ -34,6 +39,7 @@ struct Part {
     std::vector<mgcfd_edge> edges;                    // internal | boundary | wall, the whole mesh's relative order kept
     int64_t ni = 0, nb = 0, nw = 0;
     std::map<int, std::vector<int64_t>> send, recv;   // peer -> local ids (ascending global id on both sides)
+    std::vector<int64_t> mg_map;                      // partitioned hierarchy: LOCAL coarse id of every local node's parent
 };
 
 // recursive coordinate bisection: split along the longest axis of the bounding box into halves whose sizes are
@@ -105,6 +111,118 @@ std::vector<Part> partition_level(const mgcfd_level_desc &L, const std::vector<i
     return parts;
 }
 
+// Every level of a hierarchy split over n_parts ranks (the C++ twin of mgcfd/partition.py: partition_hierarchy).  Level 0
+// follows part0; a coarse node goes to the rank that owns its first child (a childless one to rank 0).  Besides the flux
+// ghosts a rank holds, per level, what the transfers need: the children of its owned coarse nodes (mg_restrict computes a
+// coarse node where it is owned, src/Kernels/mg_loops.cpp:30-202) and the parent of every local fine node (the prolongation
+// reads the parents of a node's neighbours, mg_loops.cpp:678-864; the local map must be total).  Local edge lists keep the
+// whole mesh's order, and a coarse node's children are summed by GLOBAL id (the gids go to the library as order keys).
+// out[rank][level].
+std::vector<std::vector<Part>> partition_hierarchy(const std::vector<mgcfd_level_desc> &L, const std::vector<int> &part0, int n_parts)
+{
+    const int n = static_cast<int>(L.size());
+    std::vector<std::vector<int>> owner(static_cast<size_t>(n));
+    owner[0] = part0;
+    for (int l = 0; l + 1 < n; l++) {
+        const int64_t nc = L[static_cast<size_t>(l) + 1].nel;
+        std::vector<int> o(static_cast<size_t>(nc), -1);
+        for (int64_t i = 0; i < L[static_cast<size_t>(l)].mgc; i++) {
+            const int64_t c = L[static_cast<size_t>(l)].mg_map[i];
+            if (o[static_cast<size_t>(c)] < 0) o[static_cast<size_t>(c)] = owner[static_cast<size_t>(l)][static_cast<size_t>(i)];   // (ascending i: the first child)
+        }
+        for (int &v : o) if (v < 0) v = 0;
+        owner[static_cast<size_t>(l) + 1] = std::move(o);
+    }
+    std::vector<std::vector<Part>> out(static_cast<size_t>(n_parts), std::vector<Part>(static_cast<size_t>(n)));
+    for (int r = 0; r < n_parts; r++) {
+        std::vector<std::vector<char>> local(static_cast<size_t>(n));
+        for (int l = 0; l < n; l++) {
+            const mgcfd_level_desc &D = L[static_cast<size_t>(l)];
+            const std::vector<int> &own = owner[static_cast<size_t>(l)];
+            std::vector<char> &in = local[static_cast<size_t>(l)];
+            in.assign(static_cast<size_t>(D.nel), 0);
+            for (int64_t i = 0; i < D.nel; i++) if (own[static_cast<size_t>(i)] == r) in[static_cast<size_t>(i)] = 1;
+            for (int64_t e = D.internal_start; e < D.internal_start + D.n_internal; e++) {
+                const int64_t a = D.edges[e].a, b = D.edges[e].b;
+                if (own[static_cast<size_t>(a)] == r || own[static_cast<size_t>(b)] == r) in[static_cast<size_t>(a)] = in[static_cast<size_t>(b)] = 1;
+            }
+            if (l + 1 < n)                             // the children of the coarse nodes this rank owns
+                for (int64_t i = 0; i < D.mgc; i++) if (owner[static_cast<size_t>(l) + 1][static_cast<size_t>(D.mg_map[i])] == r) in[static_cast<size_t>(i)] = 1;
+            if (l > 0) {                               // the parent of every local node of the finer level
+                const mgcfd_level_desc &F = L[static_cast<size_t>(l) - 1];
+                const std::vector<char> &fin = local[static_cast<size_t>(l) - 1];
+                for (int64_t i = 0; i < F.mgc; i++) if (fin[static_cast<size_t>(i)]) in[static_cast<size_t>(F.mg_map[i])] = 1;
+            }
+        }
+        std::vector<std::vector<int64_t>> to_local(static_cast<size_t>(n));
+        for (int l = 0; l < n; l++) {
+            const mgcfd_level_desc &D = L[static_cast<size_t>(l)];
+            const std::vector<int> &own = owner[static_cast<size_t>(l)];
+            Part &P = out[static_cast<size_t>(r)][static_cast<size_t>(l)];
+            for (int64_t i = 0; i < D.nel; i++) if (own[static_cast<size_t>(i)] == r) P.gids.push_back(i);
+            P.n_owned = static_cast<int64_t>(P.gids.size());
+            for (int64_t i = 0; i < D.nel; i++) if (local[static_cast<size_t>(l)][static_cast<size_t>(i)] && own[static_cast<size_t>(i)] != r) P.gids.push_back(i);
+            std::vector<int64_t> &loc = to_local[static_cast<size_t>(l)];
+            loc.assign(static_cast<size_t>(D.nel), int64_t(-1));
+            for (size_t k = 0; k < P.gids.size(); k++) loc[static_cast<size_t>(P.gids[k])] = static_cast<int64_t>(k);
+            for (int64_t g : P.gids) {
+                P.volumes.push_back(D.volumes[g]);
+                if (D.coords) for (int d = 0; d < 3; d++) P.coords.push_back(D.coords[3 * g + d]);
+            }
+            for (int64_t e = D.internal_start; e < D.internal_start + D.n_internal; e++)
+                if (own[static_cast<size_t>(D.edges[e].a)] == r || own[static_cast<size_t>(D.edges[e].b)] == r) {
+                    mgcfd_edge x = D.edges[e];
+                    x.a = loc[static_cast<size_t>(x.a)]; x.b = loc[static_cast<size_t>(x.b)];
+                    P.edges.push_back(x); P.ni++;
+                }
+            for (int64_t e = D.boundary_start; e < D.boundary_start + D.n_boundary; e++)
+                if (own[static_cast<size_t>(D.edges[e].b)] == r) { mgcfd_edge x = D.edges[e]; x.b = loc[static_cast<size_t>(x.b)]; P.edges.push_back(x); P.nb++; }
+            for (int64_t e = D.wall_start; e < D.wall_start + D.n_wall; e++)
+                if (own[static_cast<size_t>(D.edges[e].b)] == r) { mgcfd_edge x = D.edges[e]; x.b = loc[static_cast<size_t>(x.b)]; P.edges.push_back(x); P.nw++; }
+            for (size_t k = static_cast<size_t>(P.n_owned); k < P.gids.size(); k++) P.recv[own[static_cast<size_t>(P.gids[k])]].push_back(static_cast<int64_t>(k));
+        }
+        for (int l = 0; l + 1 < n; l++) {
+            Part &P = out[static_cast<size_t>(r)][static_cast<size_t>(l)];
+            for (int64_t g : P.gids) {
+                const int64_t c = to_local[static_cast<size_t>(l) + 1][static_cast<size_t>(L[static_cast<size_t>(l)].mg_map[g])];
+                if (c < 0) throw std::logic_error("partition_hierarchy: a local node's parent is not local");
+                P.mg_map.push_back(c);
+            }
+        }
+    }
+    for (int l = 0; l < n; l++)
+        for (int r = 0; r < n_parts; r++)
+            for (auto &kv : out[static_cast<size_t>(r)][static_cast<size_t>(l)].recv) {
+                Part &Q = out[static_cast<size_t>(kv.first)][static_cast<size_t>(l)];
+                std::vector<int64_t> &snd = Q.send[r];
+                for (int64_t lg : kv.second) {
+                    const int64_t g = out[static_cast<size_t>(r)][static_cast<size_t>(l)].gids[static_cast<size_t>(lg)];
+                    const auto it = std::lower_bound(Q.gids.begin(), Q.gids.begin() + Q.n_owned, g);
+                    if (it == Q.gids.begin() + Q.n_owned || *it != g) throw std::logic_error("partition_hierarchy: a ghost's owner does not own it");
+                    snd.push_back(static_cast<int64_t>(it - Q.gids.begin()));
+                }
+            }
+    return out;
+}
+
+void set_halo(mgcfd_solver *s, int level, Part &P)
+{
+    std::vector<int> peers;
+    for (auto &kv : P.send) peers.push_back(kv.first);
+    for (auto &kv : P.recv) if (!P.send.count(kv.first)) peers.push_back(kv.first);
+    std::sort(peers.begin(), peers.end());
+    std::vector<int64_t> sc, rc;
+    std::vector<const int64_t *> sp, rp;
+    static const int64_t none = 0;
+    for (int q : peers) {
+        const auto &sv = P.send[q], &rv = P.recv[q];
+        sc.push_back(static_cast<int64_t>(sv.size())); rc.push_back(static_cast<int64_t>(rv.size()));
+        sp.push_back(sv.empty() ? &none : sv.data()); rp.push_back(rv.empty() ? &none : rv.data());
+    }
+    if (mgcfd_rank_set_halo(s, level, static_cast<int>(peers.size()), peers.data(), sc.data(), sp.data(), rc.data(), rp.data()) != MGCFD_OK)
+        throw std::runtime_error(std::string("setting a rank's halo lists: ") + mgcfd_last_error());
+}
+
 void check(int rc, const char *what)
 {
     if (rc != MGCFD_OK) throw std::runtime_error(std::string(what) + ": " + mgcfd_last_error());
@@ -118,6 +236,8 @@ struct Run::Impl {
     Options opt;
     int levels = 0, mesh_variant = 0;
     bool partitioned = false;
+    bool partitioned_mg = false;                      // every level of a multigrid input split over the ranks (mgcfd_group_cycles)
+    std::vector<std::vector<Part>> hparts;            // ... its parts, [rank][level] (parts = the level-0 parts then)
     std::vector<mgcfd_solver *> solvers;
     mgcfd_group *group = nullptr;
     std::vector<Part> parts;
@@ -145,7 +265,50 @@ Run::Run(const mgcfd_mesh *mesh, const Options &opt) : p(new Impl)
     }
     p->nel0 = p->nel[0];
     p->partitioned = p->levels == 1;
-    if (p->partitioned) {
+    p->partitioned_mg = p->levels > 1 && opt.gpus > 1 && (opt.gpus > p->levels || opt.partition_levels);
+    if (p->partitioned_mg) {
+        std::vector<mgcfd_level_desc> L(static_cast<size_t>(p->levels));
+        for (int l = 0; l < p->levels; l++) check(mgcfd_mesh_level(mesh, l, &L[static_cast<size_t>(l)]), "reading a level");
+        std::vector<int> part(static_cast<size_t>(L[0].nel), 0);
+        if (L[0].coords) {
+            std::vector<int64_t> ids(static_cast<size_t>(L[0].nel));
+            std::iota(ids.begin(), ids.end(), int64_t(0));
+            rcb(L[0].coords, ids, 0, L[0].nel, 0, opt.gpus, part);
+        } else {
+            for (int64_t i = 0; i < L[0].nel; i++) part[static_cast<size_t>(i)] = static_cast<int>((i * opt.gpus) / L[0].nel);
+        }
+        p->hparts = partition_hierarchy(L, part, opt.gpus);
+        for (int r = 0; r < opt.gpus; r++) {
+            std::vector<Part> &H = p->hparts[static_cast<size_t>(r)];
+            std::vector<mgcfd_level_desc> d(static_cast<size_t>(p->levels));
+            std::vector<int64_t> owned;
+            std::vector<const int64_t *> keys;
+            for (int l = 0; l < p->levels; l++) {
+                Part &P = H[static_cast<size_t>(l)];
+                mgcfd_level_desc &x = d[static_cast<size_t>(l)];
+                x = mgcfd_level_desc{};
+                x.nel = static_cast<int64_t>(P.gids.size());
+                x.n_edges = static_cast<int64_t>(P.edges.size());
+                x.n_internal = P.ni; x.n_boundary = P.nb; x.n_wall = P.nw;
+                x.internal_start = 0; x.boundary_start = P.ni; x.wall_start = P.ni + P.nb;
+                x.volumes = P.volumes.data();
+                x.coords = P.coords.empty() ? nullptr : P.coords.data();
+                x.edges = P.edges.data();
+                x.mg_map = l + 1 < p->levels ? P.mg_map.data() : nullptr;
+                x.mgc = l + 1 < p->levels ? static_cast<int64_t>(P.mg_map.size()) : 0;
+                owned.push_back(P.n_owned);
+                keys.push_back(P.gids.data());
+            }
+            mgcfd_solver *s = nullptr;
+            check(mgcfd_create_partitioned_mg(d.data(), p->levels, p->mesh_variant, device_of_rank(opt, r), owned.data(), keys.data(), &s), "creating a rank's solver");
+            p->solvers.push_back(s);
+            p->parts.push_back(H[0]);                            // (get_level0 / check_invalid gather level 0 through these)
+        }
+        check(mgcfd_group_create(opt.gpus, p->solvers.data(), &p->group), "forming the group");
+        for (int r = 0; r < opt.gpus; r++)
+            for (int l = 0; l < p->levels; l++) set_halo(p->solvers[static_cast<size_t>(r)], l, p->hparts[static_cast<size_t>(r)][static_cast<size_t>(l)]);
+        for (int l = 0; l < p->levels; l++) check(mgcfd_group_exchange(p->group, l), "the first halo exchange");
+    } else if (p->partitioned) {
         mgcfd_level_desc L;
         check(mgcfd_mesh_level(mesh, 0, &L), "reading level 0");
         std::vector<int> part(static_cast<size_t>(L.nel), 0);
@@ -174,23 +337,7 @@ Run::Run(const mgcfd_mesh *mesh, const Options &opt) : p(new Impl)
             p->solvers.push_back(s);
         }
         check(mgcfd_group_create(opt.gpus, p->solvers.data(), &p->group), "forming the group");
-        for (int r = 0; r < opt.gpus; r++) {
-            Part &P = p->parts[static_cast<size_t>(r)];
-            std::vector<int> peers;
-            for (auto &kv : P.send) peers.push_back(kv.first);
-            for (auto &kv : P.recv) if (!P.send.count(kv.first)) peers.push_back(kv.first);
-            std::sort(peers.begin(), peers.end());
-            std::vector<int64_t> sc, rc;
-            std::vector<const int64_t *> sp, rp;
-            static const int64_t none = 0;
-            for (int q : peers) {
-                const auto &sv = P.send[q], &rv = P.recv[q];
-                sc.push_back(static_cast<int64_t>(sv.size())); rc.push_back(static_cast<int64_t>(rv.size()));
-                sp.push_back(sv.empty() ? &none : sv.data()); rp.push_back(rv.empty() ? &none : rv.data());
-            }
-            check(mgcfd_rank_set_halo(p->solvers[static_cast<size_t>(r)], 0, static_cast<int>(peers.size()), peers.data(), sc.data(), sp.data(), rc.data(), rp.data()),
-                  "setting a rank's halo lists");
-        }
+        for (int r = 0; r < opt.gpus; r++) set_halo(p->solvers[static_cast<size_t>(r)], 0, p->parts[static_cast<size_t>(r)]);
         check(mgcfd_group_exchange(p->group, 0), "the first halo exchange");
     } else {
         // one multigrid level per GPU: every rank holds the hierarchy (plans and static data), sweeps only its levels
@@ -216,7 +363,8 @@ Run::~Run()
 }
 
 int Run::ranks() const { return static_cast<int>(p->solvers.size()); }
-bool Run::partitioned() const { return p->partitioned; }
+bool Run::partitioned() const { return p->partitioned || p->partitioned_mg; }
+bool Run::partitioned_hierarchy() const { return p->partitioned_mg; }
 
 // level-per-GPU: move a whole node array of `level` from the solver of rank `src` to the solver of rank `dst`
 static void hand_over(Run::Impl *p, int level, int which, int src, int dst, bool restricted)
@@ -249,6 +397,17 @@ static void hand_over(Run::Impl *p, int level, int which, int src, int dst, bool
 int Run::run_cycles(int cycles, double *rms_out)
 {
     const int n = p->levels, w = ranks();
+    if (p->partitioned_mg) {
+        // every level partitioned: the whole batch of V-cycles inside the library, the RMS of every cycle read back once
+        std::vector<double> rms(static_cast<size_t>(std::max(cycles, 1)));
+        for (int c = 0; c < cycles; c += 4096) {
+            const int rc = mgcfd_group_cycles(p->group, std::min(4096, cycles - c), rms.data() + c);
+            if (rc == MGCFD_ERR_NAN || rc == MGCFD_ERR_NEG_DENSITY || rc == MGCFD_ERR_NEG_ENERGY) return rc;
+            check(rc, "the partitioned V-cycles");
+        }
+        if (rms_out) std::copy(rms.begin(), rms.begin() + cycles, rms_out);
+        return MGCFD_OK;
+    }
     if (p->partitioned) {
         // the whole batch inside the library: a host thread per rank, the RMS of every cycle read back once
         std::vector<double> rms(static_cast<size_t>(std::max(cycles, 1)));
@@ -294,7 +453,7 @@ int Run::run_cycles(int cycles, double *rms_out)
 
 void Run::get_level0(int which, int ncols, double *out) const
 {
-    if (!p->partitioned) { check(mgcfd_get_array(p->solvers[0], 0, which, out), "reading back an array"); return; }
+    if (!p->partitioned && !p->partitioned_mg) { check(mgcfd_get_array(p->solvers[0], 0, which, out), "reading back an array"); return; }
     for (size_t r = 0; r < p->solvers.size(); r++) {
         const Part &P = p->parts[r];
         std::vector<double> a(P.gids.size() * static_cast<size_t>(ncols));
@@ -307,14 +466,16 @@ void Run::get_level0(int which, int ncols, double *out) const
 int Run::check_invalid(int level, int64_t *bad_cell) const
 {
     // (validation.cpp:107-138 stops at the first bad cell in original order: the smallest global id over the ranks)
-    if (!p->partitioned) return mgcfd_check_for_invalid_variables(p->solvers[static_cast<size_t>(level % ranks())], level, bad_cell);
+    if (!p->partitioned && !p->partitioned_mg) return mgcfd_check_for_invalid_variables(p->solvers[static_cast<size_t>(level % ranks())], level, bad_cell);
     int rc_all = MGCFD_OK;
     int64_t first = -1;
     for (size_t r = 0; r < p->solvers.size(); r++) {
         int64_t bad = -1;
-        const int rc = mgcfd_check_for_invalid_variables(p->solvers[r], 0, &bad);
+        const int lvl = p->partitioned_mg ? level : 0;
+        const std::vector<int64_t> &gids = p->partitioned_mg ? p->hparts[r][static_cast<size_t>(level)].gids : p->parts[r].gids;
+        const int rc = mgcfd_check_for_invalid_variables(p->solvers[r], lvl, &bad);
         if (rc == MGCFD_OK) continue;
-        const int64_t g = (bad >= 0 && bad < int64_t(p->parts[r].gids.size())) ? p->parts[r].gids[static_cast<size_t>(bad)] : bad;
+        const int64_t g = (bad >= 0 && bad < int64_t(gids.size())) ? gids[static_cast<size_t>(bad)] : bad;
         if (first < 0 || g < first) { first = g; rc_all = rc; }
     }
     if (bad_cell) *bad_cell = first;
@@ -326,6 +487,18 @@ void Run::loop_iters(int level, int cycles, int64_t out[MGCFD_NUM_LOOPS]) const
     // what the reference's counters would hold for the whole mesh (src/Monitoring/loop_stats.cpp:48-81): a rank's own
     // counters include the edges cut by the partition once per side
     std::memset(out, 0, sizeof(int64_t) * MGCFD_NUM_LOOPS);
+    if (p->partitioned_mg) {
+        // (a V-cycle sweeps levels 0 .. n-1, n-2 .. 1: every level but the first and the last twice; restrict is booked on the
+        //  coarse level, op_restrict / op_prolong of solver.cpp give the counts: mg_loops.cpp:61,117,172 and :728,842)
+        const int n = p->levels;
+        const int64_t sw = (level == 0 || level == n - 1) ? 1 : 2;
+        out[MGCFD_LOOP_FLUX] = int64_t(MGCFD_RK) * sw * cycles * p->n_internal[static_cast<size_t>(level)];
+        out[MGCFD_LOOP_COMPUTE_STEP] = sw * cycles * p->nel[static_cast<size_t>(level)];
+        out[MGCFD_LOOP_TIME_STEP] = int64_t(MGCFD_RK) * sw * cycles * p->nel[static_cast<size_t>(level)];
+        if (level > 0) out[MGCFD_LOOP_RESTRICT] = int64_t(cycles) * (2 * p->nel[static_cast<size_t>(level) - 1] + p->nel[static_cast<size_t>(level)]);
+        if (level + 1 < n) out[MGCFD_LOOP_PROLONG] = int64_t(cycles) * (p->n_internal[static_cast<size_t>(level)] + p->nel[static_cast<size_t>(level)]);
+        return;
+    }
     if (p->partitioned) {
         out[MGCFD_LOOP_FLUX] = int64_t(MGCFD_RK) * cycles * p->n_internal[0];
         out[MGCFD_LOOP_COMPUTE_STEP] = int64_t(cycles) * p->nel[0];

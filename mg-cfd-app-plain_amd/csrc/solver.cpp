@@ -2023,7 +2023,7 @@ static void halo_start(mgcfd_solver *s, int level, const double *field, int b)
 
 // in-process group: every rank's segments copied into its peers' receive buffers (device to device, over xGMI between
 // devices), each destination's copies on its own comm stream behind the sources' pack events
-static void group_deliver(mgcfd_group *g, int level, int b)
+static void group_deliver(mgcfd_group *g, int level, int b, bool behind_own_pack = false)
 {
     for (mgcfd_solver *dst : g->ranks) {
         dst->use_device();
@@ -2031,6 +2031,9 @@ static void group_deliver(mgcfd_group *g, int level, int b)
         HaloExchange &hd = *ld.hx;
         const int me = comm_of(dst).rank;
         bool any = false;
+        // (an exchange outside the sweeps' three-set rotation: the destination's receive buffer is free only behind its own
+        //  stream's last unpack, which lies before its pack of this exchange)
+        if (behind_own_pack) HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, hd.packed[b], 0));
         for (size_t k = 0; k < hd.peer.size(); k++) {
             mgcfd_solver *src = g->ranks[static_cast<size_t>(hd.peer[k])];
             HaloExchange &hs = *src->level(level).hx;
@@ -3114,6 +3117,220 @@ int mgcfd_group_synchronize(mgcfd_group *g)
 {
     REQUIRE(g);
     return guarded([&] { for (mgcfd_solver *s : g->ranks) { s->use_device(); HIP_CHECK(hipStreamSynchronize(s->stream)); HIP_CHECK(hipGetLastError()); } });
+}
+
+// ---- V-cycles on a PARTITIONED hierarchy, the whole state machine inside the library --------------------------------------
+// mgcfd_create_partitioned_mg + mgcfd_rank_set_halo on EVERY level.  The cycle is the reference's
+// (src/euler3d_cpu_double.cpp:371-694: sweeps on levels 0 .. n-1, n-2 .. 1 with mg_restrict on the way up and
+// prolong_residuals_interpolate_proper on the way down) with ghost values moved where the next loop reads them:
+//   `variables` of a level   after every time_step (inside the partitioned sweep: one message per Runge-Kutta stage),
+//                            after mg_restrict filled it (coarse ghosts: mg_loops.cpp:30-202 writes owned coarse nodes only) and
+//                            after the prolongation corrected it (fine ghosts: the next sweep's fluxes read them);
+//   `residuals` of the coarse level before the prolongation (mg_loops.cpp:678-864 reads the parents of a node's neighbours).
+// A coarse node is averaged where it is owned, over its children in GLOBAL-id order (order_keys), so every level equals the
+// unpartitioned hierarchy's bit for bit on owned nodes.  The transfers' exchanges are the buffered form (pack, copies or RCCL
+// send / receive, unpack) outside the sweeps' three-set rotation, hence with explicit waits for the buffers.
+
+static void group_prepare_level(mgcfd_group *g, int level)
+{
+    for (mgcfd_solver *s : g->ranks) {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        if (!lv.hx) throw std::invalid_argument("a rank has no halo lists on level " + std::to_string(level) + ": call mgcfd_rank_set_halo for every level");
+        s->settle_fluxes(lv);
+    }
+    for (mgcfd_solver *s : g->ranks) {                      // (allocations and uploads: never inside a sweep)
+        HaloExchange &hx = *s->level(level).hx;
+        if (hx.min_par) continue;
+        s->use_device();
+        hx.min_par = dev_alloc<double>(2);
+    }
+    for (mgcfd_solver *s : g->ranks) {
+        HaloExchange &hx = *s->level(level).hx;
+        if (hx.peer_scalars[0]) continue;
+        s->use_device();
+        for (int par = 0; par < 2; par++) {
+            std::vector<const double *> ptrs;
+            for (mgcfd_solver *src : g->ranks) ptrs.push_back(src->level(level).hx->min_par + par);
+            hx.peer_scalars[par] = dev_upload(ptrs);
+        }
+    }
+    group_prepare_direct(g, level);
+}
+
+static double *array_ptr(DeviceLevel &lv, int which, int *ncols);
+
+// the ghosts of array `which` of `level` <- their owners, on every rank of the group
+static void group_exchange_array(mgcfd_group *g, int level, int which)
+{
+    const int b = 0;
+    for (mgcfd_solver *s : g->ranks) {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        HaloExchange &hx = *lv.hx;
+        s->settle_residuals(lv);
+        // this rank's send buffer is free behind the copies the peers made out of it (their `arrived` of the last use of the
+        // set); and in direct mode nobody's last push into this rank's ghosts may still be on its way when the unpack writes them
+        for (int p : hx.peer) HIP_CHECK(hipStreamWaitEvent(s->stream, g->ranks[static_cast<size_t>(p)]->level(level).hx->arrived[b], 0));
+        if (hx.direct) wait_for_peers(g, s, level, 2);
+        int nc = 0;
+        halo_start(s, level, array_ptr(lv, which, &nc), b);
+    }
+    group_deliver(g, level, b, true);
+    for (mgcfd_solver *s : g->ranks) {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        int nc = 0;
+        halo_finish(s, level, array_ptr(lv, which, &nc), b);
+        if (which == MGCFD_ARR_VARIABLES) lv.min_ahead = false;
+    }
+}
+
+static void append_level0_sumsq(mgcfd_solver *s)
+{
+    DeviceLevel &lv = s->level(0);
+    exact::launch_sumsq(s->stream, lv.info.nel, lv.dp.stride, lv.residuals, lv.partials, lv.n_partials, lv.sumsq, lv.dp.old_of_new, lv.n_owned);
+    exact::launch_append_scalar(s->stream, lv.sumsq, s->rms_ring, s->rms_count, mgcfd_solver::kRmsRing);
+}
+
+// one V-cycle of every rank of an in-process group (one host thread issues it)
+static void group_cycle_once(mgcfd_group *g, bool with_rms)
+{
+    const int n = static_cast<int>(g->ranks[0]->L.size());
+    for (int l = 0; l < n; l++) {
+        group_sweep_once(g, l);                                                    // :383-508
+        if (l == 0 && with_rms) for (mgcfd_solver *s : g->ranks) { s->use_device(); append_level0_sumsq(s); }   // :509-512
+        if (l + 1 < n) {
+            for (mgcfd_solver *s : g->ranks) {
+                s->use_device();
+                if (s->level(l).hx->direct) wait_for_peers(g, s, l, 2);            // (the children this rank holds as ghosts: the peers' last pushes)
+                s->op_restrict(l);                                                 // :527-559
+            }
+            group_exchange_array(g, l + 1, MGCFD_ARR_VARIABLES);
+        }
+    }
+    for (int l = n - 2; l >= 0; l--) {
+        group_exchange_array(g, l + 1, MGCFD_ARR_RESIDUALS);
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); s->op_prolong(l); }    // :560-688
+        group_exchange_array(g, l, MGCFD_ARR_VARIABLES);
+        if (l > 0) group_sweep_once(g, l);
+    }
+}
+
+// what the checks inside the launches of every rank found (the reference exits at the first bad cell of the first failing time_step)
+static int group_read_errors(mgcfd_group *g)
+{
+    int code = MGCFD_OK;
+    for (mgcfd_solver *s : g->ranks) {
+        s->use_device();
+        const int c = s->read_error(nullptr);
+        if (c != MGCFD_OK && code == MGCFD_OK) code = c;
+    }
+    return code;
+}
+
+int mgcfd_group_cycles(mgcfd_group *g, int cycles, double *rms_out)
+{
+    REQUIRE(g);
+    int code = MGCFD_OK;
+    const int rc = guarded([&] {
+        if (cycles > mgcfd_solver::kRmsRing) throw std::invalid_argument("at most 4096 cycles per call");
+        const int n = static_cast<int>(g->ranks[0]->L.size());
+        for (mgcfd_solver *s : g->ranks) if (static_cast<int>(s->L.size()) != n) throw std::invalid_argument("the ranks of a group hold the same number of levels");
+        for (int l = 0; l < n; l++) group_prepare_level(g, l);
+        for (mgcfd_solver *s : g->ranks) {
+            s->use_device();
+            if (!s->rms_ring) { s->rms_ring = dev_alloc<double>(mgcfd_solver::kRmsRing); s->rms_count = dev_alloc<int>(1); }
+            HIP_CHECK(hipMemsetAsync(s->rms_count, 0, sizeof(int), s->stream));
+        }
+        for (int c = 0; c < cycles; c++) group_cycle_once(g, rms_out != nullptr);
+        // every rank's stream behind the last pushes into it, then the read-backs
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); for (int l = 0; l < n; l++) if (s->level(l).hx->direct) wait_for_peers(g, s, l, 2); }
+        if (rms_out) {
+            std::vector<double> sums(static_cast<size_t>(cycles), 0.0), part(static_cast<size_t>(std::max(cycles, 1)));
+            int64_t nodes = 0;
+            for (mgcfd_solver *s : g->ranks) {                  // (added in rank order, as mgcfd_group_rms adds them)
+                s->use_device();
+                HIP_CHECK(hipMemcpyAsync(part.data(), s->rms_ring, sizeof(double) * static_cast<size_t>(cycles), hipMemcpyDeviceToHost, s->stream));
+                HIP_CHECK(hipStreamSynchronize(s->stream));
+                for (int k = 0; k < cycles; k++) sums[static_cast<size_t>(k)] += part[static_cast<size_t>(k)];
+                nodes += s->level(0).n_owned;
+            }
+            for (int k = 0; k < cycles; k++) rms_out[k] = std::sqrt(sums[static_cast<size_t>(k)] / double(nodes));
+        }
+        code = group_read_errors(g);
+        for (mgcfd_solver *s : g->ranks) { s->use_device(); HIP_CHECK(hipGetLastError()); }
+    });
+    if (rc != MGCFD_OK) return rc;
+    if (code != MGCFD_OK) g_last_error = "check_for_invalid_variables: a rank of the group found an invalid state during the cycles";
+    return code;
+}
+
+// ---- the same for one rank per process over RCCL ----
+static void rank_exchange_array(mgcfd_solver *s, int level, int which)
+{
+    DeviceLevel &lv = s->level(level);
+    s->settle_residuals(lv);
+    int nc = 0;
+    double *field = array_ptr(lv, which, &nc);
+    halo_start(s, level, field, 0);                         // (set 0 is free: a sweep finishes every exchange it starts, and so does this)
+    halo_finish(s, level, field, 0);
+    if (which == MGCFD_ARR_VARIABLES) lv.min_ahead = false;
+}
+
+static void rank_cycle_once(mgcfd_solver *s, bool with_rms)
+{
+    const int n = static_cast<int>(s->L.size());
+    for (int l = 0; l < n; l++) {
+        rank_sweep_once(s, l);
+        if (l == 0 && with_rms) append_level0_sumsq(s);
+        if (l + 1 < n) { s->op_restrict(l); rank_exchange_array(s, l + 1, MGCFD_ARR_VARIABLES); }
+    }
+    for (int l = n - 2; l >= 0; l--) {
+        rank_exchange_array(s, l + 1, MGCFD_ARR_RESIDUALS);
+        s->op_prolong(l);
+        rank_exchange_array(s, l, MGCFD_ARR_VARIABLES);
+        if (l > 0) rank_sweep_once(s, l);
+    }
+}
+
+int mgcfd_rank_cycles(mgcfd_solver *s, int cycles, double *rms_out)
+{
+    REQUIRE(s);
+    int code = MGCFD_OK;
+    const int rc = guarded([&] {
+        s->use_device();
+        mgcfd_comm &c = comm_of(s);
+        if (!c.rccl) throw std::invalid_argument("in-process ranks cycle through mgcfd_group_cycles");
+        if (cycles > mgcfd_solver::kRmsRing) throw std::invalid_argument("at most 4096 cycles per call");
+        for (DeviceLevel &lv : s->L) {
+            if (!lv.hx) throw std::invalid_argument("a level has no halo lists: call mgcfd_rank_set_halo for every level");
+            if (lv.hx->ipc) throw std::invalid_argument("mgcfd_rank_cycles runs the buffered exchange: mgcfd_rank_ipc_detach first");
+            s->settle_fluxes(lv);
+        }
+        if (!s->rms_ring) { s->rms_ring = dev_alloc<double>(mgcfd_solver::kRmsRing); s->rms_count = dev_alloc<int>(1); }
+        HIP_CHECK(hipMemsetAsync(s->rms_count, 0, sizeof(int), s->stream));
+        for (int k = 0; k < cycles; k++) rank_cycle_once(s, rms_out != nullptr);
+        if (rms_out && cycles > 0) {
+            // calc_rms of the whole level (validation.cpp:91-105): the ranks' sums of every cycle added by ONE all-reduce
+            RCCL_CHECK(g_rccl.AllReduce(s->rms_ring, s->rms_ring, static_cast<size_t>(cycles), Rccl::kDouble, Rccl::kSum, c.rccl, s->stream));
+            double nodes_local = double(s->level(0).n_owned);
+            DeviceLevel &l0 = s->level(0);
+            HIP_CHECK(hipMemcpyAsync(l0.sumsq, &nodes_local, sizeof(double), hipMemcpyHostToDevice, s->stream));
+            RCCL_CHECK(g_rccl.AllReduce(l0.sumsq, l0.hx->gmin, 1, Rccl::kDouble, Rccl::kSum, c.rccl, s->stream));
+            double nodes = 0.0;
+            std::vector<double> sums(static_cast<size_t>(cycles));
+            HIP_CHECK(hipMemcpyAsync(sums.data(), s->rms_ring, sizeof(double) * static_cast<size_t>(cycles), hipMemcpyDeviceToHost, s->stream));
+            HIP_CHECK(hipMemcpyAsync(&nodes, l0.hx->gmin, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            HIP_CHECK(hipStreamSynchronize(s->stream));
+            for (int k = 0; k < cycles; k++) rms_out[k] = std::sqrt(sums[static_cast<size_t>(k)] / nodes);
+        }
+        code = s->read_error(nullptr);                      // synchronises
+        HIP_CHECK(hipGetLastError());
+    });
+    if (rc != MGCFD_OK) return rc;
+    if (code != MGCFD_OK) g_last_error = "check_for_invalid_variables: invalid state during the cycles";
+    return code;
 }
 
 // how a level's tiles split for the overlapped exchange: out[0] boundary tiles, out[1] interior tiles, out[2] nodes sent, out[3] nodes received

@@ -135,6 +135,8 @@ _SIGNATURES = [
     ("mgcfd_rank_ipc_export", C.c_int, [_vp, C.c_int, _vp]),
     ("mgcfd_rank_ipc_attach", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_rank_ipc_status", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    ("mgcfd_group_cycles", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
+    ("mgcfd_rank_cycles", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_rank_ipc_detach", C.c_int, [_vp, C.c_int]),
     ("mgcfd_group_sweeps", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mgcfd_group_sweeps_rms", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -580,6 +582,12 @@ class Solver:
     def rank_exchange(self, l: int): self._c(self.lib.mgcfd_rank_exchange(self.handle, l))
     def rank_sweeps(self, l: int, sweeps: int = 1): self._c(self.lib.mgcfd_rank_sweeps(self.handle, l, sweeps))
 
+    def rank_cycles(self, cycles: int, rms: bool = True) -> np.ndarray:
+        """V-cycles of this rank's share of a partitioned hierarchy over RCCL (mgcfd_rank_cycles); the level-0 RMS of each cycle."""
+        out = np.zeros(max(cycles, 1), dtype=np.float64)
+        self._c(self.lib.mgcfd_rank_cycles(self.handle, cycles, out.ctypes.data_as(C.POINTER(C.c_double)) if rms else None))
+        return out[:cycles]
+
     def rank_residual_sumsq(self, l: int) -> float:
         v = C.c_double()
         self._c(self.lib.mgcfd_rank_residual_sumsq(self.handle, l, C.byref(v)))
@@ -629,6 +637,12 @@ class Group:
         _check(self.lib, self.lib.mgcfd_group_sweeps_rms(self.handle, l, n, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out[:n]
     def synchronize(self): _check(self.lib, self.lib.mgcfd_group_synchronize(self.handle))
+
+    def cycles(self, n: int = 1, rms: bool = True) -> np.ndarray:
+        """n V-cycles of a partitioned hierarchy (mgcfd_group_cycles); the level-0 RMS of each cycle."""
+        out = np.zeros(max(n, 1), dtype=np.float64)
+        _check(self.lib, self.lib.mgcfd_group_cycles(self.handle, n, out.ctypes.data_as(C.POINTER(C.c_double)) if rms else None))
+        return out[:n]
 
     def rms(self, l: int = 0) -> float:
         v = C.c_double()

@@ -396,13 +396,25 @@ class PartitionedCycle:
             self.exchange_fn(self, level)
         elif self.dist:
             d, ops = self.dist, []
-            for p in sorted(set(self.buf_send[level]) | set(self.buf_recv[level])):
-                if p in self.buf_send[level]:
-                    ops.append(d.P2POp(d.isend, self.buf_send[level][p], p))
-                if p in self.buf_recv[level]:
-                    ops.append(d.P2POp(d.irecv, self.buf_recv[level][p], p))
+            send, recv = self.buf_send[level], self.buf_recv[level]
+            # (gloo given DEVICE tensors — bench.py's one-GPU rehearsal — knows nothing of streams: through the host, stream drained)
+            staged = any(_gloo_on_device(d, b) for b in list(send.values()) + list(recv.values()))
+            if staged:
+                import torch
+                torch.cuda.current_stream().synchronize()
+                send = {p: b.cpu() for p, b in send.items()}
+                recv = {p: torch.empty(b.shape, dtype=b.dtype) for p, b in recv.items()}
+            for p in sorted(set(send) | set(recv)):
+                if p in send:
+                    ops.append(d.P2POp(d.isend, send[p], p))
+                if p in recv:
+                    ops.append(d.P2POp(d.irecv, recv[p], p))
             for req in d.batch_isend_irecv(ops):
                 req.wait()
+            if staged:
+                for p, h in recv.items():
+                    self.buf_recv[level][p].copy_(h)
+                torch.cuda.current_stream().synchronize()
         for p, plan in self.plan_recv[level].items():
             s.halo_unpack(level, plan, name, self.buf_recv[level][p].data_ptr())
 

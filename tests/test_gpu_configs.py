@@ -344,8 +344,8 @@ def test_bench_rehearsal_two_ranks_on_this_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MGCFD_BENCH_REHEARSAL="1")
-    for extra, kind, scaling in ((["--lattice", "30"], "partitioned", "strong"), (["--workload", "copies", "--lattice", "24"], "copies", "weak"),
-                                 (["--lattice", "30", "--exchange", "ipc"], "partitioned", "strong")):
+    for extra, kind, scaling in ((["--lattice", "30", "--vcycle-hierarchy", "tiny"], "partitioned", "strong"), (["--workload", "copies", "--lattice", "24"], "copies", "weak"),
+                                 (["--lattice", "30", "--exchange", "ipc", "--no-vcycle"], "partitioned", "strong")):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"] + extra,
                            capture_output=True, text=True, env=env, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -357,6 +357,12 @@ def test_bench_rehearsal_two_ranks_on_this_gpu():
             # the same flags) and had reproduced the torch path's sweep bit for bit at start-up — no fall-back
             assert "HIP IPC" in line["config"]["exchange"] and "checked against the torch path" in line["config"]["exchange"]
             assert "not used" not in line["config"]["exchange"] and "bit for bit on every rank" in line["config"]["exchange"]
+            if "--no-vcycle" not in extra:
+                # ... and the V-cycle half of the metric on the partitioned hierarchy (the torch orchestration here: RCCL cannot
+                # form a communicator with both ranks on one device; on N GPUs the library's mgcfd_rank_cycles)
+                vc = line["vcycle"]
+                assert vc["wall_s_per_cycle"] > 0 and vc["state_valid"] and "every level partitioned over 2 ranks" in vc["workload"]
+                assert "MG V-cycle wall-s" in line["metric"]
 
 
 def _group_sweeps_check(mg, n_parts, sweeps, partitioner="rcb"):

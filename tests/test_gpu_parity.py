@@ -1572,6 +1572,35 @@ def test_driver_on_several_gpus_validates_and_dumps_as_on_one(case, gpus, tmp_pa
     assert r.returncode != 0 and "ERROR: Unacceptable error detected at (i=7, v=1)" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("case,gpus,flag", [("m6_3lvl", 4, []), ("m6_3lvl", 2, ["--gpus-partition"]), ("m6_2lvl_dup2", 3, []), ("tet_2lvl", 3, [])])
+def test_driver_on_a_partitioned_hierarchy_reproduces_reference_binary(case, gpus, flag, tmp_path):
+    """euler3d_gpu_double --gpus N with N above the number of levels (or --gpus-partition): EVERY level split over the N ranks
+    (multi_gpu.cpp: partition_hierarchy), the V-cycles swept inside the library (mgcfd_group_cycles).  The variables dump
+    must still be the reference binary's byte for byte, the RMS lines and the loop counters the same; -v passes."""
+    import shutil
+    d, cycles, dup = _case(case)
+    work = tmp_path / "in"
+    shutil.copytree(os.path.join(d, "input"), work)
+    shutil.copy(os.path.join(d, "variables.level0.txt"), work / f"solution.variables.size={dup}x.cycles={cycles}.level=0")
+    exe = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")
+    cmd = [exe, "-i", "input.dat", "-d", str(work), "-o", str(tmp_path) + "/", "-g", str(cycles),
+           "-m", str(dup), "--output-variables", "-v", "--gpus", str(gpus), "--gpus-share-device"] + flag
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "every level partitioned" in r.stderr and f"{gpus} ranks" in r.stderr
+    dump = tmp_path / f"variables.size={dup}x.cycles={cycles}.level=0"
+    assert dump.read_bytes() == open(os.path.join(d, "variables.level0.txt"), "rb").read()
+    assert "PASS: variables[] validated successfully" in r.stdout
+    want_lines = [l.strip() for l in open(os.path.join(d, "stdout.txt")) if "RMS" in l]
+    got_lines = [l.strip() for l in r.stdout.splitlines() if "RMS" in l]
+    assert got_lines == want_lines
+    want, got = _csv_row(os.path.join(d, "LoopNumIters.csv")), _csv_row(tmp_path / "LoopNumIters.csv")
+    for k in want:
+        if k[:-1] in ("flux", "update", "compute_step", "time_step", "restrict", "prolong") or k in ("Size", "Mesh", "MG cycles"):
+            assert got[k] == want[k], k
+    assert got["Num threads"] == str(gpus)
+
+
 def test_driver_refuses_more_gpus_than_there_are(tmp_path):
     d, cycles, dup = _case("fvcorr_1lvl")
     exe = os.path.join(ROOT, "mg-cfd-app-plain_amd", "csrc", "euler3d_gpu_double")

@@ -2023,9 +2023,15 @@ static void halo_start(mgcfd_solver *s, int level, const double *field, int b)
 
 // in-process group: every rank's segments copied into its peers' receive buffers (device to device, over xGMI between
 // devices), each destination's copies on its own comm stream behind the sources' pack events
+static void deliver_to(mgcfd_group *g, mgcfd_solver *dst, int level, int b, bool behind_own_pack);
 static void group_deliver(mgcfd_group *g, int level, int b, bool behind_own_pack = false)
 {
-    for (mgcfd_solver *dst : g->ranks) {
+    for (mgcfd_solver *dst : g->ranks) deliver_to(g, dst, level, b, behind_own_pack);
+}
+// the segments the other ranks packed for `dst` into its receive buffer (its comm stream behind the sources' pack events)
+static void deliver_to(mgcfd_group *g, mgcfd_solver *dst, int level, int b, bool behind_own_pack)
+{
+    {
         dst->use_device();
         DeviceLevel &ld = dst->level(level);
         HaloExchange &hd = *ld.hx;
@@ -3217,6 +3223,99 @@ static void group_cycle_once(mgcfd_group *g, bool with_rms)
     }
 }
 
+// The same cycle with a host thread per rank (direct mode; what mgcfd_group_cycles runs for groups of several ranks:
+// one thread issuing every rank's ~100 calls per cycle makes the host the bottleneck N times over).  As in
+// group_sweeps_threaded the threads agree on the ORDER of event records and waits through barriers: one after the first
+// half of compute_step_factor and after every stage of a sweep, two per transfer exchange (all packed | all delivered).
+static void group_cycles_threaded(mgcfd_group *g, int cycles, bool with_rms)
+{
+    const int n = static_cast<int>(g->ranks.size());
+    const int nl = static_cast<int>(g->ranks[0]->L.size());
+    SpinBarrier bar(n);
+    std::atomic<bool> failed{false};
+    std::mutex mu;
+    std::exception_ptr first_error;
+    const bool global_dt = g->ranks[0]->mesh_variant != MGCFD_MESH_FVCORR;
+    auto run = [&](int r) {
+        mgcfd_solver *s = g->ranks[static_cast<size_t>(r)];
+        // (a rank that failed keeps arriving at the barriers, doing nothing, so that the others are not left waiting)
+        auto step = [&](auto &&body) {
+            if (failed.load(std::memory_order_acquire)) return;
+            try { body(); }
+            catch (...) { std::lock_guard<std::mutex> lock(mu); if (!first_error) first_error = std::current_exception(); failed.store(true, std::memory_order_release); }
+        };
+        step([&] { s->use_device(); });
+        auto sweep = [&](int level) {                   // (group_sweeps_threaded's body)
+            DeviceLevel &lv = s->level(level);
+            HaloExchange &hx = *lv.hx;
+            const int par = hx.min_parity;
+            step([&] {
+                sweep_first_half(s, level, hx.min_par + par);
+                if (global_dt) HIP_CHECK(hipEventRecord(hx.reduced, s->stream));
+            });
+            hx.min_parity = par ^ 1;
+            bar.wait();
+            PushPeers to[MGCFD_RK];
+            step([&] {
+                if (global_dt) {
+                    for (mgcfd_solver *src : g->ranks) if (src != s) HIP_CHECK(hipStreamWaitEvent(s->stream, src->level(level).hx->reduced, 0));
+                    exact::launch_min_over_peers(s->stream, hx.peer_scalars[par], n, hx.gmin);
+                }
+                for (int j = 0; j < MGCFD_RK; j++) to[j] = make_push_peers(g, s, level, [&](DeviceLevel &pl) { return stage_out_buffer(pl, j); });
+            });
+            for (int j = 0; j < MGCFD_RK; j++) {
+                step([&] {
+                    stage_boundary_direct(g, s, level, j, global_dt ? 3 : 0, hx.gmin, 1, &to[j]);
+                    stage_interior(s, level, j, global_dt ? 3 : 0, hx.gmin, 1);
+                });
+                bar.wait();
+            }
+        };
+        auto exchange = [&](int level, int which) {
+            const int b = 0;
+            DeviceLevel &lv = s->level(level);
+            HaloExchange &hx = *lv.hx;
+            step([&] {
+                s->settle_residuals(lv);
+                for (int p : hx.peer) HIP_CHECK(hipStreamWaitEvent(s->stream, g->ranks[static_cast<size_t>(p)]->level(level).hx->arrived[b], 0));
+                wait_for_peers(g, s, level, 2);
+                int nc = 0;
+                halo_start(s, level, array_ptr(lv, which, &nc), b);
+            });
+            bar.wait();                                 // every rank's pack event is recorded
+            step([&] {
+                deliver_to(g, s, level, b, true);
+                int nc = 0;
+                halo_finish(s, level, array_ptr(lv, which, &nc), b);
+                if (which == MGCFD_ARR_VARIABLES) lv.min_ahead = false;
+            });
+            bar.wait();                                 // ... and every rank's arrival event, before anybody's next wait for it
+        };
+        for (int c = 0; c < cycles; c++) {
+            for (int l = 0; l < nl; l++) {
+                sweep(l);
+                if (l == 0 && with_rms) step([&] { append_level0_sumsq(s); });
+                if (l + 1 < nl) {
+                    step([&] { wait_for_peers(g, s, l, 2); s->op_restrict(l); });
+                    exchange(l + 1, MGCFD_ARR_VARIABLES);
+                }
+            }
+            for (int l = nl - 2; l >= 0; l--) {
+                exchange(l + 1, MGCFD_ARR_RESIDUALS);
+                step([&] { s->op_prolong(l); });
+                exchange(l, MGCFD_ARR_VARIABLES);
+                if (l > 0) sweep(l);
+            }
+        }
+        step([&] { for (int l = 0; l < nl; l++) wait_for_peers(g, s, l, 2); HIP_CHECK(hipGetLastError()); });
+    };
+    std::vector<std::thread> threads;
+    for (int r = 1; r < n; r++) threads.emplace_back(run, r);
+    run(0);
+    for (std::thread &t : threads) t.join();
+    if (first_error) std::rethrow_exception(first_error);
+}
+
 // what the checks inside the launches of every rank found (the reference exits at the first bad cell of the first failing time_step)
 static int group_read_errors(mgcfd_group *g)
 {
@@ -3243,7 +3342,21 @@ int mgcfd_group_cycles(mgcfd_group *g, int cycles, double *rms_out)
             if (!s->rms_ring) { s->rms_ring = dev_alloc<double>(mgcfd_solver::kRmsRing); s->rms_count = dev_alloc<int>(1); }
             HIP_CHECK(hipMemsetAsync(s->rms_count, 0, sizeof(int), s->stream));
         }
-        for (int c = 0; c < cycles; c++) group_cycle_once(g, rms_out != nullptr);
+        // A host thread per rank where every level runs the direct form and every rank has a device of its own: one thread
+        // issuing N ranks' ~100 calls per cycle costs N x 0.76 ms (tools/hostcost_cycles.py).  Ranks that SHARE a device (the
+        // one-GPU rehearsal) are issued by the caller's thread: there the threads only contend for the one device's queues
+        // (8 ranks: 12.2 ms per cycle against 6.0).  MGCFD_GROUP_THREADS=0 / 1 forces either form.
+        bool all_direct = g->ranks.size() > 1;
+        for (int l = 0; l < n; l++) all_direct = all_direct && g->ranks[0]->level(l).hx->direct;
+        if (const char *e = std::getenv("MGCFD_GROUP_THREADS")) all_direct = all_direct && std::atoi(e) != 0;
+        else {
+            std::vector<int> devs;
+            for (mgcfd_solver *s : g->ranks) devs.push_back(s->device);
+            std::sort(devs.begin(), devs.end());
+            all_direct = all_direct && std::adjacent_find(devs.begin(), devs.end()) == devs.end();
+        }
+        if (all_direct) group_cycles_threaded(g, cycles, rms_out != nullptr);
+        else for (int c = 0; c < cycles; c++) group_cycle_once(g, rms_out != nullptr);
         // every rank's stream behind the last pushes into it, then the read-backs
         for (mgcfd_solver *s : g->ranks) { s->use_device(); for (int l = 0; l < n; l++) if (s->level(l).hx->direct) wait_for_peers(g, s, l, 2); }
         if (rms_out) {

@@ -72,6 +72,22 @@ def test_group_cycles_on_lattice_hierarchies_equal_the_whole(sizes, n_parts):
     _check_against_whole(mgcfd.generated_to_levels(mg), mg.mesh_variant, n_parts, cycles=3)
 
 
+@pytest.mark.parametrize("threads", ["0", "1"])
+def test_group_cycles_with_and_without_a_host_thread_per_rank(monkeypatch, threads):
+    """MGCFD_GROUP_THREADS=1: a host thread per rank issues that rank's calls (the default when every rank has a device of
+    its own; barriers keep event records ahead of the waits for them); 0: the caller's thread issues everything (the default
+    when the ranks share one device, as here)."""
+    import mgcfd
+    from mgcfd import meshgen
+    monkeypatch.setenv("MGCFD_GROUP_THREADS", threads)
+    mg = meshgen.make_multigrid((13, 9, 6), "m6wing", seed=6, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+    _check_against_whole(mgcfd.generated_to_levels(mg), mg.mesh_variant, 4, cycles=3)
+    if threads == "1":
+        import bench
+        mg, levels = bench.build_hierarchy()
+        _check_against_whole(levels, mg.mesh_variant, 3, cycles=2)
+
+
 def test_group_cycles_on_a_tetrahedral_hierarchy_and_with_the_local_time_step():
     import mgcfd
     from mgcfd import meshgen

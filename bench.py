@@ -68,11 +68,46 @@ TRAFFIC_PROFILE = os.path.join("profiles", "r2_traffic.json")
 ROOFLINE_LAUNCHES = 1000     # back-to-back launches of the standalone flux kernel / of its data-movement probe per measurement
 
 
-def build_workload(lattice: int, seed: int = 0):
+def build_workload(lattice: int, seed: int = 0, mesh: str = "lattice"):
+    """mesh = "lattice": the jittered n^3 lattice (every interior node has six neighbours); "mixed": the same points with the
+    connectivity of three element types — hexahedral core, prism layers on a wall, a tetrahedral far field: internal degrees
+    3 ... 14, 18 % of the nodes not 6 (mgcfd.meshgen.make_mixed_level; 67^3: 300,763 nodes / 1,004,901 internal edges)."""
     from mgcfd import meshgen, generated_to_levels
-    mg = meshgen.make_multigrid((lattice,), "m6wing", seed=seed, jitter=0.2, area_noise=0.02,
-                                volume_noise=0.02, permute=True)
+    if mesh == "mixed":
+        mg = meshgen.make_mixed_multigrid((lattice,), "m6wing", seed=seed, jitter=0.2, area_noise=0.02, volume_noise=0.02, permute=True)
+    else:
+        mg = meshgen.make_multigrid((lattice,), "m6wing", seed=seed, jitter=0.2, area_noise=0.02,
+                                    volume_noise=0.02, permute=True)
     return mg, generated_to_levels(mg)
+
+
+def mixed_mesh_roofline(make_solver, fast: bool):
+    """The headline kernel on a level of NON-UNIFORM degree beside the lattice's figure: compute_flux_edge (+ boundary + far-field
+    faces) on the mixed-element level, priced as the lattice's (40 B per internal edge + 80 B per node against 8 TB/s)."""
+    mg, levels = build_workload(LATTICE, mesh="mixed")
+    s = make_solver(levels, mg.mesh_variant)
+    nel, n_int = s.nel(0), s.num_internal_edges(0)
+    s.set(0, "variables", perturbed_state(nel, s.far_field()[:5]))
+    til = s.tiling(0)
+    s.bench_flux(0, ROOFLINE_LAUNCHES)
+    t = s.bench_flux(0, ROOFLINE_LAUNCHES)
+    probe = s.bench_indirect_rw(0, ROOFLINE_LAUNCHES)
+    s.zero_fluxes(0)
+    s.smooth(0, 200); s.synchronize()
+    t0 = time.perf_counter(); s.smooth(0, 1000); s.synchronize(); sweep = (time.perf_counter() - t0) / 1000
+    algo = 40 * n_int + 80 * nel
+    out = {"mesh": f"mixed-element level on the {LATTICE}^3 points (hexahedral core, prism layers on a wall, tetrahedral far field; permuted ids): {nel} nodes / "
+                   f"{n_int} internal edges, internal degrees 3 ... 14",
+           "kernel": "compute_flux_edge + boundary + far-field faces in one launch (the same instantiation as on the lattice, or its long-row form)",
+           "avg_kernel_us": round(t * 1e6, 3), "launches": ROOFLINE_LAUNCHES, "algorithmic_bytes_per_launch": algo,
+           "achieved": round(algo / t / 1e9, 1), "frac": round(algo / t / 1e9 / HBM_PEAK_GBS, 4), "medges_per_s": round(n_int / t / 1e6, 1),
+           "empirical_ceiling_us": round(probe * 1e6, 3), "sweep_us": round(sweep * 1e6, 2), "sweep_medges_per_s": round(3 * n_int / sweep / 1e6, 1),
+           "tiling": {"tiles": til["tiles"], "halo_max": til["halo_max"], "halo_mean": round(til["halo_nodes"] / max(til["tiles"], 1), 1),
+                      "ell_padding": round(til["padding_entries"] / max(til["row_entries"], 1), 4), "long_row_list_entries": til["list_entries"],
+                      "overflow_refs": til["overflow_refs"]},
+           "numerics": "fast (FMA contraction)" if fast else "exact (bit-identical to the reference: tests/test_gpu_configs.py::test_mixed_level_full_size_sweep)"}
+    s.close()
+    return out
 
 
 def build_hierarchy(sizes=HIERARCHY):
@@ -372,6 +407,10 @@ def main():
                     help="N > 1: the hierarchy of the V-cycle leg — the 4-level hierarchy tiled 8x (per-rank work as on one GPU), the "
                          "one-GPU hierarchy itself (strong scaling of a 0.3 ms cycle), or a (20, 12, 8, 6)^3 one for functional rehearsals")
     ap.add_argument("--lattice", type=int, default=0, help="nodes per side of the synthetic level (default 67; 134 for `partitioned`)")
+    ap.add_argument("--mesh", default="lattice", choices=["lattice", "mixed"],
+                    help="level0 workload: the jittered lattice (default; every interior node six neighbours) or the mixed-element level on the same points "
+                         "(hexahedral core, prism layers, tetrahedral far field: internal degrees 3 ... 14); the default line reports the mixed level's "
+                         "flux-kernel figure beside the lattice's in roofline.mixed_mesh")
     ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
     ap.add_argument("--variant", type=int, default=-1, help="MGCFD_OPT_FLUX_VARIANT (see include/mgcfd.h)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "library", "ipc", "torch"],
@@ -470,14 +509,14 @@ def main():
     levels = None
 
     if workload in ("level0", "copies"):
-        mg, levels = build_workload(lattice)
+        mg, levels = build_workload(lattice, mesh=args.mesh)
         solver = make_solver(levels, mg.mesh_variant)
         nel, n_int = solver.nel(0), solver.num_internal_edges(0)
         solver.set(0, "variables", perturbed_state(nel, solver.far_field()[:5]))
         sharded = ShardedSweep(HipSolverAdapter(solver, dev), dist) if world > 1 else None
         step = (lambda: solver.smooth(0, 1)) if world == 1 else (lambda: sharded.sweep(0))
         edges_per_step_all_ranks = 3 * n_int * world
-        config.update({"workload": f"M6-L0-like synthetic level ({lattice}^3 jittered lattice, permuted ids): {nel} nodes / "
+        config.update({"workload": f"M6-L0-like synthetic level ({lattice}^3 jittered lattice" + (" points, mixed element types" if args.mesh == "mixed" else "") + f", permuted ids): {nel} nodes / "
                                    f"{n_int} internal edges per GPU, flux + update sweep, no MG",
                        "step": "copy, compute_step_factor, 3 x (fluxes, time_step), residual (the reference's per-sweep loops; run as 3 fused launches)",
                        "parallelism": f"{world} mesh copies (the reference's -m {world}), all-reduce(min dt) per sweep" if world > 1 else "1 GPU"})
@@ -815,7 +854,7 @@ def main():
             bytes_ts = 168 * nel                                # time_step
             traffic = {}
             try:
-                if lattice == LATTICE and not args.fast and args.variant == -1:
+                if lattice == LATTICE and not args.fast and args.variant == -1 and args.mesh == "lattice":
                     traffic = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
             except (OSError, ValueError):
                 traffic = {}
@@ -861,6 +900,8 @@ def main():
                                        "traffic": traffic.get("fused_stage", {}).get("bytes")}
             out["roofline"] = roof
     solver.close()
+    if rank == 0 and world == 1 and workload == "level0" and args.mesh == "lattice" and lattice == LATTICE and not args.no_vcycle and "roofline" in out:
+        out["roofline"]["mixed_mesh"] = mixed_mesh_roofline(make_solver, args.fast)
     if world > 1:
         dist.barrier()
     if world > 1 and workload in ("partitioned", "partitioned-mg") and not args.no_vcycle:

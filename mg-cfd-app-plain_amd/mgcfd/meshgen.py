@@ -142,6 +142,106 @@ def make_box_level(n: int, *, seed: int = 0, cavity_radius: float = 0.0, jitter:
                      nbr_idx=new_nb[order].copy(), nbr_w=w[order].copy())
 
 
+# ---------------------------------------------------------------------------------------
+# A level of MIXED element types on one lattice of points: what an M6-like mesh is made of
+# ---------------------------------------------------------------------------------------
+_DIAG_FACE = np.array([[1, 1, 0], [-1, -1, 0], [0, 1, 1], [0, -1, -1], [1, 0, 1], [-1, 0, -1]], dtype=np.int64)
+_DIAG_BODY = np.array([[1, 1, 1], [-1, -1, -1]], dtype=np.int64)
+
+
+def make_mixed_level(n: int, *, seed: int = 0, prism_layers: int = 3, tet_shell: int = 2, jitter: float = 0.0,
+                     area_noise: float = 0.0, volume_noise: float = 0.0, permute: bool = True,
+                     shuffle_neighbours: bool = True) -> LevelMesh:
+    """n^3 points with the connectivity of three element types (the Onera-M6 release is hexahedra-dominant with prism layers on
+    the wing and tetrahedra towards the far field; the files are not shipped):
+
+    * a HEXAHEDRAL core: the lattice's six neighbours (interior degree 6);
+    * PRISM layers on the wall z = 0 (a solid wall, -1): the ``prism_layers`` point layers next to it carry the in-plane
+      diagonal of a triangulated wall surface extruded upwards (degree 8);
+    * a TETRAHEDRAL far field: the ``tet_shell`` point layers next to the five other faces (far field, -2) are connected as
+      the Kuhn triangulation of their cells — three face diagonals and the body diagonal (degree up to 14).
+
+    A diagonal exists only between two nodes of the same region, and every direction comes with its opposite at equal
+    weight, so the dual faces of an interior node close (a uniform state stays uniform).  Internal degrees 3 ... 14 (18 %
+    of the nodes not 6); at n = 67: 300,763 nodes / 1,004,901 internal edges (3.3 per node; the M6: 300 K / 930 K)."""
+    assert n >= 4
+    rng = np.random.default_rng(seed)
+    h = 1.0 / (n - 1)
+    ii, jj, kk = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    ijk = np.stack([ii.ravel(), jj.ravel(), kk.ravel()], axis=1).astype(np.int64)
+    nel = len(ijk)
+    prism = ijk[:, 2] < prism_layers
+    near_far = (np.minimum(ijk[:, 0], n - 1 - ijk[:, 0]) < tet_shell) | (np.minimum(ijk[:, 1], n - 1 - ijk[:, 1]) < tet_shell) | \
+               (n - 1 - ijk[:, 2] < tet_shell)
+    tet = near_far & ~prism
+    dirs = np.concatenate([_DIRS, _DIAG_FACE, _DIAG_BODY])                    # 6 axis | 6 face diagonals | 2 body diagonals
+    nd = len(dirs)
+    half = np.where((ijk == 0) | (ijk == n - 1), 0.5, 1.0)
+    volumes = (h ** 3) * half.prod(axis=1)
+    if volume_noise > 0.0:
+        volumes = volumes * (1.0 + volume_noise * rng.uniform(-1.0, 1.0, nel))
+    src = np.repeat(np.arange(nel, dtype=np.int64), nd)
+    d = np.tile(dirs, (nel, 1))
+    kind = np.tile(np.arange(nd), nel)                                        # which direction
+    nb_ijk = np.repeat(ijk, nd, axis=0) + d
+    inside = ((nb_ijk >= 0) & (nb_ijk < n)).all(axis=1)
+    nb = np.where(inside, (nb_ijk[:, 0].clip(0, n - 1) * n + nb_ijk[:, 1].clip(0, n - 1)) * n + nb_ijk[:, 2].clip(0, n - 1), 0)
+    axis_dir = kind < 6
+    # an axis direction that leaves the cube is a boundary face: the wall below, the far field everywhere else
+    code = np.where(inside, nb, np.where(d[:, 2] < 0, -1, -2))
+    # diagonals: both ends in the prism region (only the in-plane pair), or both ends in the tetrahedral region (all eight)
+    both_prism = prism[src] & prism[nb] & inside
+    both_tet = tet[src] & tet[nb] & inside
+    in_plane = (kind == 6) | (kind == 7)
+    keep = axis_dir | (in_plane & both_prism) | ((kind >= 6) & both_tet)
+    keep &= axis_dir | inside                                                 # (a diagonal that leaves the cube is no face)
+    src, d, kind, code, inside = src[keep], d[keep], kind[keep], code[keep], inside[keep]
+    # dual-face areas: axis faces as the box's (halved on the hull); diagonal faces a fixed share of h^2
+    half_s = half[src]
+    transverse = np.ones(len(src))
+    ax = np.abs(d).argmax(axis=1)
+    for a in range(3):
+        transverse *= np.where((kind < 6) & (ax != a), half_s[:, a], 1.0)
+    length = np.linalg.norm(d, axis=1)
+    area = (h ** 2) * np.where(kind < 6, transverse, np.where(kind < 12, 0.30, 0.18))
+    if area_noise > 0.0:
+        other = np.where(code >= 0, code, src)
+        lo, hi = np.minimum(src, other), np.maximum(src, other)
+        key = (lo * 1000003 + hi * 7919 + (kind // 2) * 13) % 2147483647
+        area = area * (1.0 + area_noise * np.sin(key.astype(np.float64) * 12.9898 + seed))
+    w = d.astype(np.float64) / length[:, None] * area[:, None]
+    xyz = ijk / float(n - 1)
+    if jitter > 0.0:
+        interior = ((ijk > 0) & (ijk < n - 1)).all(axis=1)
+        xyz[interior] += jitter * h * rng.uniform(-1.0, 1.0, (int(interior.sum()), 3))
+    perm = rng.permutation(nel).astype(np.int64) if permute else np.arange(nel, dtype=np.int64)
+    new_src = perm[src]
+    new_nb = np.where(code >= 0, perm[np.clip(code, 0, nel - 1)], code)
+    tie = rng.random(len(src)) if shuffle_neighbours else np.arange(len(src), dtype=np.float64)
+    order = np.lexsort((tie, new_src))
+    counts = np.bincount(new_src, minlength=nel)
+    ptr = np.zeros(nel + 1, dtype=np.int64)
+    np.cumsum(counts, out=ptr[1:])
+    inv = np.empty(nel, dtype=np.int64)
+    inv[perm] = np.arange(nel)
+    return LevelMesh(nel=nel, volumes=volumes[inv].copy(), coords=xyz[inv].copy(), nbr_ptr=ptr,
+                     nbr_idx=new_nb[order].copy(), nbr_w=w[order].copy())
+
+
+def make_mixed_multigrid(sizes: Sequence[int], mesh_name: str = "m6wing", *, seed: int = 0, jitter: float = 0.0,
+                         area_noise: float = 0.0, volume_noise: float = 0.0, permute: bool = True, **mixed) -> MultigridMesh:
+    """A hierarchy whose level 0 is a mixed-element level (make_mixed_level) over plain lattice levels, nearest-node maps."""
+    mg = MultigridMesh(mesh_name=mesh_name)
+    for l, n in enumerate(sizes):
+        if l == 0:
+            mg.levels.append(make_mixed_level(n, seed=seed, jitter=jitter, area_noise=area_noise, volume_noise=volume_noise, permute=permute, **mixed))
+        else:
+            mg.levels.append(make_box_level(n, seed=seed + 101 * l, area_noise=area_noise, volume_noise=volume_noise, permute=permute))
+    for l in range(len(sizes) - 1):
+        mg.levels[l].mg_map = nearest_map(mg.levels[l], mg.levels[l + 1])
+    return mg
+
+
 def make_random_graph_level(nel: int, *, degree: int = 6, seed: int = 0, boundary_fraction: float = 0.1) -> LevelMesh:
     """A deliberately NON-geometric level: every node is joined to `degree` random others, so no
     numbering has locality and any 256-node cluster touches far more outside nodes than an LDS

@@ -41,6 +41,8 @@ CASES = {
     "fvcorr_1lvl_legacy_ordering": ((8,), "fvcorr", dict(seed=8, cavity_radius=0.01, volume_noise=0.02), 30, 1),
     # unstructured: Delaunay tetrahedra with median-dual metrics (sizes = node counts), degrees 4..30, wall + far-field hull faces
     "tet_2lvl": ((420, 90), "rotor37", dict(seed=4, tet=True), 4, 1),
+    # mixed element types on level 0 (hexahedral core, prism layers on a wall, tetrahedral far field: internal degrees 3..14)
+    "mixed_2lvl": ((9, 5), "m6wing", dict(seed=6, jitter=0.2, area_noise=0.05, volume_noise=0.05, mixed=True), 3, 1),
     # runs that the reference ABORTS (check_for_invalid_variables, validation.cpp:107-138): a 300-spoke hub with
     # non-physical weights, undamped; only the binary's stdout (cycle lines, ERROR line, first "Cell" line) and exit code
     "fvcorr_hub_nan": ((300,), "fvcorr", dict(seed=5, hub=1.2e-4), 40, 1),                   # NaN in cycle 7
@@ -156,7 +158,8 @@ def main():
             mg = meshgen.MultigridMesh(mesh_name=mesh_name)
             mg.levels.append(meshgen.make_hub_level(sizes[0], scale=hub, **kw))
         else:
-            mg = (meshgen.make_tet_multigrid if kw.pop("tet", False) else meshgen.make_multigrid)(sizes, mesh_name, **kw)
+            make = meshgen.make_tet_multigrid if kw.pop("tet", False) else (meshgen.make_mixed_multigrid if kw.pop("mixed", False) else meshgen.make_multigrid)
+            mg = make(sizes, mesh_name, **kw)
         meshgen.write_input(mg, os.path.join(d, "input"))
         out_dir = os.path.join(d, "_out")
         os.makedirs(out_dir)

@@ -127,6 +127,50 @@ def test_cfg2_full_size_sweeps_the_bench_times(oracle):
     s.close()
 
 
+def test_mixed_level_full_size_sweep(oracle):
+    """The non-uniform-degree headline level (bench.py --mesh mixed: hexahedral core, prism layers on a wall, tetrahedral far
+    field on the 67^3 points: 300,763 nodes / 1,004,901 internal edges, internal degrees 3 ... 14) at size: the standalone
+    flux launch and two fused sweeps against the oracle's loops, bit for bit."""
+    import bench
+    import mgcfd
+    mg, levels = bench.build_workload(67, mesh="mixed")
+    L = levels[0]
+    assert L["nel"] == 300763 and L["n_internal"] == 1004901
+    lib = oracle.load()
+    edges = np.ascontiguousarray(L["edges"]).copy()
+    coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+    lib.ora_adjust_ewt(oracle.ptr(coords), len(edges), oracle.ptr(edges))
+    lib.ora_dampen_ewt(len(edges), oracle.ptr(edges), 5e-8)
+    ff = oracle.farfield()
+    nel, ni, nb, nw = L["nel"], L["n_internal"], L["n_boundary"], L["n_wall"]
+    vol = np.ascontiguousarray(L["volumes"], dtype=np.float64)
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    q = bench.perturbed_state(nel, s.far_field()[:5])
+    s.set(0, "variables", q)
+    s.zero_fluxes(0)
+    s.compute_fluxes(0)
+    f = np.zeros_like(q)
+    lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(f))
+    lib.ora_compute_boundary_flux_edge(ni, nb, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(f))
+    lib.ora_compute_wall_flux_edge(ni + nb, nw, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(f), C.byref(ff))
+    _bits_equal(s.get(0, "fluxes"), f, "all three flux loops at size on the mixed level")
+    s.zero_fluxes(0)
+    v, sf = q.copy(), np.zeros(nel)
+    f[:] = 0.0
+    for sweep in range(2):
+        old = v.copy()
+        lib.ora_compute_step_factor(nel, oracle.ptr(v), oracle.ptr(vol), oracle.ptr(sf))
+        for j in range(3):
+            lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f))
+            lib.ora_compute_boundary_flux_edge(ni, nb, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f))
+            lib.ora_compute_wall_flux_edge(ni + nb, nw, oracle.ptr(edges), oracle.ptr(v), oracle.ptr(f), C.byref(ff))
+            lib.ora_time_step(j, nel, oracle.ptr(sf), oracle.ptr(f), oracle.ptr(old), oracle.ptr(v))
+        s.smooth(0, 1)
+        _bits_equal(s.get(0, "variables"), v, f"sweep {sweep}: variables")
+        _bits_equal(s.get(0, "residuals"), v - old, f"sweep {sweep}: residuals")
+    s.close()
+
+
 def test_cfg1_fvcorr_like_97k_nodes_1000_iterations(oracle):
     """BASELINE configs[0] in its synthetic form at its full 1,000 iterations: mesh_name = fvcorr,
     46^3 box minus its centre node = 97,335 nodes, undamped weights, local time step; state bit for bit, RMS history to

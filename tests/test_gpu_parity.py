@@ -707,7 +707,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-GOLDEN_CASES = ["m6_2lvl", "m6_3lvl", "m6_2lvl_dup2", "fvcorr_1lvl", "tet_2lvl"]
+GOLDEN_CASES = ["m6_2lvl", "m6_3lvl", "m6_2lvl_dup2", "fvcorr_1lvl", "tet_2lvl", "mixed_2lvl"]
 
 
 def _case(name):

@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ["m6_2lvl", "m6_3lvl", "fvcorr_1lvl", "tet_2lvl"]
+CASES = ["m6_2lvl", "m6_3lvl", "fvcorr_1lvl", "tet_2lvl", "mixed_2lvl"]
 
 
 @pytest.fixture(scope="module")

@@ -10,6 +10,7 @@ ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--launches", type=int, default=20)
 ap.add_argument("--fast", action="store_true")
 ap.add_argument("--tet", type=int, default=0, help="node count of a Delaunay tetrahedral level to use instead of the lattice")
+ap.add_argument("--mesh", default="lattice", choices=["lattice", "mixed"], help="bench.py --mesh")
 a = ap.parse_args()
 if a.tet:
     from mgcfd import meshgen
@@ -17,7 +18,7 @@ if a.tet:
     mg.levels.append(meshgen.make_tet_level(a.tet, seed=0))
     levels = mgcfd.generated_to_levels(mg)
 else:
-    mg, levels = bench.build_workload(a.lattice)
+    mg, levels = bench.build_workload(a.lattice, mesh=a.mesh)
 s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
 s.set(0, "variables", bench.perturbed_state(s.nel(0), s.far_field()[:5]))
 s.set_option("exact", 0 if a.fast else 1)

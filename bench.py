@@ -116,6 +116,21 @@ def build_hierarchy(sizes=HIERARCHY):
     return mg, generated_to_levels(mg)
 
 
+def injected_failure(where: str, rank: int = 0):
+    """MGCFD_BENCH_FAIL = a comma list of places where THIS run pretends something breaks on ONE rank (the last), so that the
+    form ladder's every way out can be rehearsed (tests/test_gpu_configs.py): `attach` the library's rank set-up raises, `phase`
+    the library's start-up sweep raises, `vcycle-setup` / `vcycle-cycles` the same in the V-cycle leg; `ipc-start` / `ipc-end`
+    (also MGCFD_BENCH_FAIL_IPC=start|end) make the IPC form's checks come out negative."""
+    want = [w.strip() for w in os.environ.get("MGCFD_BENCH_FAIL", "").split(",") if w.strip()]
+    if os.environ.get("MGCFD_BENCH_FAIL_IPC") in ("start", "end"):
+        want.append("ipc-" + os.environ["MGCFD_BENCH_FAIL_IPC"])
+    if where in ("ipc-start", "ipc-end"):
+        return where in want
+    if where in want and rank == int(os.environ.get("WORLD_SIZE", "1")) - 1:
+        raise RuntimeError(f"injected failure ({where}) on rank {rank}")
+    return False
+
+
 def perturbed_state(nel, ff_var, seed=1234, amplitude=0.01):
     rng = np.random.default_rng(seed)
     base = np.tile(np.asarray(ff_var, dtype=np.float64), (nel, 1))
@@ -286,6 +301,7 @@ def vcycle_partitioned(args, dist, world, rank, dev, stream, rehearsal, sizes, c
         try:
             if err:
                 raise err
+            injected_failure("vcycle-setup", rank)
             s.rank_attach_rccl(rank, world, uid[0])
             for l in range(nlev):
                 s.rank_set_halo(l, H.levels[l])
@@ -303,6 +319,7 @@ def vcycle_partitioned(args, dist, world, rank, dev, stream, rehearsal, sizes, c
             reset(lambda l: s.rank_exchange(l))
             err = None
             try:
+                injected_failure("vcycle-cycles", rank)
                 s.rank_cycles(2, rms=False)
                 same = all(np.array_equal(s.get(l, "variables").view(np.int64), want[l].view(np.int64)) for l in range(nlev))
             except Exception as e:
@@ -593,6 +610,7 @@ def main():
                 part_mode = mode; part_reset()
 
                 def one_sweep():
+                    injected_failure("phase", rank)
                     solver.rank_sweeps(0, 1)
                     torch.cuda.synchronize()
                     # (the status first: while waits that gave up are unacknowledged the library refuses to hand out the state)
@@ -600,7 +618,7 @@ def main():
                     return solver.get(0, "variables"), late_
                 got1, late = phase("the library's sweep", one_sweep)
                 same = bool(np.array_equal(got1.view(np.int64), want.view(np.int64))) and late == 0
-                if mode.startswith("ipc") and os.environ.get("MGCFD_BENCH_FAIL_IPC") == "start":
+                if mode.startswith("ipc") and injected_failure("ipc-start"):
                     same = False
                 # every rank's verdict, and whether a wait for a neighbour gave up anywhere (about 2 s each: the other IPC forms are then not tried)
                 verdict = torch.tensor([1.0 if same else 0.0, -1.0 if late else 0.0], dtype=torch.float64, device=dev)
@@ -640,17 +658,12 @@ def main():
             part_reset()
 
         def part_pick():
-            """--exchange auto: every candidate that passes its start-up check runs a short burst of sweeps; the fastest one is
-            used, the others stay behind it as fall-backs (in the order of their bursts)."""
+            """--exchange auto: every candidate that passes its start-up check — the RCCL form first, then the IPC forms — runs a
+            short burst of sweeps; the fastest one is used, the others stay behind it as fall-backs (in the order of their bursts)."""
             timed = []
-            held_back = []
             for mode in list(part_candidates):
-                if mode == "library" and timed:
-                    # (an IPC form is valid and, by the model of DESIGN.md §9.2, faster: the RCCL form — never run with more than
-                    #  one rank either — stays behind it as a fall-back and is not exercised unless it is needed)
-                    held_back.append(mode)
-                    part_notes.append("'library' kept as a fall-back, not timed: an IPC form passed its start-up check")
-                    continue
+                # (the RCCL form comes FIRST: it is the form whose every call is a documented stream-ordered one; the IPC forms,
+                #  whose hand-over between devices has never run across xGMI, are upgrades that must beat it AND pass the end check)
                 if part_try(mode):
                     part_reset()
                     for _ in range(3):
@@ -666,7 +679,6 @@ def main():
                     part_notes.append(f"start-up burst of '{mode}': {timed[-1][0] * 1e6:.0f} us per sweep")
             part_candidates.clear()
             part_candidates.extend(m for _, m in sorted(timed))
-            part_candidates.extend(held_back)
             part_next()
 
         if world == 1:
@@ -683,6 +695,7 @@ def main():
             try:
                 if setup_error:
                     raise setup_error
+                injected_failure("attach", rank)
                 if rehearsal:
                     # (every rank on device 0: RCCL refuses that; the IPC form needs no collective library at all)
                     solver.rank_attach_plain(rank, world)
@@ -691,7 +704,7 @@ def main():
                     if uid[0] is None:
                         raise RuntimeError("no RCCL unique id from rank 0")
                     solver.rank_attach_rccl(rank, world, uid[0])
-                    part_candidates = ["ipc-fused", "ipc", "ipc-unsplit", "library"] if args.exchange == "auto" else [args.exchange]
+                    part_candidates = ["library", "ipc-fused", "ipc", "ipc-unsplit"] if args.exchange == "auto" else [args.exchange]
                 solver.rank_set_halo(0, P)
             except Exception as e:
                 setup_error = e
@@ -710,11 +723,16 @@ def main():
         scaling = "strong"
         edges_per_step_all_ranks = 3 * n_int
         halo_nodes = int(halo_volume(L, part)) if world > 1 else 0
+        try:
+            extra["collectives_as_the_library_sees_them"] = solver.rank_info()    # (ranks, transport, ncclCommCount: not what the launcher said)
+        except Exception as e:
+            extra["collectives_as_the_library_sees_them"] = {"error": str(e)}
         config.update({"workload": f"M6-L0-like level tiled 8x ({lattice}^3 jittered lattice, permuted ids, connected): {nel} nodes / {n_int} "
                                    f"internal edges in total, recursive coordinate bisection into {world} part(s)",
                        "step": "compute_step_factor + all-reduce(min dt), 3 x (fused fluxes + time_step launch, halo message to every neighbouring rank), residual",
                        "parallelism": f"{world} ranks, owner computes, ghosts read-only", "halo_nodes_total": halo_nodes,
-                       "halo_bytes_per_stage_all_ranks": halo_nodes * 40, "peers_of_rank0": len(sw.peers),
+                       "halo_bytes_per_stage_all_ranks": halo_nodes * 40, "halo_bytes_per_stage_rank0_sent": int(sum(len(v) for v in P.send.values())) * 40,
+                       "library_ranks": extra.get("collectives_as_the_library_sees_them"), "peers_of_rank0": len(sw.peers),
                        "owned_nodes_rank0": int(P.n_owned), "local_internal_edges_rank0": int(P.level["n_internal"]), "exchange": exchange})
     else:                                                    # level-per-gpu
         mg, levels = build_hierarchy()
@@ -798,7 +816,7 @@ def main():
         torch.cuda.synchronize()
         ref_final = solver.get(0, "variables")
         n_diff = int(np.count_nonzero(np.any(got.view(np.int64) != ref_final.view(np.int64), axis=1)))
-        same = late == 0 and n_diff == 0 and os.environ.get("MGCFD_BENCH_FAIL_IPC") != "end"
+        same = late == 0 and n_diff == 0 and not injected_failure("ipc-end")
         if not same:
             print(f"bench.py: rank {rank}: IPC run: {late} wait(s) gave up, {n_diff} node(s) differ from the torch path's final state "
                   f"({int(np.count_nonzero(np.any(got[:P.n_owned].view(np.int64) != ref_final[:P.n_owned].view(np.int64), axis=1)))} owned)", file=sys.stderr)

@@ -395,6 +395,10 @@ int mgcfd_rank_detach(mgcfd_solver *s);
 int mgcfd_rank_set_halo(mgcfd_solver *s, int level, int n_peers, const int *peers, const int64_t *send_counts,
                         const int64_t *const *send_ids, const int64_t *recv_counts, const int64_t *const *recv_ids);
 int mgcfd_rank_halo_info(const mgcfd_solver *s, int level, int64_t out[4]);   /* boundary tiles, interior tiles, nodes sent, nodes received */
+/* What the solver is a rank of, as the library sees it: out[0] this rank, out[1] the number of ranks, out[2] the transport
+ * (0 none, 1 an RCCL communicator, 2 an in-process group, 3 plain attachment: HIP IPC messages only), out[3] the size the RCCL
+ * communicator itself reports (ncclCommCount; -1 without one). */
+int mgcfd_rank_info(const mgcfd_solver *s, int out[4]);
 int mgcfd_rank_exchange(mgcfd_solver *s, int level);          /* ghosts of `variables` <- owners (after mgcfd_set_array) */
 int mgcfd_rank_sweeps(mgcfd_solver *s, int level, int sweeps); /* the per-level body of the cycle loop, `sweeps` times; asynchronous */
 int mgcfd_rank_residual_sumsq(mgcfd_solver *s, int level, double *sum_all_ranks);

@@ -1887,6 +1887,8 @@ struct Rccl {
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;    // (optional: what the communicator itself says about its size and this rank)
+    int (*CommUserRank)(void *, int *) = nullptr;
     static constexpr int kDouble = 8, kMin = 3, kSum = 0;     // ncclDouble, ncclMin, ncclSum (rccl.h)
 };
 Rccl g_rccl;
@@ -1908,6 +1910,8 @@ void rccl_load()
     g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(sym("ncclRecv"));
     g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(sym("ncclAllReduce"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+    g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(h, "ncclCommCount"));
+    g_rccl.CommUserRank = reinterpret_cast<decltype(g_rccl.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
     g_rccl.lib = h;
 }
 #define RCCL_CHECK(x) do { const int rc_ = (x); if (rc_ != 0) throw std::runtime_error(std::string("RCCL: ") + #x + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc_) : "error")); } while (0)
@@ -3444,6 +3448,21 @@ int mgcfd_rank_cycles(mgcfd_solver *s, int cycles, double *rms_out)
     if (rc != MGCFD_OK) return rc;
     if (code != MGCFD_OK) g_last_error = "check_for_invalid_variables: invalid state during the cycles";
     return code;
+}
+
+// What a solver is a rank of, AS THE LIBRARY SEES IT: out[0] this rank, out[1] the number of ranks, out[2] the transport
+// (0 none, 1 RCCL communicator, 2 in-process group, 3 plain attachment: messages through HIP IPC only), out[3] the size the
+// RCCL communicator itself reports (ncclCommCount; -1 when there is none).
+int mgcfd_rank_info(const mgcfd_solver *s, int out[4])
+{
+    REQUIRE(s); REQUIRE(out);
+    out[0] = 0; out[1] = 1; out[2] = 0; out[3] = -1;
+    const auto it = g_comms.find(const_cast<mgcfd_solver *>(s));
+    if (it == g_comms.end()) return MGCFD_OK;
+    const mgcfd_comm &c = it->second;
+    out[0] = c.rank; out[1] = c.world; out[2] = c.rccl ? 1 : (c.group ? 2 : 3);
+    if (c.rccl && g_rccl.CommCount) { int n = -1; if (g_rccl.CommCount(c.rccl, &n) == 0) out[3] = n; }
+    return MGCFD_OK;
 }
 
 // how a level's tiles split for the overlapped exchange: out[0] boundary tiles, out[1] interior tiles, out[2] nodes sent, out[3] nodes received

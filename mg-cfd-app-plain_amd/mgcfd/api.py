@@ -135,6 +135,7 @@ _SIGNATURES = [
     ("mgcfd_rank_ipc_export", C.c_int, [_vp, C.c_int, _vp]),
     ("mgcfd_rank_ipc_attach", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_rank_ipc_status", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    ("mgcfd_rank_info", C.c_int, [_vp, C.POINTER(C.c_int)]),
     ("mgcfd_group_cycles", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_rank_cycles", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_rank_ipc_detach", C.c_int, [_vp, C.c_int]),
@@ -550,6 +551,12 @@ class Solver:
         out = (_i64 * 4)()
         self._c(self.lib.mgcfd_rank_halo_info(self.handle, l, out))
         return dict(zip(("boundary_tiles", "interior_tiles", "nodes_sent", "nodes_received"), [int(v) for v in out]))
+
+    def rank_info(self) -> dict:
+        """What this solver is a rank of, as the library sees it (mgcfd_rank_info)."""
+        out = (C.c_int * 4)()
+        self._c(self.lib.mgcfd_rank_info(self.handle, out))
+        return {"rank": out[0], "ranks": out[1], "transport": ("none", "rccl", "in-process group", "plain (HIP IPC messages)")[out[2]], "rccl_comm_count": out[3]}
 
     def rank_attach_rccl(self, rank: int, world: int, unique_id: bytes):
         buf = C.create_string_buffer(bytes(unique_id), 128)

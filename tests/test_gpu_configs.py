@@ -409,6 +409,33 @@ def test_bench_rehearsal_two_ranks_on_this_gpu():
                 assert "MG V-cycle wall-s" in line["metric"]
 
 
+@pytest.mark.parametrize("fail,expect", [("attach", "the library's rank loop not used"), ("phase", "not used"),
+                                         ("ipc-start", "differs from the torch path"), ("ipc-end", "discarded after the run")])
+def test_bench_form_ladder_survives_injected_failures(fail, expect):
+    """What the first run on several GPUs will execute, with something breaking on ONE rank at every rung of bench.py's ladder
+    (MGCFD_BENCH_FAIL, rehearsal: both ranks on this device over gloo): the library's rank set-up raising, its start-up sweep
+    raising mid-phase, the IPC form failing its start-up check, the IPC form's final state failing its check.  Every time the
+    run must END — within the bound, never a stuck rank — with a valid line from a fall-back (ultimately the torch path)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGCFD_BENCH_REHEARSAL="1", MGCFD_BENCH_FAIL=fail, MGCFD_BENCH_WATCHDOG_S="240")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--lattice", "30", "--no-vcycle"],
+                       capture_output=True, text=True, env=env, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["workload_kind"] == "partitioned"
+    ex = line["config"]["exchange"]
+    assert expect in ex, ex
+    # what the library itself says it is a rank of (not what the launcher said)
+    assert line["config"]["halo_bytes_per_stage_rank0_sent"] > 0
+    if fail == "attach":
+        assert ex.startswith("torch.distributed")                           # nothing of the library's loop was usable: the torch path ran
+    assert line["config"]["library_ranks"]["ranks"] == 2                    # (rank 0's own attachment succeeded in every case)
+
+
 def _group_sweeps_check(mg, n_parts, sweeps, partitioner="rcb"):
     """Level 0 of `mg` split into n_parts solvers, the sweeps run by the LIBRARY's own loop (mgcfd_group_sweeps: boundary
     tiles, one pack, device-to-device messages, interior tiles meanwhile, one unpack) against the unpartitioned run."""

@@ -558,6 +558,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
 {
     constexpr bool LOADK = WMODE == 1;
     static_assert(!PUSH || FUSE, "only a fused stage sends its message");
+    PH_BEGIN();
     constexpr bool IDXW = WMODE == 2;
     static_assert(!(IDXW && TAIL), "indexed weights: levels without long rows only");
     __shared__ double2 tile[kTileCap * kLdsRecD2];
@@ -697,7 +698,9 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         pm = wave_min(pm);
         if (lane == 0) s_pm[tid >> 6] = pm;
     }
+    PH_MARK(0);
     __syncthreads();
+    PH_MARK(1);
     // (the four per-wave minima stay in LDS until the epilogue: nothing of them occupies a register across the row loop)
 
     // ---- phase 2: incidence rows two at a time (independent arithmetic, ordered accumulation),
@@ -781,6 +784,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         if (r < n_int) MGCFD_ROW_PAIR();
     }
 #undef MGCFD_ROW_PAIR
+    PH_MARK(2);
 
     if (TAIL && (classes & 1) && tl_e > tl_b) {                            // (uniform)
         // Long rows.  The entries beyond the tile's row limit, one per thread whatever node they belong to: the same
@@ -886,6 +890,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
             fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
         }
+        PH_MARK(3);
         return;
     }
     // ---- fused time_step: same operations as k_time_step on the flux just summed ----
@@ -972,6 +977,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             if (fs.sumsq_partial) fs.sumsq_partial[t] = sum;
         }
     }
+    PH_MARK(3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2119,7 +2125,8 @@ k_restrict(int64_t nel_coarse, int64_t stride_coarse, int64_t stride_fine, const
         if (partial_min) sf = local_step_factor(n0, n1, n2, n3, n4, cbrt_vol[c]);
     }
     if (partial_min) block_min_to(sf, partial_min);
-    if (rms.partial && blockIdx.x == gridDim.x - 1) block_sum_partials(rms);      // (uniform per workgroup)
+    // (the workgroup dispatched FIRST adds them up: its extra microsecond ends long before the launch's last workgroups do)
+    if (rms.partial && blockIdx.x == 0) block_sum_partials(rms);                  // (uniform per workgroup)
 }
 
 // ------------------------------------------------------------------------------------------

@@ -40,14 +40,18 @@ def run():
     if os.environ.get("PH_PROBE"):        # time the indirect_rw probe instead (ablation builds)
         print(f"indirect_rw through the tiles: {s.bench_indirect_rw(0, 200) * 1e6:.2f} us; flux kernel {s.bench_flux(0, 200) * 1e6:.2f} us")
         return
-    s.bench_flux(0, 20)
+    sweep = os.environ.get("PH_SWEEP") == "1"         # the fused stages of whole sweeps instead of the standalone flux launch
+    run_ = (lambda n: (s.smooth(0, n // 3), s.synchronize(), 0.0)[2]) if sweep else (lambda n: s.bench_flux(0, n))
+    run_(21)
     lib.mgcfd_debug_phases(buf, 1)
-    t = s.bench_flux(0, 200)
+    t = run_(201)
     lib.mgcfd_debug_phases(buf, 1)
     a = np.ctypeslib.as_array(buf).reshape(4096, 8).astype(np.float64)
     n = a[:, 7].sum()
     tot = a.sum(0)
-    if variant & 64:
+    if not (variant & (64 | 32)):
+        names = ["loads + derive + stage (thread 0)", "staging barrier", "row pairs", "boundary rows + epilogue / store", "-", "-"]
+    elif variant & 64:
         names = ["loads + derive + stage (thread 0)", "staging barrier", "half rows + LDS adds", "barrier", "own sums + boundary + store", "-"]
     else:
         names = ["stage + barrier", "half rows", "barrier (records dead)", "hand-over + barrier", "ordered adds", "boundary + store"]

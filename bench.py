@@ -64,7 +64,7 @@ LATTICE = 67                 # 67^3 = 300,763 nodes, 888,822 internal edges
 LATTICE_8X = 134             # the level tiled 8x (connected): 2,406,104 nodes / 7,164,444 internal edges
 HIERARCHY = (67, 55, 48, 43) # 300,763 / 166,375 / 110,592 / 79,507 nodes
 HIERARCHY_8X = (134, 110, 96, 86)   # the same hierarchy tiled 8x (connected): 2,406,104 / 1,331,000 / 884,736 / 636,056 nodes
-TRAFFIC_PROFILE = os.path.join("profiles", "r2_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r3_traffic.json")
 ROOFLINE_LAUNCHES = 1000     # back-to-back launches of the standalone flux kernel / of its data-movement probe per measurement
 
 
@@ -106,6 +106,12 @@ def mixed_mesh_roofline(make_solver, fast: bool):
                       "ell_padding": round(til["padding_entries"] / max(til["row_entries"], 1), 4), "long_row_list_entries": til["list_entries"],
                       "overflow_refs": til["overflow_refs"]},
            "numerics": "fast (FMA contraction)" if fast else "exact (bit-identical to the reference: tests/test_gpu_configs.py::test_mixed_level_full_size_sweep)"}
+    if not fast and s.has_order_free(0):
+        s.set_option("exact", 0); s.set_option("flux_variant", 65)
+        s.bench_flux(0, ROOFLINE_LAUNCHES)
+        tf = s.bench_flux(0, ROOFLINE_LAUNCHES)
+        out["order_free"] = {"avg_kernel_us": round(tf * 1e6, 3), "frac": round(algo / tf / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "k_flux_free on this level (slices of more than five half rows per lane walk the rest in a loop); tests/test_gpu_order_free.py"}
     s.close()
     return out
 
@@ -775,7 +781,7 @@ def main():
             flux_contracted = solver.bench_flux(0, ROOFLINE_LAUNCHES)
             # ... and with ORDER-FREE accumulation on top (k_flux_free, variant bit 6, the contracted namespace only: every edge of a
             # tile evaluated once, the other end's share added to its LDS sum with ds_add_f64; tests/test_gpu_order_free.py)
-            if args.variant == -1 and solver.has_half_rows(0):
+            if args.variant == -1 and solver.has_order_free(0):
                 solver.set_option("flux_variant", 65)
                 solver.bench_flux(0, ROOFLINE_LAUNCHES)
                 flux_free = solver.bench_flux(0, ROOFLINE_LAUNCHES)
@@ -899,6 +905,7 @@ def main():
                                                       "(north_star allows 1e-10); the line's other figures are the bit-identical mode"}
             if flux_free:
                 roof["order_free"] = {"avg_kernel_us": round(flux_free * 1e6, 3), "launches": ROOFLINE_LAUNCHES,
+                                      "traffic": traffic.get("flux_order_free", {}).get("bytes"),
                                       "frac": round(bytes_flux / flux_free / 1e9 / HBM_PEAK_GBS, 4),
                                       "medges_per_s": round(n_int / flux_free / 1e6, 1),
                                       "kernel": "k_flux_free (MGCFD_OPT_EXACT = 0, MGCFD_OPT_FLUX_VARIANT = 65): one 28-byte entry per edge and tile, -F added to the other "

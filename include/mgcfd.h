@@ -195,6 +195,9 @@ int mgcfd_level_has_edge_once(const mgcfd_solver *s, int level, int *yes);
 /* *yes = 1 when level `level` can run the half-row flux kernel (MGCFD_OPT_FLUX_VARIANT bit 5): no long rows, no halo node
  * left outside LDS, at most 5 edges evaluated per node. */
 int mgcfd_level_has_half_rows(const mgcfd_solver *s, int level, int *yes);
+/* *yes = 1 when level `level` can run the order-free flux kernel (MGCFD_OPT_FLUX_VARIANT bit 6 with MGCFD_OPT_EXACT = 0): no halo
+ * node left outside LDS; any number of edges per node (what a lane's five requested rows do not hold is walked in a loop). */
+int mgcfd_level_has_order_free(const mgcfd_solver *s, int level, int *yes);
 /* What the tiling of level `level` looks like (the figures MGCFD_VERBOSE=1 prints at creation):
  * out[0] tiles of 256 nodes, out[1] halo nodes of all tiles together, out[2] the largest halo, out[3] halo nodes a
  * tile can stage in LDS, out[4] incidence-row entries that refer to a halo node beyond that (each a gather from

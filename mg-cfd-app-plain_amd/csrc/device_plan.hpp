@@ -141,6 +141,8 @@ struct DevicePlan {
     double *te_w3 = nullptr;            // [chunk*256 + p][3]: the same a-side weights as 24-byte records (k_flux_tile WMODE 2)
     // half rows (preprocess.hpp: LevelPlan::hr_*); half == 0: not available on this level
     int half = 0;
+    int free_rows = 0;                  // the half-row plan is present at all (k_flux_free; `half`: k_flux_half can run on it too)
+    int32_t hr_max_rows = 0;            // the most half rows a slice holds
     int32_t hr_pad_row = 0;             // index of a half row of padding after the last one
     int32_t *hr_row0 = nullptr;         // [n_slices+1]
     uint32_t *hr_code = nullptr;        // [half row][64]

@@ -1462,7 +1462,8 @@ __device__ __forceinline__ void lds_add(double *p, double v) { unsafeAtomicAdd(p
 
 // CAP: nodes a tile may stage.  kFreeCap4 (halos of at most 290 nodes) lets four workgroups share a CU, kTileCap three.
 constexpr int kFreeCap4 = 546;
-template <bool FUSE, bool ACC, int CAP>
+// LONG: some slice of the level holds more half rows than the prologue requests (the loop behind the unrolled pairs exists)
+template <bool FUSE, bool ACC, int CAP, bool LONG>
 __global__ void __launch_bounds__(kBlock, CAP <= kFreeCap4 ? 4 : 3)
 k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue's first loads need)
             const double *__restrict__ q, const int32_t *__restrict__ tile_halo, uint32_t n_tiles, int32_t hr_pad_row,
@@ -1565,6 +1566,18 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
         } else {
             eval(er[j], false);
             if (two) eval(er[j + 1 < kHalfMaxRows ? j + 1 : j], false);
+        }
+    }
+    // a slice with more half rows than the prologue requests (tetrahedral regions, hubs: the plan spreads a high-degree node's
+    // evaluations over the tile's lanes, preprocess.hpp kFreeMaxRows): the rest one at a time, two in flight
+    if (LONG && n_h > kHalfMaxRows) {               // (uniform over the wave)
+        EdgeRow x0 = load_half_row(hr_code, hr_w, h0 + kHalfMaxRows, lane);
+        EdgeRow x1 = load_half_row(hr_code, hr_w, kHalfMaxRows + 1 < n_h ? h0 + kHalfMaxRows + 1 : hr_pad_row, lane);
+        for (int32_t j = kHalfMaxRows; j < n_h; j++) {
+            const EdgeRow x2 = load_half_row(hr_code, hr_w, j + 2 < n_h ? h0 + j + 2 : hr_pad_row, lane);
+            if (__any((x0.code & kHalfForeign) != 0)) eval(x0, true);
+            else eval(x0, false);
+            x0 = x1; x1 = x2;
         }
     }
     PH_MARK(2);
@@ -2407,11 +2420,13 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     }
 #ifdef MGCFD_ORDER_FREE
     // variant bit 6 (64), this namespace only: order-free accumulation over the half-row plan (k_flux_free)
-    if ((variant & 64) && p.half && (classes & 1) && !(fused && fs.vin_flux) && !part) {
-#define MGCFD_FREE_LAUNCH_C(FUSE, ACC, CAP)                                                                     \
-    hipLaunchKernelGGL((k_flux_free<FUSE, ACC, CAP>), grid, block, 0, st, q, p.tile_halo, uint32_t(p.n_tiles),  \
+    if ((variant & 64) && p.free_rows && (classes & 1) && !(fused && fs.vin_flux) && !part) {
+#define MGCFD_FREE_LAUNCH_L(FUSE, ACC, CAP, LONG)                                                               \
+    hipLaunchKernelGGL((k_flux_free<FUSE, ACC, CAP, LONG>), grid, block, 0, st, q, p.tile_halo, uint32_t(p.n_tiles), \
                        p.hr_pad_row, p.stride, p.nel, p.hr_row0, p.hr_code, p.hr_w, p.slice_row0,               \
                        p.rows_int, p.rows_bnd, p.nbr16, p.w, ff, fluxes, classes, fs)
+#define MGCFD_FREE_LAUNCH_C(FUSE, ACC, CAP)                                                                     \
+    do { if (p.hr_max_rows > kHalfMaxRows) MGCFD_FREE_LAUNCH_L(FUSE, ACC, CAP, true); else MGCFD_FREE_LAUNCH_L(FUSE, ACC, CAP, false); } while (0)
         // (four workgroups per CU where every tile's halo fits the smaller LDS image, three otherwise; MGCFD_FREE_WG3=1: always three, for A/B)
         static const bool wg3 = std::getenv("MGCFD_FREE_WG3") && std::atoi(std::getenv("MGCFD_FREE_WG3")) != 0;
 #define MGCFD_FREE_LAUNCH(FUSE, ACC)                                                                            \
@@ -2420,6 +2435,7 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
         else if (accumulate) MGCFD_FREE_LAUNCH(false, true);
         else MGCFD_FREE_LAUNCH(false, false);
 #undef MGCFD_FREE_LAUNCH_C
+#undef MGCFD_FREE_LAUNCH_L
 #undef MGCFD_FREE_LAUNCH
         return;
     }

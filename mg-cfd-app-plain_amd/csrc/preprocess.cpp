@@ -468,7 +468,8 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         std::vector<int32_t> halo, tile_edges;
         std::vector<std::array<int64_t, 4>> half_ents;      // {edge, entry index, thread of the node, its half row or -1}
         std::vector<std::pair<int32_t, int32_t>> half_where;
-        P.half = true;
+        P.free_rows = true;
+        P.hr_max_rows = P.hr_max_tile_rows = 0;
         P.hr_row0.assign(static_cast<size_t>(P.n_slices) + 1, 0);
         P.hr_code.clear(); P.hr_w.clear(); P.hr_foreign = 0;
         P.hg16.assign(P.nbr.size(), static_cast<uint16_t>(kT16Pad));
@@ -596,8 +597,8 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             // slice has rows left (the evaluator then has its record in registers), otherwise in any lane with a free
             // slot ("foreign": that lane reads the owner's record from LDS as well).  A tile gets ceil(evaluations / 64)
             // half rows, spread over its slices in proportion to what their nodes own, so slots are ~98 % used.
-            if (P.half) {
-                if (n_halo > staged) P.half = false;
+            if (P.free_rows) {
+                if (n_halo > staged) P.free_rows = false;
                 const int32_t n_here = static_cast<int32_t>(std::min<int64_t>(kTile, nel - base));
                 int32_t own[kTile] = {0};
                 half_ents.clear();
@@ -623,23 +624,24 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                 for (int32_t sl = 0; sl < kTile / kSlice; sl++) {
                     // floor of the slice's mean — never more than a lane keeps in registers (k_flux_half walks kHalfMaxRows half
                     // rows at most: what a slice cannot hold goes to the other slices' lanes, or the level runs the node gather)
-                    rows_h[sl] = lanes[sl] ? std::min<int32_t>(kHalfMaxRows, own_slice[sl] / lanes[sl]) : 0;
+                    rows_h[sl] = lanes[sl] ? std::min<int32_t>(kFreeMaxRows, own_slice[sl] / lanes[sl]) : 0;
                     cap_total += rows_h[sl] * lanes[sl];
                 }
                 while (cap_total < n_eval) {
                     int32_t best = -1; double need = -1.0;
                     for (int32_t sl = 0; sl < kTile / kSlice; sl++) {
-                        if (!lanes[sl] || rows_h[sl] >= kHalfMaxRows) continue;
+                        if (!lanes[sl] || rows_h[sl] >= kFreeMaxRows) continue;
                         const double d = double(own_slice[sl]) / lanes[sl] - rows_h[sl];      // how far the slice's mean is above its rows
                         if (d > need) { need = d; best = sl; }
                     }
-                    if (best < 0) { P.half = false; break; }
+                    if (best < 0) { P.free_rows = false; break; }
                     rows_h[best]++; cap_total += lanes[best];
                 }
                 for (int32_t sl = 0; sl < kTile / kSlice; sl++)
                     P.hr_row0[static_cast<size_t>(s0 + sl) + 1] = P.hr_row0[static_cast<size_t>(s0 + sl)] + rows_h[sl];
-                if (P.hr_row0[static_cast<size_t>(s1)] - P.hr_row0[static_cast<size_t>(s0)] > kHalfTileRows) P.half = false;
-                if (P.half) {
+                for (int32_t sl = 0; sl < kTile / kSlice; sl++) P.hr_max_rows = std::max(P.hr_max_rows, rows_h[sl]);
+                P.hr_max_tile_rows = std::max(P.hr_max_tile_rows, P.hr_row0[static_cast<size_t>(s1)] - P.hr_row0[static_cast<size_t>(s0)]);
+                if (P.free_rows) {
                     const size_t rows_end = static_cast<size_t>(P.hr_row0[static_cast<size_t>(s1)]);
                     P.hr_code.resize(rows_end * kSlice, kHalfPad);
                     P.hr_w.resize(rows_end * 3 * kSlice, 0.0);
@@ -794,9 +796,10 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     P.tail_tile_ptr[static_cast<size_t>(P.n_tiles)] = static_cast<int32_t>(P.tail_rec.size() / 6);
     P.tail_total = static_cast<int64_t>(P.tail_rec.size() / 6);
     if (!P.has_tail) { P.tail_begin.clear(); P.tail_count.clear(); }
-    // half rows: levels without long rows whose every slice fits the per-thread row limit
-    if (P.has_tail) P.half = false;
-    if (!P.half) { P.hr_row0.clear(); P.hr_code.clear(); P.hr_w.clear(); P.hg16.clear(); P.hr_entries = 0; P.hr_foreign = 0; }
+    // the ordered half-row kernel: levels without long rows whose every slice fits the per-thread row limit and every tile the
+    // flux terms' LDS image; the order-free kernel (free_rows) takes any row count
+    P.half = P.free_rows && !P.has_tail && P.hr_max_rows <= kHalfMaxRows && P.hr_max_tile_rows <= kHalfTileRows;
+    if (!P.free_rows) { P.hr_row0.clear(); P.hr_code.clear(); P.hr_w.clear(); P.hg16.clear(); P.hr_entries = 0; P.hr_foreign = 0; }
     else P.hr_padding = int64_t(P.hr_row0.back()) * kSlice - P.hr_entries;
 
     P.n_internal_entries = useful;
@@ -1014,13 +1017,13 @@ std::string audit_level_plan(const mgcfd_level_desc &L, const LevelPlan &P, int6
                 if (nc > 0 && (nb < b || nb + nc > e)) bad(8, "tile " + S(t) + ": a node's list entries leave its tile's range");
             }
         }
-        if (P.half) {
+        if (P.free_rows) {
             const int32_t r0 = P.hr_row0[size_t(s0)], r1 = P.hr_row0[size_t(s0) + kTile / kSlice];
-            if (r1 - r0 > kHalfTileRows) bad(9, "tile " + S(t) + ": " + S(r1 - r0) + " half rows exceed what the flux terms' LDS image holds");
+            if (P.half && r1 - r0 > kHalfTileRows) bad(9, "tile " + S(t) + ": " + S(r1 - r0) + " half rows exceed what the flux terms' LDS image holds");
             if (staged != (P.tile_halo_ptr[size_t(t) + 1] - P.tile_halo_ptr[size_t(t)]) || n_ovf != 0) bad(9, "tile " + S(t) + ": half rows on a tile with unstaged halo nodes");
             for (int32_t sl = s0; sl < s0 + kTile / kSlice; sl++) {
                 const int32_t n_h = P.hr_row0[size_t(sl) + 1] - P.hr_row0[size_t(sl)];
-                if (n_h < 0 || n_h > kHalfMaxRows) bad(9, "slice " + S(sl) + ": " + S(n_h) + " half rows per lane (a lane keeps " + S(kHalfMaxRows) + ")");
+                if (n_h < 0 || n_h > (P.half ? kHalfMaxRows : kFreeMaxRows)) bad(9, "slice " + S(sl) + ": " + S(n_h) + " half rows per lane (a lane keeps " + S(kHalfMaxRows) + ")");
                 for (int64_t row = P.hr_row0[size_t(sl)]; row < P.hr_row0[size_t(sl) + 1]; row++)
                     for (int lane = 0; lane < kSlice; lane++) {
                         const uint32_t c = P.hr_code[size_t(row) * kSlice + lane];

@@ -41,6 +41,7 @@ constexpr uint32_t kHalfMirror = 1u << 25;    // the edge lies inside the tile a
                                               // negated terms (k_flux_free adds them to that node's LDS sum; k_flux_half hands them over by position)
 constexpr uint32_t kHalfPad = 0x00007FFFu;   // (low 15 bits = kT16Pad)
 constexpr int kHalfMaxRows = 5;            // half rows (edges a node evaluates) a thread keeps the results of in registers
+constexpr int kFreeMaxRows = 32;           // ... and what a slice may hold at all: the order-free kernel walks the rows beyond five in a loop
 constexpr int kHalfTileRows = 21;          // half rows of a tile's four slices together (21 * 64 * 40 B = the whole LDS tile)
 constexpr int kHalfSlots = kHalfTileRows * kSlice;   // flux-term slots of a tile in LDS: 5 fields x 1344 x 8 B = 52.5 KiB (its own array in k_flux_half)
 constexpr int kHalfLdsD2 = (5 * kHalfSlots + 1) / 2;   // double2 the half-row kernel's flux terms take in LDS (they replace the node records)
@@ -106,7 +107,10 @@ struct LevelPlan {
     //      every node then adds its incident edges in row order from there (hg16: position | kT16RoleB when the entry's
     //      edge was evaluated by the OTHER end point: that node adds the negated terms, which is what the reference's
     //      expressions for the other end evaluate to bit for bit) ----
-    bool half = false;                    // false: some slice needs more than kHalfMaxRows rows (a tile more than kHalfTileRows), or a tile has unstaged halo nodes
+    bool free_rows = false;               // the half-row plan exists (k_flux_free can run): every tile's halo is staged in LDS
+    bool half = false;                    // ... and k_flux_half can run on it too: no slice needs more than kHalfMaxRows rows, no tile more than
+                                          // kHalfTileRows, no long rows
+    int32_t hr_max_rows = 0, hr_max_tile_rows = 0;
     std::vector<int32_t> hr_row0;         // [n_slices+1] first half row of each slice
     std::vector<uint32_t> hr_code;        // [half rows*64] low 16 bits as nbr16 (the other end's LDS slot | kT16RoleB when the OWNING end
                                           //   is the edge's b end), bits 16-23 the owning node's thread, kHalfForeign when the slot

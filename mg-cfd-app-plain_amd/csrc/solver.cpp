@@ -767,7 +767,9 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
             lv.dp.gat16 = dev_upload(P.gat16);
         }
         lv.dp.half = (P.half && !std::getenv("MGCFD_NO_HALF_ROWS")) ? 1 : 0;
-        if (lv.dp.half) {
+        lv.dp.free_rows = (P.free_rows && !std::getenv("MGCFD_NO_HALF_ROWS")) ? 1 : 0;
+        lv.dp.hr_max_rows = P.hr_max_rows;
+        if (lv.dp.free_rows) {
             lv.dp.hr_pad_row = P.hr_row0.back();
             lv.dp.hr_row0 = dev_upload(P.hr_row0);
             lv.plan.hr_code.resize(P.hr_code.size() + 2 * kSlice, kHalfPad);      // two half rows of padding
@@ -1001,6 +1003,13 @@ int mgcfd_level_has_half_rows(const mgcfd_solver *s, int level, int *yes)
     REQUIRE(s); REQUIRE(yes);
     if (level < 0 || level >= static_cast<int>(s->L.size())) { g_last_error = "level out of range"; return MGCFD_ERR_ARG; }
     *yes = s->L[static_cast<size_t>(level)].dp.half;
+    return MGCFD_OK;
+}
+int mgcfd_level_has_order_free(const mgcfd_solver *s, int level, int *yes)
+{
+    REQUIRE(s); REQUIRE(yes);
+    if (level < 0 || level >= static_cast<int>(s->L.size())) { g_last_error = "level out of range"; return MGCFD_ERR_ARG; }
+    *yes = s->L[static_cast<size_t>(level)].dp.free_rows;
     return MGCFD_OK;
 }
 int mgcfd_level_has_edge_once(const mgcfd_solver *s, int level, int *yes)

@@ -71,6 +71,7 @@ _SIGNATURES = [
     ("mgcfd_level_has_edge_once", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_level_has_half_rows", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_pending_invalid_state", C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    ("mgcfd_level_has_order_free", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_level_tiling", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
     ("mgcfd_invalid_state_location", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     ("mgcfd_get_option", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
@@ -371,6 +372,11 @@ class Solver:
     def has_half_rows(self, l: int) -> bool:
         yes = C.c_int(0)
         self._c(self.lib.mgcfd_level_has_half_rows(self.handle, l, C.byref(yes)))
+        return bool(yes.value)
+
+    def has_order_free(self, l: int) -> bool:
+        yes = C.c_int(0)
+        self._c(self.lib.mgcfd_level_has_order_free(self.handle, l, C.byref(yes)))
         return bool(yes.value)
 
     def has_edge_once(self, l: int) -> bool:

@@ -43,7 +43,7 @@ def test_order_free_flux_kernels_against_the_oracle(oracle, mesh3_dir):
         L = case.levels[l]
         lib.ora_adjust_ewt(L.coords, L.n_edges, L.edges)
         lib.ora_dampen_ewt(L.n_edges, L.edges, 5e-8)
-        ran_free += int(s.has_half_rows(l))
+        ran_free += int(s.has_order_free(l))
         q = perturbed_state(L.nel, ff.var, seed=900 + l)
         f0 = np.random.default_rng(17 + l).normal(size=(L.nel, 5)) * 1e-7
         steps = [(lambda f: lib.ora_compute_flux_edge(L.internal_start, L.n_internal, L.edges, oracle.ptr(q), oracle.ptr(f)), s.compute_flux_edge),
@@ -111,7 +111,7 @@ def test_order_free_is_off_in_the_exact_namespace_and_where_no_plan_exists(oracl
         s = mgcfd.Solver.from_arrays(lv, rg.mesh_variant)
         s.set_option("exact", 0)
         s.set_option("flux_variant", v)
-        assert not s.has_half_rows(0)
+        assert not s.has_order_free(0)                       # (tiles with halo nodes beyond the LDS image)
         s.set(0, "variables", q)
         s.compute_fluxes(0)
         res[v] = s.get(0, "fluxes").copy()
@@ -138,7 +138,7 @@ def test_order_free_at_full_size(oracle):
     s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
     s.set_option("exact", 0)
     s.set_option("flux_variant", FREE)
-    assert s.has_half_rows(0)
+    assert s.has_order_free(0)
     q = bench.perturbed_state(nel, s.far_field()[:5])
     s.set(0, "variables", q)
     s.zero_fluxes(0)
@@ -169,10 +169,57 @@ def test_order_free_at_full_size(oracle):
     s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
     s.set_option("exact", 0)
     s.set_option("flux_variant", FREE)
-    assert all(s.has_half_rows(l) for l in range(4))
+    assert all(s.has_order_free(l) for l in range(4))
     rms = s.run_cycles(cycles)
     got = s.get(0, "variables")
     assert _rel(got, keep[0]["variables"]) <= REL_RUN, "level-0 variables after 25 V-cycles"
     assert lib.ora_identify_differences(oracle.ptr(np.ascontiguousarray(got)), oracle.ptr(keep[0]["variables"]), levels[0]["nel"], mg.mesh_variant) == -1
     assert np.allclose(rms, want_rms, rtol=1e-9, atol=0)
     s.close()
+
+
+def test_order_free_on_levels_of_non_uniform_degree(oracle):
+    """Slices with more than five half rows per lane (the loop behind the prologue's five): the mixed-element level at size
+    (internal degrees 3 ... 14: 300,763 nodes / 1,004,901 edges) and a small mixed hierarchy through whole cycles, against the
+    oracle's loops."""
+    import bench
+    import mgcfd
+    from mgcfd import meshgen
+    lib = oracle.load()
+    ff = oracle.farfield()
+    mg, levels = bench.build_workload(67, mesh="mixed")
+    L = levels[0]
+    edges = np.ascontiguousarray(L["edges"]).copy()
+    coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+    lib.ora_adjust_ewt(oracle.ptr(coords), len(edges), oracle.ptr(edges))
+    lib.ora_dampen_ewt(len(edges), oracle.ptr(edges), 5e-8)
+    nel, ni, nb, nw = L["nel"], L["n_internal"], L["n_boundary"], L["n_wall"]
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    s.set_option("exact", 0)
+    s.set_option("flux_variant", FREE)
+    assert s.has_order_free(0) and not s.has_half_rows(0)       # (more than five evaluations per lane somewhere: the ordered half-row kernel declines)
+    q = bench.perturbed_state(nel, s.far_field()[:5])
+    s.set(0, "variables", q)
+    s.zero_fluxes(0)
+    s.compute_fluxes(0)
+    f = np.zeros_like(q)
+    lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(f))
+    lib.ora_compute_boundary_flux_edge(ni, nb, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(f))
+    lib.ora_compute_wall_flux_edge(ni + nb, nw, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(f), C.byref(ff))
+    assert _rel(s.get(0, "fluxes"), f) <= REL_LAUNCH
+    s.close()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        mgs = meshgen.make_mixed_multigrid((11, 6), "m6wing", seed=2, jitter=0.2, area_noise=0.05, volume_noise=0.05)
+        meshgen.write_input(mgs, d)
+        s = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", d))
+        s.set_option("exact", 0)
+        s.set_option("flux_variant", FREE)
+        assert s.has_order_free(0)
+        s.run_cycles(5)
+        case = oracle.OracleCase.from_input_dat(d + "/input.dat")
+        rc, _, _ = case.solve(5)
+        assert rc == 0
+        for l in range(2):
+            assert _rel(s.get(l, "variables"), case.array(l, "variables").reshape(-1, 5)) <= REL_RUN
+        s.close()

@@ -143,6 +143,8 @@ struct DevicePlan {
     int half = 0;
     int free_rows = 0;                  // the half-row plan is present at all (k_flux_free; `half`: k_flux_half can run on it too)
     int32_t hr_max_rows = 0;            // the most half rows a slice holds
+    int free_wide = 0;                  // some tile's halo exceeds kHaloStride: k_flux_free stages from free_halo ([n_tiles][kFreeHaloStride])
+    int32_t *free_halo = nullptr;
     int32_t hr_pad_row = 0;             // index of a half row of padding after the last one
     int32_t *hr_row0 = nullptr;         // [n_slices+1]
     uint32_t *hr_code = nullptr;        // [half row][64]

@@ -1463,7 +1463,9 @@ __device__ __forceinline__ void lds_add(double *p, double v) { unsafeAtomicAdd(p
 // CAP: nodes a tile may stage.  kFreeCap4 (halos of at most 290 nodes) lets four workgroups share a CU, kTileCap three.
 constexpr int kFreeCap4 = 546;
 // LONG: some slice of the level holds more half rows than the prologue requests (the loop behind the unrolled pairs exists)
-template <bool FUSE, bool ACC, int CAP, bool LONG>
+// WIDE: some tile's halo exceeds the shared table's 303 ids: the halo comes from the kernel's own table, two ids per thread
+//       (tile_halo then points at it, stride kFreeHaloStride; CAP = kTile + kFreeHaloStride)
+template <bool FUSE, bool ACC, int CAP, bool LONG, bool WIDE = false>
 __global__ void __launch_bounds__(kBlock, CAP <= kFreeCap4 ? 4 : 3)
 k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue's first loads need)
             const double *__restrict__ q, const int32_t *__restrict__ tile_halo, uint32_t n_tiles, int32_t hr_pad_row,
@@ -1489,9 +1491,9 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
 
     // load issue order as in k_flux_tile: halo ids, own state, the first two half rows, then the halo state by id;
     // nothing under a branch
-    const int32_t *hrow = tile_halo + int64_t(t) * kHaloStride;
+    const int32_t *hrow = tile_halo + int64_t(t) * (WIDE ? kFreeHaloStride : kHaloStride);
     const int32_t hid = hrow[tid];
-    const int32_t hid2 = tid < kHaloStride - kBlock ? hrow[kBlock + tid] : -1;
+    const int32_t hid2 = (WIDE || tid < kHaloStride - kBlock) ? hrow[kBlock + tid] : -1;
     const int32_t h0 = hr_row0[slice];
     const int32_t n_h = (classes & 1) ? hr_row0[slice + 1] - h0 : 0;
     const int32_t n_bnd = rows_bnd[slice];
@@ -1504,13 +1506,18 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
     for (int j = 0; j < kHalfMaxRows; j++) er[j] = load_half_row(hr_code, hr_w, j < n_h ? h0 + j : hr_pad_row, lane);
     const int64_t hnode = hid >= 0 ? int64_t(hid) : i;
     const double g0 = q[hnode], g1 = q[stride + hnode], g2 = q[2 * stride + hnode], g3 = q[3 * stride + hnode], g4 = q[4 * stride + hnode];
+    // (WIDE: the second halo node of every thread as unconditionally as the first)
+    const int64_t hnode2 = (WIDE && hid2 >= 0) ? int64_t(hid2) : i;
+    double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0, u4 = 0.0;
+    if (WIDE) { u0 = q[hnode2]; u1 = q[stride + hnode2]; u2 = q[2 * stride + hnode2]; u3 = q[3 * stride + hnode2]; u4 = q[4 * stride + hnode2]; }
 
 #pragma unroll
     for (int f = 0; f < 5; f++) acc[f * kTile + tid] = 0.0;
     const NodeF me = make_nodef(o0, o1, o2, o3, o4);
     lds_store_nodef(tile, scs, uint32_t(tid), me);
     lds_store_nodef(tile, scs, uint32_t(kTile + tid), make_nodef(g0, g1, g2, g3, g4));          // unconditional, see k_flux_tile
-    if (hid2 >= 0) {
+    if (WIDE) lds_store_nodef(tile, scs, uint32_t(kTile + kBlock + tid), make_nodef(u0, u1, u2, u3, u4));
+    else if (hid2 >= 0) {
         const int64_t h = hid2;
         lds_store_nodef(tile, scs, uint32_t(kTile + kBlock + tid), make_nodef(q[h], q[stride + h], q[2 * stride + h], q[3 * stride + h], q[4 * stride + h]));
     }
@@ -2427,15 +2434,22 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
                        p.rows_int, p.rows_bnd, p.nbr16, p.w, ff, fluxes, classes, fs)
 #define MGCFD_FREE_LAUNCH_C(FUSE, ACC, CAP)                                                                     \
     do { if (p.hr_max_rows > kHalfMaxRows) MGCFD_FREE_LAUNCH_L(FUSE, ACC, CAP, true); else MGCFD_FREE_LAUNCH_L(FUSE, ACC, CAP, false); } while (0)
+        // (a level with halos beyond the shared table: the kernel's own table of kFreeHaloStride ids per tile, 768 LDS images)
+#define MGCFD_FREE_LAUNCH_W(FUSE, ACC)                                                                          \
+    hipLaunchKernelGGL((k_flux_free<FUSE, ACC, kTile + kFreeHaloStride, true, true>), grid, block, 0, st, q, p.free_halo, uint32_t(p.n_tiles), \
+                       p.hr_pad_row, p.stride, p.nel, p.hr_row0, p.hr_code, p.hr_w, p.slice_row0,               \
+                       p.rows_int, p.rows_bnd, p.nbr16, p.w, ff, fluxes, classes, fs)
         // (four workgroups per CU where every tile's halo fits the smaller LDS image, three otherwise; MGCFD_FREE_WG3=1: always three, for A/B)
         static const bool wg3 = std::getenv("MGCFD_FREE_WG3") && std::atoi(std::getenv("MGCFD_FREE_WG3")) != 0;
 #define MGCFD_FREE_LAUNCH(FUSE, ACC)                                                                            \
-    do { if (p.halo_max <= kFreeCap4 - kTile && !wg3) MGCFD_FREE_LAUNCH_C(FUSE, ACC, kFreeCap4); else MGCFD_FREE_LAUNCH_C(FUSE, ACC, kTileCap); } while (0)
+    do { if (p.free_wide) MGCFD_FREE_LAUNCH_W(FUSE, ACC);                                                       \
+         else if (p.halo_max <= kFreeCap4 - kTile && !wg3) MGCFD_FREE_LAUNCH_C(FUSE, ACC, kFreeCap4); else MGCFD_FREE_LAUNCH_C(FUSE, ACC, kTileCap); } while (0)
         if (fused) MGCFD_FREE_LAUNCH(true, false);
         else if (accumulate) MGCFD_FREE_LAUNCH(false, true);
         else MGCFD_FREE_LAUNCH(false, false);
 #undef MGCFD_FREE_LAUNCH_C
 #undef MGCFD_FREE_LAUNCH_L
+#undef MGCFD_FREE_LAUNCH_W
 #undef MGCFD_FREE_LAUNCH
         return;
     }

@@ -470,6 +470,9 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         std::vector<std::pair<int32_t, int32_t>> half_where;
         P.free_rows = true;
         P.hr_max_rows = P.hr_max_tile_rows = 0;
+        P.free_wide = false;
+        P.free_halo.clear();
+        std::vector<int32_t> halo_all;                  // a tile's halo ids, ALL of them ascending (the order-free kernel's own numbering)
         P.hr_row0.assign(static_cast<size_t>(P.n_slices) + 1, 0);
         P.hr_code.clear(); P.hr_w.clear(); P.hr_foreign = 0;
         P.hg16.assign(P.nbr.size(), static_cast<uint16_t>(kT16Pad));
@@ -598,7 +601,14 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             // slot ("foreign": that lane reads the owner's record from LDS as well).  A tile gets ceil(evaluations / 64)
             // half rows, spread over its slices in proportion to what their nodes own, so slots are ~98 % used.
             if (P.free_rows) {
-                if (n_halo > staged) P.free_rows = false;
+                // the order-free kernel stages EVERY halo node (no overflow table): up to kHaloStride from the shared table, beyond
+                // that — up to kFreeHaloStride — from a table of its own, slots counted in the ascending list of all of them
+                halo_all.assign(halo.begin(), halo.end());
+                std::sort(halo_all.begin(), halo_all.end());
+                if (n_halo > kFreeHaloStride) P.free_rows = false;
+                if (n_halo > staged) P.free_wide = true;
+                P.free_halo.resize(static_cast<size_t>(t + 1) * kFreeHaloStride, -1);
+                if (P.free_rows) std::copy(halo_all.begin(), halo_all.end(), P.free_halo.begin() + static_cast<size_t>(t) * kFreeHaloStride);
                 const int32_t n_here = static_cast<int32_t>(std::min<int64_t>(kTile, nel - base));
                 int32_t own[kTile] = {0};
                 half_ents.clear();
@@ -653,7 +663,13 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                         const size_t hrow = static_cast<size_t>(P.hr_row0[static_cast<size_t>(s0 + sl)]) + static_cast<size_t>(j);
                         const int64_t e = en[1];
                         const bool only = half_eval_a[static_cast<size_t>(en[0])] >= 0;     // (an edge inside the tile: nobody else evaluates it)
-                        P.hr_code[hrow * kSlice + lane] = uint32_t(P.nbr16[static_cast<size_t>(e)]) | (uint32_t(owner) << 16) | (host != owner ? kHalfForeign : 0u)
+                        // (the other end's LDS slot: own nodes as in nbr16; a halo node by its position among ALL the tile's halo ids —
+                        //  the same slot as nbr16's wherever the tile has no overflow entries)
+                        const int32_t other = P.nbr[static_cast<size_t>(e)] & kIdMask;
+                        const uint32_t oslot = (other >= base && other < base + kTile) ? uint32_t(other - base)
+                                             : uint32_t(kTile + (std::lower_bound(halo_all.begin(), halo_all.end(), other) - halo_all.begin()));
+                        const uint32_t c16 = oslot | ((P.nbr[static_cast<size_t>(e)] & kRoleB) ? kT16RoleB : 0u);
+                        P.hr_code[hrow * kSlice + lane] = c16 | (uint32_t(owner) << 16) | (host != owner ? kHalfForeign : 0u)
                                                           | (only ? kHalfMirror : 0u);
                         const EdgeW &W = P.w[static_cast<size_t>(e)];
                         P.hr_w[(hrow * 3 + 0) * kSlice + lane] = W.x;
@@ -798,7 +814,8 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     if (!P.has_tail) { P.tail_begin.clear(); P.tail_count.clear(); }
     // the ordered half-row kernel: levels without long rows whose every slice fits the per-thread row limit and every tile the
     // flux terms' LDS image; the order-free kernel (free_rows) takes any row count
-    P.half = P.free_rows && !P.has_tail && P.hr_max_rows <= kHalfMaxRows && P.hr_max_tile_rows <= kHalfTileRows;
+    P.half = P.free_rows && !P.free_wide && !P.has_tail && P.hr_max_rows <= kHalfMaxRows && P.hr_max_tile_rows <= kHalfTileRows;
+    if (!P.free_rows || !P.free_wide) { P.free_halo.clear(); P.free_halo.shrink_to_fit(); }
     if (!P.free_rows) { P.hr_row0.clear(); P.hr_code.clear(); P.hr_w.clear(); P.hg16.clear(); P.hr_entries = 0; P.hr_foreign = 0; }
     else P.hr_padding = int64_t(P.hr_row0.back()) * kSlice - P.hr_entries;
 
@@ -1020,7 +1037,7 @@ std::string audit_level_plan(const mgcfd_level_desc &L, const LevelPlan &P, int6
         if (P.free_rows) {
             const int32_t r0 = P.hr_row0[size_t(s0)], r1 = P.hr_row0[size_t(s0) + kTile / kSlice];
             if (P.half && r1 - r0 > kHalfTileRows) bad(9, "tile " + S(t) + ": " + S(r1 - r0) + " half rows exceed what the flux terms' LDS image holds");
-            if (staged != (P.tile_halo_ptr[size_t(t) + 1] - P.tile_halo_ptr[size_t(t)]) || n_ovf != 0) bad(9, "tile " + S(t) + ": half rows on a tile with unstaged halo nodes");
+            if (!P.free_wide && n_ovf != 0) bad(9, "tile " + S(t) + ": half rows on a tile with unstaged halo nodes and no table of their own");
             for (int32_t sl = s0; sl < s0 + kTile / kSlice; sl++) {
                 const int32_t n_h = P.hr_row0[size_t(sl) + 1] - P.hr_row0[size_t(sl)];
                 if (n_h < 0 || n_h > (P.half ? kHalfMaxRows : kFreeMaxRows)) bad(9, "slice " + S(sl) + ": " + S(n_h) + " half rows per lane (a lane keeps " + S(kHalfMaxRows) + ")");
@@ -1028,8 +1045,15 @@ std::string audit_level_plan(const mgcfd_level_desc &L, const LevelPlan &P, int6
                     for (int lane = 0; lane < kSlice; lane++) {
                         const uint32_t c = P.hr_code[size_t(row) * kSlice + lane];
                         if ((c & kT16SlotMask) == kT16Pad) continue;
-                        code_ok(c & 0xFFFFu, -1, "half row");
-                        if ((c & kT16SlotMask) >= uint32_t(kTileCap)) bad(10, "half row names an overflow node");
+                        if (P.free_wide) {
+                            int32_t n_all = 0;
+                            while (n_all < kFreeHaloStride && P.free_halo[size_t(t) * kFreeHaloStride + n_all] >= 0) n_all++;
+                            const uint32_t sl_ = c & kT16SlotMask;
+                            if (sl_ >= uint32_t(kTile + n_all) || (sl_ < uint32_t(kTile) && int32_t(sl_) >= n_here)) bad(10, "tile " + S(t) + ": a half row names slot " + S(sl_) + " beyond the " + S(n_all) + " halo nodes of its own table");
+                        } else {
+                            code_ok(c & 0xFFFFu, -1, "half row");
+                            if ((c & kT16SlotMask) >= uint32_t(kTileCap)) bad(10, "half row names an overflow node");
+                        }
                         const uint32_t own = (c >> 16) & 0xFFu, host = uint32_t((sl - s0) * kSlice + lane);
                         if (int32_t(own) >= n_here) bad(10, "tile " + S(t) + ": half row owned by thread " + S(own) + " of " + S(n_here));
                         if (((c & kHalfForeign) != 0) != (own != host)) bad(10, "tile " + S(t) + ": the foreign flag of a half row disagrees with its owner");

@@ -41,6 +41,8 @@ constexpr uint32_t kHalfMirror = 1u << 25;    // the edge lies inside the tile a
                                               // negated terms (k_flux_free adds them to that node's LDS sum; k_flux_half hands them over by position)
 constexpr uint32_t kHalfPad = 0x00007FFFu;   // (low 15 bits = kT16Pad)
 constexpr int kHalfMaxRows = 5;            // half rows (edges a node evaluates) a thread keeps the results of in registers
+constexpr int kFreeHaloStride = 2 * kTile; // halo ids a tile of the order-free kernel can stage from its OWN table (two per thread: 56-byte LDS images,
+                                           // 768 of them + the sums = 53,248 B, three workgroups per CU) where some tile's halo exceeds kHaloStride
 constexpr int kFreeMaxRows = 32;           // ... and what a slice may hold at all: the order-free kernel walks the rows beyond five in a loop
 constexpr int kHalfTileRows = 21;          // half rows of a tile's four slices together (21 * 64 * 40 B = the whole LDS tile)
 constexpr int kHalfSlots = kHalfTileRows * kSlice;   // flux-term slots of a tile in LDS: 5 fields x 1344 x 8 B = 52.5 KiB (its own array in k_flux_half)
@@ -111,6 +113,9 @@ struct LevelPlan {
     bool half = false;                    // ... and k_flux_half can run on it too: no slice needs more than kHalfMaxRows rows, no tile more than
                                           // kHalfTileRows, no long rows
     int32_t hr_max_rows = 0, hr_max_tile_rows = 0;
+    bool free_wide = false;               // some tile's halo exceeds kHaloStride: the order-free kernel stages from free_halo, and the half rows' slots
+                                          // count positions in THAT list (256 + position among ALL the tile's halo ids, ascending)
+    std::vector<int32_t> free_halo;       // [n_tiles][kFreeHaloStride] (free_wide only), -1 padded
     std::vector<int32_t> hr_row0;         // [n_slices+1] first half row of each slice
     std::vector<uint32_t> hr_code;        // [half rows*64] low 16 bits as nbr16 (the other end's LDS slot | kT16RoleB when the OWNING end
                                           //   is the edge's b end), bits 16-23 the owning node's thread, kHalfForeign when the slot

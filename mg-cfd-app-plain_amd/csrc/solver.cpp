@@ -534,7 +534,7 @@ mgcfd_solver::~mgcfd_solver()
         void *ptrs[] = {lv.q_alt, lv.sf_alt, lv.tile_sumsq, lv.dp.nbr16, lv.dp.tile_halo, lv.dp.tile_ovf_ptr, lv.dp.tile_ovf, lv.q, lv.old_variables, lv.fluxes, lv.residuals, lv.step_factors, lv.volumes,
                         lv.cbrt_vol, lv.min_dt, lv.partial_min, lv.sumsq, lv.partials, lv.dp.slice_row0, lv.dp.rows_int,
                         lv.dp.rows_bnd, lv.dp.nbr, lv.dp.w, lv.dp.old_of_new, lv.dp.child_ptr, lv.dp.child, lv.dp.child4, lv.dp.pro_w, lv.dp.pro_p, lv.dp.pro_tile_n, lv.dp.pro_tile_ids, lv.dp.pro_s16, lv.dp.pro_own16,
-                        lv.dp.pro_parent, lv.dp.pro_wsum, lv.dp.te_chunk_ptr, lv.dp.te_count, lv.dp.te_slots, lv.dp.te_w, lv.dp.te_w3, lv.dp.hr_row0, lv.dp.hr_code, lv.dp.hr_w, lv.dp.hg16,
+                        lv.dp.pro_parent, lv.dp.pro_wsum, lv.dp.te_chunk_ptr, lv.dp.te_count, lv.dp.te_slots, lv.dp.te_w, lv.dp.te_w3, lv.dp.hr_row0, lv.dp.hr_code, lv.dp.hr_w, lv.dp.hg16, lv.dp.free_halo,
                         lv.dp.gat16, lv.dp.fe_ab, lv.dp.fe_w, lv.dp.row_edge, lv.dp.edge_flux,
                         const_cast<int32_t *>(lv.dp.tail.rows_main), const_cast<int32_t *>(lv.dp.tail.tile_ptr),
                         const_cast<double2 *>(lv.dp.tail.rec), const_cast<int32_t *>(lv.dp.tail.begin),
@@ -769,6 +769,9 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.dp.half = (P.half && !std::getenv("MGCFD_NO_HALF_ROWS")) ? 1 : 0;
         lv.dp.free_rows = (P.free_rows && !std::getenv("MGCFD_NO_HALF_ROWS")) ? 1 : 0;
         lv.dp.hr_max_rows = P.hr_max_rows;
+        lv.dp.free_wide = (lv.dp.free_rows && P.free_wide) ? 1 : 0;
+        if (lv.dp.free_wide) lv.dp.free_halo = dev_upload(P.free_halo);
+        lv.plan.free_halo.clear(); lv.plan.free_halo.shrink_to_fit();
         if (lv.dp.free_rows) {
             lv.dp.hr_pad_row = P.hr_row0.back();
             lv.dp.hr_row0 = dev_upload(P.hr_row0);

@@ -223,3 +223,53 @@ def test_order_free_on_levels_of_non_uniform_degree(oracle):
         for l in range(2):
             assert _rel(s.get(l, "variables"), case.array(l, "variables").reshape(-1, 5)) <= REL_RUN
         s.close()
+
+
+def test_order_free_on_tetrahedral_levels_with_halos_beyond_the_shared_table(oracle):
+    """Delaunay tetrahedra with median-dual metrics (degrees 5 ... 50, halos of 300-500 nodes per tile: beyond the 303 ids of the
+    table the node-gather kernels share): the order-free kernel stages from its own table, two halo nodes per thread, and
+    spreads a high-degree node's evaluations over its tile's lanes.  One launch on a 30,000-node level and whole cycles on a
+    tetrahedral hierarchy against the oracle."""
+    import mgcfd
+    from mgcfd import meshgen
+    lib = oracle.load()
+    ff = oracle.farfield()
+    mg = meshgen.MultigridMesh(mesh_name="m6wing")
+    mg.levels.append(meshgen.make_tet_level(30000, seed=1))
+    levels = mgcfd.generated_to_levels(mg)
+    L = levels[0]
+    edges = np.ascontiguousarray(L["edges"]).copy()
+    coords = np.ascontiguousarray(L["coords"], dtype=np.float64)
+    lib.ora_adjust_ewt(oracle.ptr(coords), len(edges), oracle.ptr(edges))
+    lib.ora_dampen_ewt(len(edges), oracle.ptr(edges), 5e-8)
+    nel, ni, nb, nw = L["nel"], L["n_internal"], L["n_boundary"], L["n_wall"]
+    s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
+    til = s.tiling(0)
+    assert til["halo_max"] > til["halo_capacity"], "this level was meant to have tiles with more halo nodes than the shared table stages"
+    assert s.has_order_free(0) and not s.has_half_rows(0)
+    s.set_option("exact", 0)
+    s.set_option("flux_variant", FREE)
+    q = perturbed_state(nel, ff.var, seed=77)
+    s.set(0, "variables", q)
+    s.zero_fluxes(0)
+    s.compute_fluxes(0)
+    f = np.zeros_like(q)
+    lib.ora_compute_flux_edge(0, ni, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(f))
+    lib.ora_compute_boundary_flux_edge(ni, nb, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(f))
+    lib.ora_compute_wall_flux_edge(ni + nb, nw, oracle.ptr(edges), oracle.ptr(q), oracle.ptr(f), C.byref(ff))
+    assert _rel(s.get(0, "fluxes"), f) <= REL_LAUNCH
+    s.close()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        mgs = meshgen.make_tet_multigrid((6000, 1200), "m6wing", seed=3)
+        meshgen.write_input(mgs, d)
+        s = mgcfd.Solver.from_mesh(mgcfd.Mesh("input.dat", d))
+        s.set_option("exact", 0)
+        s.set_option("flux_variant", FREE)
+        s.run_cycles(4)
+        case = oracle.OracleCase.from_input_dat(d + "/input.dat")
+        rc, _, _ = case.solve(4)
+        assert rc == 0
+        for l in range(2):
+            assert _rel(s.get(l, "variables"), case.array(l, "variables").reshape(-1, 5)) <= REL_RUN
+        s.close()

@@ -46,6 +46,21 @@ int main(int argc, char **argv)
         int hist[16] = {0};
         for (size_t s = 0; s + 1 < P.hr_row0.size(); s++) hist[std::min(15, P.hr_row0[s + 1] - P.hr_row0[s])]++;
         for (int k = 0; k < 16; k++) if (hist[k]) std::printf("  slices with %d half rows: %d\n", k, hist[k]);
+        // where the evaluations a lane does for ANOTHER node sit (the order-free kernel takes a slower path for a row pair that holds one)
+        long rows = 0, rows_f = 0, pairs = 0, pairs_f = 0, by_pos[16] = {0}, lanes_by_pos[16] = {0};
+        for (size_t s = 0; s + 1 < P.hr_row0.size(); s++) {
+            bool prev = false;
+            for (int32_t r = P.hr_row0[s]; r < P.hr_row0[s + 1]; r++) {
+                int n = 0;
+                for (int l = 0; l < 64; l++) n += (P.hr_code[size_t(r) * 64 + l] & mgcfd::kHalfForeign) != 0;
+                const int pos = std::min(15, int(r - P.hr_row0[s]));
+                rows++; rows_f += n > 0; by_pos[pos] += n > 0; lanes_by_pos[pos] += n;
+                if (pos % 2 == 0) { pairs++; prev = n > 0; if (r + 1 == P.hr_row0[s + 1]) pairs_f += prev; }
+                else pairs_f += prev || n > 0;
+            }
+        }
+        std::printf("  half rows holding a foreign evaluation: %ld of %ld; row pairs: %ld of %ld\n", rows_f, rows, pairs_f, pairs);
+        for (int k = 0; k < 16; k++) if (by_pos[k]) std::printf("    row %d of its slice: %ld rows, %ld lanes\n", k, by_pos[k], lanes_by_pos[k]);
     }
     return 0;
 }

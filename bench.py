@@ -777,6 +777,8 @@ def main():
             # the same launch with FMA contraction allowed (MGCFD_OPT_EXACT = 0: results within 1e-12 relative of the reference's,
             # tests/test_gpu_parity.py REL_FAST; north_star's bound is 1e-10) — reported beside the bit-identical figure, never as it
             solver.set_option("exact", 0)
+            if args.variant == -1:
+                solver.set_option("flux_variant", 1)                # (the node gather: auto would take the order-free kernel in this mode)
             solver.bench_flux(0, ROOFLINE_LAUNCHES)                 # (untimed: the first batch after the switch reads 1 % slower)
             flux_contracted = solver.bench_flux(0, ROOFLINE_LAUNCHES)
             # ... and with ORDER-FREE accumulation on top (k_flux_free, variant bit 6, the contracted namespace only: every edge of a

@@ -91,7 +91,10 @@ enum {
                                    Sums are associated differently from the reference's (src/Kernels/flux_loops.cpp:133-136 adds
                                    in edge order) and are not reproducible bit for bit from run to run: <= 1e-12 relative per
                                    launch, <= 1e-10 after 25 V-cycles, the reference's -v rule (validation.cpp:159-166) passes;
-                                   tests/test_gpu_order_free.py.  Levels without a half-row plan run the node gather. */
+                                   tests/test_gpu_order_free.py.  Levels without a half-row plan run the node gather.
+                                   With MGCFD_OPT_EXACT = 0 the automatic choice (-1) sets this bit where the kernel is the faster
+                                   one: for every standalone flux launch of a level that has the plan, and for the fused stages of
+                                   levels with long rows or tile halos beyond the shared table (tetrahedral levels). */
     MGCFD_OPT_FUSE_UPDATE = 5, /* 1 (default): mgcfd_smooth / mgcfd_run_cycles run each Runge-Kutta stage as ONE
                                   launch (fluxes + time_step, same operations); 0: one launch per loop */
     MGCFD_OPT_GRAPH = 6,       /* 1: replay each smoothing sweep / multigrid cycle from a captured hipGraph (one host

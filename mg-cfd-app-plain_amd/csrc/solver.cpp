@@ -325,9 +325,14 @@ struct mgcfd_solver {
     // less to stream, one sqrt more per entry).  The fused stages run equally fast either way while a level's rows fit the
     // Infinity Cache (bench level: 20.15 against 20.2 us) and 13-17 % faster without the stream beyond it (1.5-2.4 M
     // nodes); the standalone flux launch gains at every size (bench level: 16.0-16.15 against 16.8-16.9 us).
-    int variant_for(const DeviceLevel &) const
+    // With MGCFD_OPT_EXACT = 0 auto also takes the order-free kernel (bit 6) wherever it is the faster one: for every standalone
+    // flux launch of a level that has the half-row plan (bench level 14.8 against 15.4 us, mixed-element level 16.4 against 17.5,
+    // tetrahedral level 12.9 against 24.0), and for the fused stages of levels with long rows or halos beyond the shared table
+    // (tetrahedral level: 45 against 78 us per sweep; on lattice-like levels the role-specialised node-gather stages stay ahead).
+    int variant_for(const DeviceLevel &lv, bool fused = false) const
     {
         if (opt_variant >= 0) return opt_variant;
+        if (!opt_exact && lv.dp.free_rows && (!fused || lv.dp.free_wide || lv.dp.has_tail)) return 1 | 64;
         return 1;
     }
     // classes: bit0 internal, bit1 solid wall (-1), bit2 far field (-2)
@@ -384,8 +389,8 @@ struct mgcfd_solver {
         if (vin_flux) fs.check_vin = next_check();       // the absorbed first stage's check_for_invalid_variables comes first
         fs.check = force_check >= 0 ? force_check : next_check();
         Timed t(this, l, MGCFD_LOOP_FLUX, true);
-        if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs, push);
-        else fast::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv), &fs, push);
+        if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv, true), &fs, push);
+        else fast::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv, true), &fs, push);
         if (count_iters) {                          // (a stage launched in two parts counts once)
             lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
             lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;

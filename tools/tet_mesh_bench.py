@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=120000)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--variants", default="-1,1,2")
+    ap.add_argument("--fast", action="store_true", help="MGCFD_OPT_EXACT = 0 for every variant (auto then picks the order-free kernel where it wins)")
     ap.add_argument("--vcycle", default="", help="comma-separated node counts of a hierarchy: also time a multigrid cycle on it")
     args = ap.parse_args()
     import numpy as np, torch, mgcfd
@@ -30,7 +31,7 @@ def main():
         stream = torch.cuda.Stream()
         torch.cuda.set_stream(stream)
         s.set_stream(stream.cuda_stream)
-        if variant >= 64:      # bit 6: the order-free kernel, which lives in the contracted namespace
+        if variant >= 64 or args.fast:      # bit 6: the order-free kernel, which lives in the contracted namespace
             s.set_option("exact", 0)
         s.set_option("flux_variant", variant)
         nel, E = s.nel(0), s.num_internal_edges(0)
@@ -54,6 +55,8 @@ def main():
         sizes = [int(v) for v in args.vcycle.split(",")]
         mgh = meshgen.make_tet_multigrid(sizes, "m6wing", seed=0)
         s = mgcfd.Solver.from_arrays(mgcfd.generated_to_levels(mgh), mgh.mesh_variant)
+        if args.fast:
+            s.set_option("exact", 0)
         stream = torch.cuda.Stream()
         torch.cuda.set_stream(stream)
         s.set_stream(stream.cuda_stream)

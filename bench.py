@@ -914,7 +914,7 @@ def main():
                                                 "end's LDS sum with ds_add_f64, one barrier, 56-byte records, four workgroups per CU",
                                       "numerics": "sums associated differently from the reference's and not reproducible bit for bit: <= 1e-12 relative per launch and "
                                                   "sweep, <= 1e-10 on level-0 variables after 25 full-size V-cycles, the reference's -v rule passes "
-                                                  "(tests/test_gpu_order_free.py); opt-in, the line's other figures are the bit-identical mode"}
+                                                  "(tests/test_gpu_order_free.py); what MGCFD_OPT_EXACT = 0 launches for this loop — the line's other figures are the bit-identical mode"}
             if flux_avg > 0:
                 a2 = (bytes_flux + bytes_ts) / flux_avg / 1e9
                 roof["fused_stage"] = {"kernel": "one whole Runge-Kutta stage per launch = compute_flux_edge + boundary + far-field + time_step: what the timed sweeps run",

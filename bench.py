@@ -880,17 +880,20 @@ def main():
             bytes_ts = 168 * nel                                # time_step
             traffic = {}
             try:
-                if lattice == LATTICE and not args.fast and args.variant == -1 and args.mesh == "lattice":
+                if lattice == LATTICE and args.variant == -1 and args.mesh == "lattice":
                     traffic = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
             except (OSError, ValueError):
                 traffic = {}
+            order_free_here = bool(args.fast and args.variant == -1 and hasattr(solver, "has_order_free") and solver.has_order_free(0))
             ach = bytes_flux / flux_only / 1e9 if flux_only > 0 else 0.0
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic.get("flux_only", {}).get("bytes"),
+                    # (--fast: MGCFD_OPT_EXACT = 0 launches the order-free kernel for this loop where the level has its plan)
+                    "traffic": (traffic.get("flux_order_free" if (args.fast and order_free_here) else "flux_only") or {}).get("bytes") if not (args.fast and not order_free_here) else None,
                     "traffic_source": (f"{TRAFFIC_PROFILE} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes; build {traffic.get('build')})"
                                        if traffic else None),
                     "frac_of_measured_copy_rate": round(ach / HBM_COPY_GBS, 4), "measured_copy_rate": HBM_COPY_GBS,
-                    "kernel": "compute_flux_edge + boundary + far-field faces in one launch (writes fluxes[], no time_step): the kernel BASELINE's 60 % target names",
+                    "kernel": "compute_flux_edge + boundary + far-field faces in one launch (writes fluxes[], no time_step): the kernel BASELINE's 60 % target names"
+                              + ("; --fast: the order-free kernel k_flux_free (<= 1e-12 per launch, tests/test_gpu_order_free.py), not the bit-identical one" if (args.fast and order_free_here) else ""),
                     "launches": ROOFLINE_LAUNCHES, "avg_kernel_us": round(flux_only * 1e6, 3), "algorithmic_bytes_per_launch": bytes_flux,
                     "algorithmic_bytes": "40 B per internal edge + 80 B per node (SURVEY.md §8d)",
                     "medges_per_s": round(n_int / flux_only / 1e6, 1) if flux_only > 0 else None}

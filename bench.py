@@ -249,6 +249,18 @@ def vcycle_wall(fast: bool, cycles: int = 25, device: int = 0):
     out = {"workload": f"4-level M6-like synthetic hierarchy {[l.nel for l in mg.levels]} nodes, {cycles} cycles, best of 5 after 100 untimed cycles",
            "wall_s_per_cycle": round(best / cycles, 9), "flux_edge_iterations_per_cycle": edge_iters,
            "medges_per_s_whole_cycle": round(edge_iters * cycles / best / 1e6, 1), "rms_last": float(rms[-1])}
+    if not fast:
+        # beside it, never as it: the same cycles with MGCFD_OPT_EXACT = 0 (FMA contraction; <= 1e-12 relative per sweep of the
+        # reference, tests/test_gpu_parity.py REL_FAST — north_star allows 1e-10)
+        s.set_option("exact", 0)
+        s.run_cycles(25)
+        best_c = float("inf")
+        for _ in range(5):
+            t0 = time.perf_counter()
+            rms_c = s.run_cycles(cycles)
+            best_c = min(best_c, time.perf_counter() - t0)
+        out["fma_contracted"] = {"wall_s_per_cycle": round(best_c / cycles, 9), "rms_last": float(rms_c[-1])}
+        s.set_option("exact", 1)
     s.close()
     return out
 

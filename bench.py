@@ -137,6 +137,11 @@ def injected_failure(where: str, rank: int = 0):
     return False
 
 
+def injected(where: str) -> bool:
+    """`where` is named in MGCFD_BENCH_FAIL (the legs one process runs alone: no rank to pick)."""
+    return where in [w.strip() for w in os.environ.get("MGCFD_BENCH_FAIL", "").split(",")]
+
+
 def perturbed_state(nel, ff_var, seed=1234, amplitude=0.01):
     rng = np.random.default_rng(seed)
     base = np.tile(np.asarray(ff_var, dtype=np.float64), (nel, 1))
@@ -201,7 +206,9 @@ def cpu_baseline(levels, sample_seconds: float):
     # process-wide statistics nobody reads here; its arithmetic touches only the arrays passed in).
     try:
         import threading
-        cores = max(1, min(cores_usable, 16))              # a one-GPU box's CPU share is 16 cores whatever the host has
+        # every core this process may use, up to 64 (the pass count per thread is fixed, so the sample's wall time does not
+        # grow with the thread count as long as the cores are there; a one-GPU box's share may be 16 of them)
+        cores = max(1, min(cores_usable, int(os.environ.get("MGCFD_BENCH_CPU_THREADS", "64"))))
         per = max(2, int(sample_seconds / 4.0 / max(one, 1e-6)))
         state = [(q.copy(), np.zeros_like(q)) for _ in range(cores)]
         if have_ref and os.environ.get("MGCFD_BENCH_ALLCORES_PORT") != "1":
@@ -222,10 +229,11 @@ def cpu_baseline(levels, sample_seconds: float):
         for th in threads:
             th.join()
         dt_all = time.perf_counter() - t0
-        out["all_cores"] = {"value": round(n_int * per * cores / dt_all / 1e6, 3), "unit": "Medges/s", "cores": cores, "kind": all_kind,
-                            "sample": f"{cores} threads x {per} passes, one private copy of the level's state per thread ({dt_all:.1f} s), {all_how}"}
+        out["multi_thread"] = {"value": round(n_int * per * cores / dt_all / 1e6, 3), "unit": "Medges/s", "threads": cores, "cores": cores, "kind": all_kind,
+                               "cores_usable_by_this_process": cores_usable, "host_cores": cores_total,
+                               "sample": f"{cores} threads x {per} passes, one private copy of the level's state per thread ({dt_all:.1f} s), {all_how}"}
     except Exception as e:                                   # the single-core figure stands on its own
-        out["all_cores"] = {"error": str(e)}
+        out["multi_thread"] = {"error": str(e)}
     return out
 
 
@@ -265,7 +273,7 @@ def vcycle_wall(fast: bool, cycles: int = 25, device: int = 0):
     return out
 
 
-def vcycle_partitioned(args, dist, world, rank, dev, stream, rehearsal, sizes, cycles=25):
+def vcycle_partitioned(args, dist, world, rank, dev, stream, rehearsal, sizes, cycles=25, keep=None):
     """The V-cycle half of BASELINE's metric on N GPUs: the 4-level hierarchy (tiled 8x by default: per-rank work as on one GPU)
     with EVERY level partitioned over the ranks (mgcfd.partition.partition_hierarchy, level 0 by recursive coordinate bisection),
     the whole cycle swept inside the library (mgcfd_rank_cycles: the partitioned sweeps of `partitioned` on every level, halo
@@ -279,10 +287,13 @@ def vcycle_partitioned(args, dist, world, rank, dev, stream, rehearsal, sizes, c
     from mgcfd.partition import partition_hierarchy, rcb_partition
     t0 = time.perf_counter()
     mg, levels = build_hierarchy(sizes)
-    H = partition_hierarchy(levels, rcb_partition(np.asarray(levels[0]["coords"]), world))[rank]
+    Hs = partition_hierarchy(levels, rcb_partition(np.asarray(levels[0]["coords"]), world))
+    H = Hs[rank]
     lv, owned, keys = H.solver_args()
     nels, n_ints = [int(L["nel"]) for L in levels], [int(L["n_internal"]) for L in levels]
-    del levels
+    if keep is not None:                                    # (rank 0's in-process group leg splits the same hierarchy the same way)
+        keep.append((mg, Hs, nels, n_ints))
+    del levels, Hs
     s = mgcfd.Solver.from_arrays(lv, mg.mesh_variant, device=dev.index, n_owned=owned, order_keys=keys)
     s.set_stream(stream.cuda_stream)
     s.set_option("exact", 0 if args.fast else 1)
@@ -306,38 +317,50 @@ def vcycle_partitioned(args, dist, world, rank, dev, stream, rehearsal, sizes, c
         return float(t.item()) == 1.0
 
     torch_exchange = lambda l: cyc.exchange(l, "variables")
-    if rehearsal:
-        notes.append("rehearsal on one GPU: RCCL cannot form a communicator there, the torch.distributed orchestration is timed")
-    else:
-        err = None
-        uid = [None]
+    # Every step only ONE rank can see failing is followed by an agreement (a torch all-reduce) BEFORE any rank makes the next call
+    # that involves the others: a rank that cannot go on then keeps every rank out of the library's RCCL loop instead of
+    # leaving them in a send / receive nobody answers (round 3's advisor finding: the `vcycle-cycles` injection hung the run).
+    # The rehearsal on one GPU (RCCL cannot form a communicator with both ranks on one device) goes through the same
+    # agreements and takes the same ways out.
+    err = None
+    uid = [None]
+    if not rehearsal:
         try:
             uid = [mgcfd.rccl_unique_id() if rank == 0 else None]
         except Exception as e:
             err = e
         dist.broadcast_object_list(uid, src=0)
-        try:
-            if err:
-                raise err
-            injected_failure("vcycle-setup", rank)
+    try:
+        if err:
+            raise err
+        injected_failure("vcycle-setup", rank)
+        if not rehearsal:
             s.rank_attach_rccl(rank, world, uid[0])
             for l in range(nlev):
                 s.rank_set_halo(l, H.levels[l])
+    except Exception as e:
+        err = e
+    if not agree(err is None):
+        notes.append(f"the library's cycle loop not used: {err or 'its set-up failed on another rank'}")
+    else:
+        # two cycles of each form from the far field: level 0's owned nodes and ghosts must be the same bits
+        reset(torch_exchange)
+        for _ in range(2):
+            cyc.cycle()
+        torch.cuda.synchronize()
+        want = [s.get(l, "variables") for l in range(nlev)]
+        err = None
+        try:
+            injected_failure("vcycle-cycles", rank)            # (the pre-flight point: whatever a rank finds wrong before the loop)
         except Exception as e:
             err = e
         if not agree(err is None):
-            notes.append(f"the library's cycle loop not used: {err or 'its set-up failed on another rank'}")
+            notes.append(f"mgcfd_rank_cycles not used: {err or 'a rank could not start it'}")
         else:
-            # two cycles of each form from the far field: level 0's owned nodes and ghosts must be the same bits
-            reset(torch_exchange)
-            for _ in range(2):
-                cyc.cycle()
-            torch.cuda.synchronize()
-            want = [s.get(l, "variables") for l in range(nlev)]
-            reset(lambda l: s.rank_exchange(l))
-            err = None
             try:
-                injected_failure("vcycle-cycles", rank)
+                if rehearsal:
+                    raise RuntimeError("rehearsal on one GPU: RCCL cannot form a communicator there, the torch.distributed orchestration is timed")
+                reset(lambda l: s.rank_exchange(l))
                 s.rank_cycles(2, rms=False)
                 same = all(np.array_equal(s.get(l, "variables").view(np.int64), want[l].view(np.int64)) for l in range(nlev))
             except Exception as e:
@@ -374,6 +397,136 @@ def vcycle_partitioned(args, dist, world, rank, dev, stream, rehearsal, sizes, c
     except Exception:
         pass
     s.close()
+    return out
+
+
+class leg_guard:
+    """A leg that only adds to the line (the V-cycle leg of an N > 1 run, the in-process group leg) must not take the measured
+    sweeps down with it: if it has not ended after `seconds`, rank 0 prints the line it has — the leg's record saying what
+    happened — and every rank leaves through os._exit (a rank stuck inside a collective cannot be interrupted any other way).
+    Nothing is re-executed; a process that has touched the GPU is never replaced."""
+
+    def __init__(self, seconds, rank, line, key, what):
+        import threading
+        self.timer = threading.Timer(seconds, self.fire)
+        self.timer.daemon = True
+        self.rank, self.line, self.key, self.what, self.seconds = rank, line, key, what, seconds
+
+    def fire(self):
+        sys.stderr.write(f"bench.py: rank {self.rank}: {self.what} did not end within {self.seconds:.0f} s; leaving with what was measured\n")
+        sys.stderr.flush()
+        if self.rank == 0 and self.line is not None:
+            self.line[self.key] = {"error": f"{self.what} did not end within {self.seconds:.0f} s on some rank; the line's other figures were measured before it"}
+            sys.stdout.write(json.dumps(self.line) + "\n")
+            sys.stdout.flush()
+        os._exit(0 if self.line is not None or self.rank != 0 else 1)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+
+
+def in_process_group_leg(args, world, lattice, level_built, sizes, hierarchy_built, share_device: bool, steps: int, warmup: int, cycles: int = 25):
+    """The form `euler3d_gpu_double --gpus N` runs, timed from ONE process: a solver per device as the ranks of an
+    in-process group (mgcfd_group_*: a host thread per rank issues that rank's launches, a stage's message is one launch that
+    stores straight into the neighbours' ghost slots over xGMI peer access, the time-step minimum read from the peers' scalars —
+    no collective library, no second process).  Sweeps on the 8x level in N parts (mgcfd_group_sweeps) and V-cycles on the
+    partitioned hierarchy (mgcfd_group_cycles); before a figure counts, the owned nodes of every rank after the timed sweeps
+    must equal the UNPARTITIONED level swept on device 0 bit for bit (the check the IPC forms get).  `share_device`: every rank
+    on device 0 (the one-GPU rehearsal: a functional run, not a measurement)."""
+    import mgcfd
+    from mgcfd.partition import partition_hierarchy, partition_level, rcb_partition
+    out = {"form": "libmgcfd_hip in-process group (mgcfd_group_sweeps / mgcfd_group_cycles): one process, a host thread per rank, a stage's message = one "
+                   "launch storing into the neighbours' ghost slots (peer access over xGMI), min dt read from the peers' scalars"
+                   + ("; REHEARSAL: every rank on device 0" if share_device else ""), "ranks": world}
+    if injected("group-setup"):
+        raise RuntimeError("injected failure (group-setup)")
+    device_of = (lambda r: 0) if share_device else (lambda r: r)
+    fast = 0 if args.fast else 1
+    # ---- sweeps on the level in N parts ----
+    mg, levels = level_built if level_built is not None else build_workload(lattice)
+    L = levels[0]
+    nel, n_int = int(L["nel"]), int(L["n_internal"])
+    parts = partition_level(L, rcb_partition(np.asarray(L["coords"]), world))
+    whole = mgcfd.Solver.from_arrays([L], mg.mesh_variant, device=0)
+    whole.set_option("exact", fast)
+    q0 = perturbed_state(nel, whole.far_field()[:5])
+    whole.set(0, "variables", q0)
+    whole.smooth(0, warmup + steps)
+    want = whole.get(0, "variables")
+    whole.close()
+    solvers = []
+    for P in parts:
+        sv = mgcfd.Solver.from_arrays([P.level], mg.mesh_variant, device=device_of(P.rank), n_owned=[P.n_owned])
+        sv.set_option("exact", fast)
+        sv.set(0, "variables", q0[P.global_ids])
+        solvers.append(sv)
+    g = mgcfd.Group(solvers)
+    for P, sv in zip(parts, solvers):
+        sv.rank_set_halo(0, P)
+    g.exchange(0)
+    g.sweeps(0, warmup); g.synchronize()
+    t0 = time.perf_counter()
+    g.sweeps(0, steps); g.synchronize()
+    dt = time.perf_counter() - t0
+    bad = sum(int(np.count_nonzero(np.any(sv.get(0, "variables")[:P.n_owned].view(np.int64) != want[P.global_ids[:P.n_owned]].view(np.int64), axis=1)))
+              for P, sv in zip(parts, solvers))
+    if injected("group-end"):
+        bad += 1
+    out["sweeps"] = {"workload": f"{lattice}^3 level ({nel} nodes / {n_int} internal edges) in {world} parts, {steps} sweeps after {warmup}",
+                     "ms_per_step": round(dt / steps * 1e3, 6), "value": round(3 * n_int * steps / dt / 1e6, 3), "unit": "Medges/s",
+                     "nodes_differing_from_the_unpartitioned_level": bad,
+                     "counts": bad == 0}
+    # a longer batch beside the contract's K steps: the host threads start once per call
+    if bad == 0 and steps < 200:
+        g.sweeps(0, 200); g.synchronize()
+        t0 = time.perf_counter(); g.sweeps(0, 200); g.synchronize()
+        out["sweeps"]["ms_per_step_200_sweeps"] = round((time.perf_counter() - t0) / 200 * 1e3, 6)
+    g.close()
+    for sv in solvers:
+        sv.close()
+    del levels, parts, solvers, want
+    # ---- V-cycles on the partitioned hierarchy ----
+    if sizes is not None:
+        if hierarchy_built is not None:
+            mg, Hs, nels, n_ints = hierarchy_built
+        else:
+            mg, levels = build_hierarchy(sizes)
+            nels, n_ints = [int(l["nel"]) for l in levels], [int(l["n_internal"]) for l in levels]
+            Hs = partition_hierarchy(levels, rcb_partition(np.asarray(levels[0]["coords"]), world))
+            del levels
+        ff = None
+        solvers = []
+        for H in Hs:
+            lv, owned, keys = H.solver_args()
+            sv = mgcfd.Solver.from_arrays(lv, mg.mesh_variant, device=device_of(H.rank), n_owned=owned, order_keys=keys)
+            sv.set_option("exact", fast)
+            ff = sv.far_field()[:5]
+            for l in range(len(lv)):
+                sv.set(l, "variables", np.tile(ff, (int(lv[l]["nel"]), 1)))
+                sv.rank_set_halo(l, H.levels[l])
+            solvers.append(sv)
+        g = mgcfd.Group(solvers)
+        for l in range(len(sizes)):
+            g.exchange(l)
+        g.cycles(cycles, rms=False); g.synchronize()
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            g.cycles(cycles, rms=False); g.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        edge_iters = 3 * (n_ints[0] + n_ints[-1] + 2 * sum(n_ints[1:-1]))
+        valid = all(sv.check_for_invalid_variables(0)[0] == 0 for sv in solvers)
+        out["vcycle"] = {"workload": f"4-level hierarchy {nels} nodes, every level in {world} parts, {cycles} cycles, best of 3 after {cycles} untimed",
+                         "wall_s_per_cycle": round(best / cycles, 9), "medges_per_s_whole_cycle": round(edge_iters * cycles / best / 1e6, 1),
+                         "state_valid": valid,
+                         "checked_by": "tests/test_gpu_partitioned_cycles.py (bit-identical to mgcfd_run_cycles on the whole hierarchy in 2-8 parts on one GPU)"}
+        g.close()
+        for sv in solvers:
+            sv.close()
     return out
 
 
@@ -455,6 +608,7 @@ def main():
                          "figure counts only if its final state equals the torch path's after the same sweeps — it has been rehearsed on one GPU only")
     ap.add_argument("--rank-graphs", action="store_true",
                     help="partitioned workload, library exchange: replay every rank's sweep from a captured hipGraph (MGCFD_OPT_GRAPH)")
+    ap.add_argument("--no-group", action="store_true", help="N > 1: skip the in-process group leg (one process sweeping all N devices: `in_process_group` in the line)")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle leg (a rocprofv3 summary of the command then holds only the timed workload's launches)")
     ap.add_argument("--vcycle", action="store_true", help="(default now; kept so older command lines still parse)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (0 disables)")
@@ -773,7 +927,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    flux_only = probe = None
+    flux_only = probe = stream_ceiling = None
     if workload in ("level0", "copies"):
         # the standalone compute_flux_edge kernel (writes fluxes[]), 50 back-to-back launches between one hipEvent pair
         # on the same stream, and the data-movement probe on the same tiles (indirect_rw: same loads and stores, the
@@ -802,6 +956,8 @@ def main():
                 solver.set_option("flux_variant", args.variant)
             solver.set_option("exact", 1)
         probe = solver.bench_indirect_rw(0, ROOFLINE_LAUNCHES) if hasattr(solver, "bench_indirect_rw") else None
+        # ... and a tile-shaped STREAM of exactly the algorithmic bytes (one workgroup per tile, nothing dependent, nothing computed)
+        stream_ceiling = solver.bench_stream_ceiling(0, ROOFLINE_LAUNCHES)
         solver.zero_fluxes(0)                                   # (the sweeps start from zero fluxes, as after any time_step)
     while True:
         for _ in range(args.warmup):
@@ -911,6 +1067,15 @@ def main():
                     "medges_per_s": round(n_int / flux_only / 1e6, 1) if flux_only > 0 else None}
             roof["preheat"] = (f"the {(3 if args.fast else (7 if flux_free else 5)) * ROOFLINE_LAUNCHES} flux + {ROOFLINE_LAUNCHES} probe launches above ({2 if args.fast else (4 if flux_free else 3)} x {ROOFLINE_LAUNCHES} of them untimed) ran BEFORE the warm-up and timed steps "
                                "(an idle MI355X needs ~30 ms of load before its clocks are up: tools/exp/first_steps.py)")
+            if roof["traffic"]:
+                roof["traffic_over_algorithmic"] = round(roof["traffic"] / bytes_flux, 3)
+            if stream_ceiling:
+                roof["practical_ceiling_us"] = round(stream_ceiling * 1e6, 3)
+                roof["practical_ceiling"] = (f"a tile-shaped stream of exactly the {bytes_flux} algorithmic bytes ({n_int} x 40 + {nel} x 40 read, {nel} x 40 written; one workgroup per tile, "
+                                             "16-byte loads, eight in flight, write-through stores, the order-free kernel's LDS footprint; nothing dependent, nothing computed), "
+                                             f"{ROOFLINE_LAUNCHES} back-to-back launches between one hipEvent pair, launch boundary included (mgcfd_bench_stream_ceiling)")
+                roof["practical_ceiling_frac"] = round(bytes_flux / stream_ceiling / 1e9 / HBM_PEAK_GBS, 4)
+                roof["flux_over_practical_ceiling"] = round(flux_only / stream_ceiling, 3)
             if probe:
                 roof["empirical_ceiling_us"] = round(probe * 1e6, 3)
                 roof["empirical_ceiling"] = "indirect_rw through the same tiles (same loads and stores, the reference's trivial arithmetic; src/Kernels/indirect_rw_loop.cpp:8-10)"
@@ -923,6 +1088,7 @@ def main():
             if flux_free:
                 roof["order_free"] = {"avg_kernel_us": round(flux_free * 1e6, 3), "launches": ROOFLINE_LAUNCHES,
                                       "traffic": traffic.get("flux_order_free", {}).get("bytes"),
+                                      "traffic_over_algorithmic": round(traffic["flux_order_free"]["bytes"] / bytes_flux, 3) if traffic.get("flux_order_free", {}).get("bytes") else None,
                                       "frac": round(bytes_flux / flux_free / 1e9 / HBM_PEAK_GBS, 4),
                                       "medges_per_s": round(n_int / flux_free / 1e6, 1),
                                       "kernel": "k_flux_free (MGCFD_OPT_EXACT = 0, MGCFD_OPT_FLUX_VARIANT = 65): one 28-byte entry per edge and tile, -F added to the other "
@@ -938,20 +1104,51 @@ def main():
                                        "algorithmic_bytes_per_launch": bytes_flux + bytes_ts,
                                        "algorithmic_bytes": {"compute_flux_edge (40E+80N)": bytes_flux, "time_step (168N)": bytes_ts},
                                        "achieved": round(a2, 1), "frac": round(a2 / HBM_PEAK_GBS, 4),
+                                       "frac_note": "priced as the TWO loops it replaces (the flux written and read again: 40 N more than a fused launch moves); "
+                                                    "bytes_a_fused_stage_must_move prices what fusion leaves",
+                                       "bytes_a_fused_stage_must_move": 40 * n_int + 128 * nel,
+                                       "bytes_a_fused_stage_must_move_terms": "40 B per internal edge + 128 B per node: the stage's input state 40, the sweep's start state 40, "
+                                                                              "the new state 40, step factor or volume 8 (the flux never leaves registers)",
+                                       "frac_of_bytes_a_fused_stage_must_move": round((40 * n_int + 128 * nel) / flux_avg / 1e9 / HBM_PEAK_GBS, 4),
                                        "frac_if_priced_as_flux_only": round(bytes_flux / flux_avg / 1e9 / HBM_PEAK_GBS, 4),
-                                       "traffic": traffic.get("fused_stage", {}).get("bytes")}
+                                       "traffic": traffic.get("fused_stage", {}).get("bytes"),
+                                       "traffic_over_bytes_a_fused_stage_must_move": round(traffic["fused_stage"]["bytes"] / (40 * n_int + 128 * nel), 3) if traffic.get("fused_stage", {}).get("bytes") else None}
             out["roofline"] = roof
     solver.close()
     if rank == 0 and world == 1 and workload == "level0" and args.mesh == "lattice" and lattice == LATTICE and not args.no_vcycle and "roofline" in out:
         out["roofline"]["mixed_mesh"] = mixed_mesh_roofline(make_solver, args.fast)
     if world > 1:
         dist.barrier()
+    vc_sizes = {"8x": HIERARCHY_8X, "base": HIERARCHY, "tiny": (20, 12, 8, 6)}[args.vcycle_hierarchy]
+    kept = [] if (rank == 0 and not args.no_group) else None
     if world > 1 and workload in ("partitioned", "partitioned-mg") and not args.no_vcycle:
-        # the second half of BASELINE's metric on N GPUs: every level of the hierarchy partitioned, the cycle inside the library
-        vc = vcycle_partitioned(args, dist, world, rank, dev, stream, rehearsal, {"8x": HIERARCHY_8X, "base": HIERARCHY, "tiny": (20, 12, 8, 6)}[args.vcycle_hierarchy])
+        # the second half of BASELINE's metric on N GPUs: every level of the hierarchy partitioned, the cycle inside the library.
+        # (guarded: nothing of it has run on several GPUs yet, and the sweeps' figure must survive whatever it does)
+        with leg_guard(float(os.environ.get("MGCFD_BENCH_LEG_S", "420")), rank, out, "vcycle", "the V-cycle leg on the partitioned hierarchy"):
+            vc = vcycle_partitioned(args, dist, world, rank, dev, stream, rehearsal, vc_sizes, keep=kept)
         if rank == 0:
             out["vcycle"] = vc
             out["metric"] = "Medges/s (compute_flux_edge) + MG V-cycle wall-s"
+    if world > 1 and workload in ("partitioned", "partitioned-mg") and not args.no_group:
+        # beside the RCCL ranks' figure, never as it: the SAME level and hierarchy swept by ONE process over all N devices (the
+        # in-process group the drop-in binary runs).  Rank 0 runs it while the other ranks — their solvers closed — wait on the
+        # rendezvous store, not in a collective (a barrier kernel would spin on the devices being measured).
+        from torch.distributed.distributed_c10d import _get_default_store
+        store = _get_default_store()
+        with leg_guard(float(os.environ.get("MGCFD_BENCH_LEG_S", "420")), rank, out, "in_process_group", "the in-process group leg"):
+            torch.cuda.synchronize()
+            dist.barrier()
+            if rank == 0:
+                try:
+                    torch.cuda.empty_cache()
+                    out["in_process_group"] = in_process_group_leg(args, world, lattice, (mg, levels) if levels is not None else None, None if args.no_vcycle else vc_sizes,
+                                                                   kept[0] if kept else None, rehearsal, args.steps, args.warmup)
+                except Exception as e:
+                    out["in_process_group"] = {"error": f"{type(e).__name__}: {e}"}
+                store.set("mgcfd_group_leg_done", "1")
+            else:
+                import datetime
+                store.wait(["mgcfd_group_leg_done"], datetime.timedelta(seconds=float(os.environ.get("MGCFD_BENCH_LEG_S", "420")) + 120.0))
     if rank == 0:
         if world == 1 and workload == "level0" and not args.no_vcycle:
             out["vcycle"] = vcycle_wall(args.fast, device=local_rank)

@@ -320,6 +320,10 @@ int mgcfd_bench_flux(mgcfd_solver *s, int level, int launches, double *avg_secon
 /* The same for the indirect_rw probe (src/Kernels/indirect_rw_loop.cpp:8-78; fluxes += ..., accumulating over the
  * launches): the empirical data-movement ceiling of the flux kernel on this level's tiles. */
 int mgcfd_bench_indirect_rw(mgcfd_solver *s, int level, int launches, double *avg_seconds);
+/* ... and for a tile-shaped STREAM of exactly the bytes SURVEY.md §8(d) prices for that launch (40 B per internal edge + 40 B per
+ * node read, 40 B per node written; one workgroup per tile, nothing dependent, nothing computed): the practical ceiling of its
+ * data movement on this chip, launch included.  Overwrites `fluxes`. */
+int mgcfd_bench_stream_ceiling(mgcfd_solver *s, int level, int launches, double *avg_seconds);
 
 /* ---------------------------------------------------------------------------------
  * Multi-GPU hooks (one process per GPU; the collectives themselves are issued by the

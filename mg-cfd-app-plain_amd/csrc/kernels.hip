@@ -39,12 +39,40 @@ namespace MGCFD_KERNEL_NS {
 // between phase boundaries of k_flux_half to its own slot.  The shipped build defines the marks away.
 #ifdef MGCFD_PHASES
 __device__ unsigned long long g_phase[4096 * 8];
-__device__ unsigned long long g_phase_abs[4096 * 2];     // the LAST launch: when every workgroup began and passed its last mark (100 MHz ticks)
-#define PH_MARK(k) do { if (threadIdx.x == 0) { unsigned long long now_ = wall_clock64(); g_phase[(blockIdx.x & 4095) * 8 + (k)] += now_ - ph_last_; ph_last_ = now_; g_phase_abs[(blockIdx.x & 4095) * 2 + 1] = now_; } } while (0)
-#define PH_BEGIN() unsigned long long ph_last_ = wall_clock64(); if (threadIdx.x == 0) { g_phase[(blockIdx.x & 4095) * 8 + 7] += 1ull; g_phase_abs[(blockIdx.x & 4095) * 2] = ph_last_; }
+__device__ unsigned long long g_phase_abs[4096 * 8];     // the LAST launch: [0] when every workgroup began, [1 + k] when it passed mark k (100 MHz ticks), [7] XCC_ID << 32 | HW_ID
+#define PH_MARK(k) do { if (threadIdx.x == 0) { unsigned long long now_ = wall_clock64(); g_phase[(blockIdx.x & 4095) * 8 + (k)] += now_ - ph_last_; ph_last_ = now_; g_phase_abs[(blockIdx.x & 4095) * 8 + 1 + (k)] = now_; } } while (0)
+#define PH_BEGIN() unsigned long long ph_last_ = wall_clock64(); if (threadIdx.x == 0) { g_phase[(blockIdx.x & 4095) * 8 + 7] += 1ull; g_phase_abs[(blockIdx.x & 4095) * 8] = ph_last_; \
+        g_phase_abs[(blockIdx.x & 4095) * 8 + 7] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11))) << 32) | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }
 #else
 #define PH_MARK(k) do { } while (0)
 #define PH_BEGIN() do { } while (0)
+#endif
+
+// Cache policy of the standalone flux launch's stores: write-through (`sc1`: the line leaves the XCD's L2 at once and is not
+// kept).  Nothing in the launch reads `fluxes`, an XCD's L2 keeps nothing across a kernel boundary (profiles/r4_l2_across_launches.txt)
+// and a launch otherwise ends with the write-back of everything it left dirty: 14.7 -> 14.1 us order-free, 16.1 -> 15.8 us
+// bit-identical (profiles/r4_flux_levers.txt).  Experiment switches (tools/exp_flags.py builds libraries with -DMGCFD_EXP_*;
+// the shipped build defines none of them).
+#if defined(MGCFD_EXP_FLUX_ST_NT)
+#define MGCFD_ST_FLUX(p, v) __builtin_nontemporal_store((v), (p))
+#elif defined(MGCFD_EXP_FLUX_ST_PLAIN)
+#define MGCFD_ST_FLUX(p, v) (*(p) = (v))
+#else
+#define MGCFD_ST_FLUX(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+// ... and of every store of a node's new state (the fused stages, time_step, the transfers): write-through as well
+// (sweep 55.0 -> 54.4 us, V-cycle 0.293 -> 0.287 ms; non-temporal stores: 57.1 us / 0.295 ms, profiles/r4_flux_levers.txt)
+#if defined(MGCFD_EXP_STAGE_ST_PLAIN)
+#define MGCFD_ST_STAGE(p, v) (*(p) = (v))
+#elif defined(MGCFD_EXP_STAGE_ST_NT)
+#define MGCFD_ST_STAGE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define MGCFD_ST_STAGE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+#if defined(MGCFD_EXP_STATE_LD_NT)
+#define MGCFD_LD_STATE(p) __builtin_nontemporal_load(p)
+#else
+#define MGCFD_LD_STATE(p) (*(p))
 #endif
 
 namespace {
@@ -90,11 +118,11 @@ __device__ __forceinline__ NodeQ load_and_derive(const double *__restrict__ q, i
 __device__ __forceinline__ void store_conserved(double *__restrict__ q, int64_t stride, int64_t i, double rho,
                                                 double mx, double my, double mz, double en)
 {
-    q[i] = rho;
-    q[stride + i] = mx;
-    q[2 * stride + i] = my;
-    q[3 * stride + i] = mz;
-    q[4 * stride + i] = en;
+    MGCFD_ST_STAGE(q + i, rho);
+    MGCFD_ST_STAGE(q + stride + i, mx);
+    MGCFD_ST_STAGE(q + 2 * stride + i, my);
+    MGCFD_ST_STAGE(q + 3 * stride + i, mz);
+    MGCFD_ST_STAGE(q + 4 * stride + i, en);
 }
 
 // LDS tile records: 12 doubles (96 B) per staged node, read back with 16-byte LDS loads.
@@ -444,8 +472,14 @@ __device__ __forceinline__ void finish_node(int64_t i, int64_t nel, int64_t stri
 {
     if (!FUSE) {
         if (i < nel) {
-            fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
-            fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
+#ifdef MGCFD_ABL_FREE_ST_AOS           /* diagnostic: the node's fluxes written as one 40-byte record (layout wrong) */
+            *reinterpret_cast<double2 *>(fluxes + 5 * i) = make_double2(a0, a1);
+            *reinterpret_cast<double2 *>(fluxes + 5 * i + 2) = make_double2(a2, a3);
+            fluxes[5 * i + 4] = a4;
+#else
+            MGCFD_ST_FLUX(fluxes + i, a0); MGCFD_ST_FLUX(fluxes + stride + i, a1); MGCFD_ST_FLUX(fluxes + 2 * stride + i, a2);
+            MGCFD_ST_FLUX(fluxes + 3 * stride + i, a3); MGCFD_ST_FLUX(fluxes + 4 * stride + i, a4);
+#endif
         }
         return;
     }
@@ -473,8 +507,8 @@ __device__ __forceinline__ void finish_node(int64_t i, int64_t nel, int64_t stri
         if (fs.residuals || fs.sumsq_partial) {
             const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
             if (fs.residuals) {                      // (null: the caller writes it on demand, solver.cpp settle_residuals)
-                fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
-                fs.residuals[3 * stride + i] = d3; fs.residuals[4 * stride + i] = d4;
+                MGCFD_ST_STAGE(fs.residuals + i, d0); MGCFD_ST_STAGE(fs.residuals + stride + i, d1); MGCFD_ST_STAGE(fs.residuals + 2 * stride + i, d2);
+                MGCFD_ST_STAGE(fs.residuals + 3 * stride + i, d3); MGCFD_ST_STAGE(fs.residuals + 4 * stride + i, d4);
             }
             if (fs.sumsq_partial) ss = (((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3) + d4 * d4;
         }
@@ -887,8 +921,8 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
 
     if (!FUSE) {
         if (i < nel) {
-            fluxes[i] = a0; fluxes[stride + i] = a1; fluxes[2 * stride + i] = a2;
-            fluxes[3 * stride + i] = a3; fluxes[4 * stride + i] = a4;
+            MGCFD_ST_FLUX(fluxes + i, a0); MGCFD_ST_FLUX(fluxes + stride + i, a1); MGCFD_ST_FLUX(fluxes + 2 * stride + i, a2);
+            MGCFD_ST_FLUX(fluxes + 3 * stride + i, a3); MGCFD_ST_FLUX(fluxes + 4 * stride + i, a4);
         }
         PH_MARK(3);
         return;
@@ -913,8 +947,8 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         if (ROLE >= 2 && ROLE <= 4) {               // last stage: residual (validation.cpp:77-89)
             const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
             if (fs.residuals) {                      // (null: the caller writes it on demand, solver.cpp settle_residuals)
-                fs.residuals[i] = d0; fs.residuals[stride + i] = d1; fs.residuals[2 * stride + i] = d2;
-                fs.residuals[3 * stride + i] = d3; fs.residuals[4 * stride + i] = d4;
+                MGCFD_ST_STAGE(fs.residuals + i, d0); MGCFD_ST_STAGE(fs.residuals + stride + i, d1); MGCFD_ST_STAGE(fs.residuals + 2 * stride + i, d2);
+                MGCFD_ST_STAGE(fs.residuals + 3 * stride + i, d3); MGCFD_ST_STAGE(fs.residuals + 4 * stride + i, d4);
             }
             if (fs.sumsq_partial) ss = (((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3) + d4 * d4;
         }
@@ -1350,7 +1384,7 @@ k_flux_half(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
 // three and two, four 16-byte LDS reads per neighbour instead of six.  Quad q of slot s sits at position q ^ ((s >> 2) & 3)
 // of its record, so a 16-lane ds_read_b128 group reaches all 16 quad positions of the 256-byte bank row.
 // ------------------------------------------------------------------------------------------
-struct NodeF { double rho, mx, my, mz, en, p, sc, inv; };
+struct NodeF { double rho, vx, vy, vz, en, p, sc; };
 constexpr int kFreeRecD2 = 3;                  // double2 per record (+ one double in the array beside)
 
 // 1/x and sqrt(x) from the hardware's estimates and Newton steps in FMAs (~1e-16 relative; the IEEE sequences hipcc emits
@@ -1365,7 +1399,8 @@ __device__ __forceinline__ double fast_rcp(double x)
     return fma(y, e, y);
 }
 
-__device__ __forceinline__ double fast_sqrt(double x)
+// sqrt(x) for x > 0 (no special cases: x = 0 gives NaN)
+__device__ __forceinline__ double fast_sqrt_pos(double x)
 {
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;                  // g -> sqrt(x), h -> 0.5 / sqrt(x) (Goldschmidt)
@@ -1374,32 +1409,40 @@ __device__ __forceinline__ double fast_sqrt(double x)
     r = fma(-h, g, 0.5);
     g = fma(g, r, g); h = fma(h, r, h);
     const double d = fma(-g, g, x);
-    g = fma(d, h, g);
-    // (x = 0: the estimate is infinite; negative or NaN: NaN, as sqrt gives)
-    return x > 0.0 ? g : (x == 0.0 ? 0.0 : __builtin_nan(""));
+    return fma(d, h, g);
 }
 
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+    const double g = fast_sqrt_pos(x);
+    // (x = 0: the estimate is infinite; +inf: the estimate is 0 and the product NaN; negative or NaN: NaN, as sqrt gives)
+    return (x > 0.0 && x < __builtin_inf()) ? g : ((x == 0.0 || x == __builtin_inf()) ? x : __builtin_nan(""));
+}
+
+// What a staged node keeps (round 4): the VELOCITY instead of the momentum.  The evaluating end needs both of its neighbour
+// — m for the dissipation's differences, v for the convective terms — and rho * v is three multiplications where m / rho was
+// a reciprocal (five instructions) and three.
 __device__ __forceinline__ NodeF make_nodef(double rho, double mx, double my, double mz, double en)
 {
     NodeF n;
-    n.rho = rho; n.mx = mx; n.my = my; n.mz = mz; n.en = en;
-    n.inv = fast_rcp(rho);
-    const double vx = mx * n.inv, vy = my * n.inv, vz = mz * n.inv;
-    const double speed_sqd = vx * vx + vy * vy + vz * vz;
+    const double inv = fast_rcp(rho);
+    n.rho = rho; n.en = en;
+    n.vx = mx * inv; n.vy = my * inv; n.vz = mz * inv;
+    const double speed_sqd = n.vx * n.vx + n.vy * n.vy + n.vz * n.vz;
     n.p = (kGamma - 1.0) * (en - 0.5 * rho * speed_sqd);
-    n.sc = fast_sqrt(speed_sqd) + fast_sqrt(kGamma * n.p * n.inv);
+    n.sc = fast_sqrt(speed_sqd) + fast_sqrt(kGamma * n.p * inv);
     return n;
 }
 
-// LDS image of a staged node: 48 bytes (rho, m, E, p) in an array of records + |v| + c in an array of its own; 1/rho is five
-// instructions away from rho.  56 bytes per node instead of 64: with the tile's 10 KB of sums, 546 nodes fit the 40 KB a
+// LDS image of a staged node: 48 bytes (rho, v, E, p) in an array of records + |v| + c in an array of its own.
+// 56 bytes per node: with the tile's 10 KB of sums, 546 nodes fit the 40 KB a
 // workgroup may take when FOUR share a CU.  A 12-dword record stride spreads a 16-lane ds_read_b128 group over all 16 quad
 // positions of the 256-byte bank row by itself.
 __device__ __forceinline__ void lds_store_nodef(double2 *rec, double *scs, uint32_t slot, const NodeF &n)
 {
     double2 *r = rec + slot * kFreeRecD2;
-    r[0] = make_double2(n.rho, n.mx);
-    r[1] = make_double2(n.my, n.mz);
+    r[0] = make_double2(n.rho, n.vx);
+    r[1] = make_double2(n.vy, n.vz);
     r[2] = make_double2(n.en, n.p);
     scs[slot] = n.sc;
 }
@@ -1409,52 +1452,55 @@ __device__ __forceinline__ NodeF lds_load_nodef(const double2 *rec, const double
     const double2 *r = rec + slot * kFreeRecD2;
     const double2 a = r[0], c = r[1], d = r[2];
     NodeF n;
-    n.rho = a.x; n.mx = a.y; n.my = c.x; n.mz = c.y; n.en = d.x; n.p = d.y; n.sc = scs[slot];
-    n.inv = fast_rcp(n.rho);
+    n.rho = a.x; n.vx = a.y; n.vy = c.x; n.vz = c.y; n.en = d.x; n.p = d.y; n.sc = scs[slot];
     return n;
 }
 
-// what the evaluating end keeps beside its record: velocity and total enthalpy per volume
-struct OwnF { double vx, vy, vz, H; };
+// what the evaluating end keeps beside its record: momentum and total enthalpy per volume
+struct OwnF { double mx, my, mz, H; };
 __device__ __forceinline__ OwnF make_ownf(const NodeF &n)
 {
     OwnF o;
-    o.vx = n.mx * n.inv; o.vy = n.my * n.inv; o.vz = n.mz * n.inv; o.H = n.en + n.p;
+    o.mx = n.rho * n.vx; o.my = n.rho * n.vy; o.mz = n.rho * n.vz; o.H = n.en + n.p;
     return o;
 }
 
-// flux_kernel.elemfunc.c:130-161 seen from end `a` (the plan folded the b-side sign into the weights f), regrouped: with
-// d_x = f . m_x the contracted flux contributions are f . Phi_x = v_x d_x + p_x f for the momenta and H_x (f . v_x) for the
-// energy (cfd_loops.h:57-83), so nothing of the 3 x 3 tensors is formed: 53 fp64 instructions per edge instead of 81.
-__device__ __forceinline__ Flux5 edge_flux_f(const NodeF &a, const OwnF &oa, const NodeF &b, double fx, double fy, double fz)
+// MINUS the flux of flux_kernel.elemfunc.c:130-161 seen from end `a` (the plan folded the b-side sign into the weights f),
+// regrouped: with d_x = f . m_x = rho_x (f . v_x) the contracted flux contributions are f . Phi_x = v_x d_x + p_x f for the
+// momenta and H_x (f . v_x) for the energy (cfd_loops.h:57-83), so nothing of the 3 x 3 tensors is formed.  The NEGATED
+// flux is what the other end of an edge inside the tile adds to its sum (ds_add_f64 has no operand negation; the evaluating
+// end subtracts, which costs nothing).  The weights of a real entry are never all zero; a padding entry's are, and it meets
+// its own record as "neighbour": the length is then ~1e-150 times a difference that is exactly zero.
+__device__ __forceinline__ Flux5 edge_flux_neg_f(const NodeF &a, const OwnF &oa, const NodeF &b, double fx, double fy, double fz)
 {
-    const double half_ewt = fast_sqrt(fx * fx + fy * fy + fz * fz);           // :27, the plan stores f = -+0.5 e
-    const double factor = -(half_ewt * double(0.2f)) * (a.sc + b.sc);         // :130-131
-    const double da = fx * a.mx + fy * a.my + fz * a.mz;
-    const double db = fx * b.mx + fy * b.my + fz * b.mz;
-    const double bvx = b.mx * b.inv, bvy = b.my * b.inv, bvz = b.mz * b.inv;
+    const double half_ewt = fast_sqrt_pos(fmax(fx * fx + fy * fy + fz * fz, 1e-300));       // :27, the plan stores f = -+0.5 e
+    const double factor = (half_ewt * double(0.2f)) * (a.sc + b.sc);                          // MINUS the factor of :130-131
+    const double fva = fx * a.vx + fy * a.vy + fz * a.vz;
+    const double fvb = fx * b.vx + fy * b.vy + fz * b.vz;
+    const double da = a.rho * fva, db = b.rho * fvb;
+    const double bmx = b.rho * b.vx, bmy = b.rho * b.vy, bmz = b.rho * b.vz;
     const double ps = a.p + b.p;
-    Flux5 f;
-    f.d = factor * (a.rho - b.rho) + (da + db);
-    f.mx = factor * (a.mx - b.mx) + oa.vx * da + bvx * db + ps * fx;
-    f.my = factor * (a.my - b.my) + oa.vy * da + bvy * db + ps * fy;
-    f.mz = factor * (a.mz - b.mz) + oa.vz * da + bvz * db + ps * fz;
-    f.en = factor * (a.en - b.en) + oa.H * (da * a.inv) + (b.en + b.p) * (db * b.inv);
-    return f;
+    Flux5 g;
+    g.d = factor * (a.rho - b.rho) - (da + db);
+    g.mx = factor * (oa.mx - bmx) - a.vx * da - b.vx * db - ps * fx;
+    g.my = factor * (oa.my - bmy) - a.vy * da - b.vy * db - ps * fy;
+    g.mz = factor * (oa.mz - bmz) - a.vz * da - b.vz * db - ps * fz;
+    g.en = factor * (a.en - b.en) - oa.H * fva - (b.en + b.p) * fvb;
+    return g;
 }
 
 __device__ __forceinline__ FluxC flux_contribution_f(const NodeF &q, const OwnF &o)
 {
     FluxC f;
-    f.xx = o.vx * q.mx + q.p;
-    f.xy = o.vx * q.my;
-    f.xz = o.vx * q.mz;
-    f.yy = o.vy * q.my + q.p;
-    f.yz = o.vy * q.mz;
-    f.zz = o.vz * q.mz + q.p;
-    f.ex = o.vx * o.H;
-    f.ey = o.vy * o.H;
-    f.ez = o.vz * o.H;
+    f.xx = q.vx * o.mx + q.p;
+    f.xy = q.vx * o.my;
+    f.xz = q.vx * o.mz;
+    f.yy = q.vy * o.my + q.p;
+    f.yz = q.vy * o.mz;
+    f.zz = q.vz * o.mz + q.p;
+    f.ex = q.vx * o.H;
+    f.ey = q.vy * o.H;
+    f.ez = q.vz * o.H;
     return f;
 }
 
@@ -1497,15 +1543,44 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
     const int32_t h0 = hr_row0[slice];
     const int32_t n_h = (classes & 1) ? hr_row0[slice + 1] - h0 : 0;
     const int32_t n_bnd = rows_bnd[slice];
-    const double o0 = q[i], o1 = q[stride + i], o2 = q[2 * stride + i], o3 = q[3 * stride + i], o4 = q[4 * stride + i];
+#ifdef MGCFD_ABL_FREE_OWN_AOS          /* diagnostic: the own node read as one 40-byte record, lanes 40 bytes apart (results wrong) */
+    const double2 oa_ = *reinterpret_cast<const double2 *>(q + 5 * i), ob_ = *reinterpret_cast<const double2 *>(q + 5 * i + 2);
+    const double o0 = oa_.x, o1 = oa_.y, o2 = ob_.x, o3 = ob_.y, o4 = q[5 * i + 4];
+#else
+    const double o0 = MGCFD_LD_STATE(q + i), o1 = MGCFD_LD_STATE(q + stride + i), o2 = MGCFD_LD_STATE(q + 2 * stride + i),
+                 o3 = MGCFD_LD_STATE(q + 3 * stride + i), o4 = MGCFD_LD_STATE(q + 4 * stride + i);
+#endif
     // EVERY half row of the lane is requested here (the plan gives a lane at most kHalfMaxRows): the row loop then waits for
     // nothing, and a workgroup has all of its tile's bytes in flight at once — what hides the memory latency is the other
     // workgroups of the CU, not a prefetch distance
     EdgeRow er[kHalfMaxRows];
+    // (round 4: the halo state is requested behind the first TWO half rows and ahead of the others, so the records can be
+    //  staged while the last three half rows are still on their way: 14.7 -> 14.1 us; 0, 1, 3 and 5 rows first: 14.3, 14.2,
+    //  14.5, 14.7 us, profiles/r4_flux_levers.txt)
+#ifdef MGCFD_EXP_FREE_ORDER
+    constexpr int kRowsFirst = MGCFD_EXP_FREE_ORDER;
+#else
+    constexpr int kRowsFirst = 2;
+#endif
 #pragma unroll
-    for (int j = 0; j < kHalfMaxRows; j++) er[j] = load_half_row(hr_code, hr_w, j < n_h ? h0 + j : hr_pad_row, lane);
+    for (int j = 0; j < kRowsFirst; j++) er[j] = load_half_row(hr_code, hr_w, j < n_h ? h0 + j : hr_pad_row, lane);
     const int64_t hnode = hid >= 0 ? int64_t(hid) : i;
-    const double g0 = q[hnode], g1 = q[stride + hnode], g2 = q[2 * stride + hnode], g3 = q[3 * stride + hnode], g4 = q[4 * stride + hnode];
+#if defined(MGCFD_ABL_FREE_HALO) && MGCFD_ABL_FREE_HALO == 1      /* diagnostic: the halo node read as ONE 40-byte record (results wrong) */
+    const double2 ga_ = *reinterpret_cast<const double2 *>(q + 5 * hnode), gb_ = *reinterpret_cast<const double2 *>(q + 5 * hnode + 2);
+    const double g0 = ga_.x, g1 = ga_.y, g2 = gb_.x, g3 = gb_.y, g4 = q[5 * hnode + 4];
+#elif defined(MGCFD_ABL_FREE_HALO) && MGCFD_ABL_FREE_HALO == 2    /* diagnostic: ... as a 64-byte aligned record (results wrong) */
+    const double2 ga_ = *reinterpret_cast<const double2 *>(q + 8 * (hnode >> 1)), gb_ = *reinterpret_cast<const double2 *>(q + 8 * (hnode >> 1) + 2);
+    const double g0 = ga_.x, g1 = ga_.y, g2 = gb_.x, g3 = gb_.y, g4 = q[8 * (hnode >> 1) + 4];
+#elif defined(MGCFD_ABL_FREE_HALO) && MGCFD_ABL_FREE_HALO == 3    /* diagnostic: no gather, the own node again (results wrong) */
+    const double g0 = q[i], g1 = q[stride + i], g2 = q[2 * stride + i], g3 = q[3 * stride + i], g4 = q[4 * stride + i];
+#elif defined(MGCFD_ABL_FREE_HALO) && MGCFD_ABL_FREE_HALO == 4    /* diagnostic: nothing loaded for the halo at all (results wrong) */
+    const double g0 = o0 + double(hnode), g1 = o1, g2 = o2, g3 = o3, g4 = o4;
+#else
+    const double g0 = MGCFD_LD_STATE(q + hnode), g1 = MGCFD_LD_STATE(q + stride + hnode), g2 = MGCFD_LD_STATE(q + 2 * stride + hnode),
+                 g3 = MGCFD_LD_STATE(q + 3 * stride + hnode), g4 = MGCFD_LD_STATE(q + 4 * stride + hnode);
+#endif
+#pragma unroll
+    for (int j = kRowsFirst; j < kHalfMaxRows; j++) er[j] = load_half_row(hr_code, hr_w, j < n_h ? h0 + j : hr_pad_row, lane);
     // (WIDE: the second halo node of every thread as unconditionally as the first)
     const int64_t hnode2 = (WIDE && hid2 >= 0) ? int64_t(hid2) : i;
     double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0, u4 = 0.0;
@@ -1537,7 +1612,7 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
         const uint32_t s = e0.code & kT16SlotMask;
         const bool v = s != kT16Pad;
         const NodeF ot = lds_load_nodef(tile, scs, v ? s : uint32_t(tid));
-        Flux5 F;
+        Flux5 G;                                    // MINUS the edge's flux as its evaluating end sees it
         bool mine = true;
         if (may_be_foreign) {
             // an evaluation another node owns (the plan found no room in that node's lane): its record comes from LDS too,
@@ -1545,21 +1620,21 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
             const bool foreign = (e0.code & kHalfForeign) != 0;
             const uint32_t own = (e0.code >> 16) & 0xFFu;
             const NodeF m0 = foreign ? lds_load_nodef(tile, scs, own) : me;
-            F = edge_flux_f(m0, make_ownf(m0), ot, e0.fx, e0.fy, e0.fz);
+            G = edge_flux_neg_f(m0, make_ownf(m0), ot, e0.fx, e0.fy, e0.fz);
             if (foreign && v) {
-                lds_add(&acc[own], F.d); lds_add(&acc[kTile + own], F.mx); lds_add(&acc[2 * kTile + own], F.my);
-                lds_add(&acc[3 * kTile + own], F.mz); lds_add(&acc[4 * kTile + own], F.en);
+                lds_add(&acc[own], -G.d); lds_add(&acc[kTile + own], -G.mx); lds_add(&acc[2 * kTile + own], -G.my);
+                lds_add(&acc[3 * kTile + own], -G.mz); lds_add(&acc[4 * kTile + own], -G.en);
             }
             mine = !foreign;
         } else {
-            F = edge_flux_f(me, mo, ot, e0.fx, e0.fy, e0.fz);
+            G = edge_flux_neg_f(me, mo, ot, e0.fx, e0.fy, e0.fz);
         }
-        // (padding carries zero weights: F = 0)
-        if (mine) { a0 += F.d; a1 += F.mx; a2 += F.my; a3 += F.mz; a4 += F.en; }
+        // (padding: G = 0)
+        if (mine) { a0 -= G.d; a1 -= G.mx; a2 -= G.my; a3 -= G.mz; a4 -= G.en; }
         if (v && (e0.code & kHalfMirror)) {
             // the other end lies in this tile and does not evaluate the edge itself: it gets -F
-            lds_add(&acc[s], -F.d); lds_add(&acc[kTile + s], -F.mx); lds_add(&acc[2 * kTile + s], -F.my);
-            lds_add(&acc[3 * kTile + s], -F.mz); lds_add(&acc[4 * kTile + s], -F.en);
+            lds_add(&acc[s], G.d); lds_add(&acc[kTile + s], G.mx); lds_add(&acc[2 * kTile + s], G.my);
+            lds_add(&acc[3 * kTile + s], G.mz); lds_add(&acc[4 * kTile + s], G.en);
         }
     };
 #pragma unroll
@@ -1606,7 +1681,7 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
                 a3 += fz * me.p;
             } else if (e.code == kT16Far && (classes & 4)) {
                 // flux_wall_kernel.elemfunc.c:51-88: average with the far-field state
-                a0 += fx * (ff.var[1] + me.mx) + fy * (ff.var[2] + me.my) + fz * (ff.var[3] + me.mz);
+                a0 += fx * (ff.var[1] + mo.mx) + fy * (ff.var[2] + mo.my) + fz * (ff.var[3] + mo.mz);
                 a4 += fx * (ff.fc_de[0] + fm.ex) + fy * (ff.fc_de[1] + fm.ey) + fz * (ff.fc_de[2] + fm.ez);
                 a1 += fx * (ff.fc_mx[0] + fm.xx) + fy * (ff.fc_mx[1] + fm.xy) + fz * (ff.fc_mx[2] + fm.xz);
                 a2 += fx * (ff.fc_my[0] + fm.xy) + fy * (ff.fc_my[1] + fm.yy) + fz * (ff.fc_my[2] + fm.yz);
@@ -2498,6 +2573,43 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
 #undef MGCFD_TILE_LAUNCH_T
 }
 
+// The practical ceiling of the flux launch's data movement (bench.py: roofline.practical_ceiling_us): a tile-shaped STREAM of
+// exactly the algorithmic bytes — workgroup t reads its share of `rd_total` doubles (contiguous, 16 bytes per lane and load,
+// eight loads in flight) and writes its share of `wr_total` (write-through, as the flux launch stores) — with the order-free
+// kernel's LDS footprint (four workgroups per CU), nothing dependent, nothing computed.  What the chip gives 1,175 workgroups
+// that only move the bytes SURVEY.md §8d prices, launch included.
+__global__ void __launch_bounds__(kBlock)
+k_stream_tiles(const double2 *__restrict__ src, double *__restrict__ dst, int64_t rd_total2, int64_t wr_total, int rd2_per_thread, int wr_per_thread)
+{
+    __shared__ double lds[40960 / 8 - 64];
+    const int64_t r0 = int64_t(blockIdx.x) * rd2_per_thread * kBlock + threadIdx.x;
+    double acc = 0.0;
+    for (int k = 0; k < rd2_per_thread; k += 8) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int64_t j = r0 + int64_t(k + u) * kBlock;
+            v[u] = src[(k + u < rd2_per_thread && j < rd_total2) ? j : int64_t(threadIdx.x)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u].x + v[u].y;
+    }
+    if (acc == 1.2345e300) { lds[threadIdx.x] = acc; __syncthreads(); acc = lds[(threadIdx.x + 1) & 255]; }   // (keeps the footprint)
+    const int64_t w0 = int64_t(blockIdx.x) * wr_per_thread * kBlock + threadIdx.x;
+    for (int k = 0; k < wr_per_thread; k++) {
+        const int64_t j = w0 + int64_t(k) * kBlock;
+        if (j < wr_total) MGCFD_ST_FLUX(dst + j, acc + double(k));
+    }
+}
+
+void launch_stream_tiles(hipStream_t st, int n_tiles, const double *src, double *dst, int64_t rd_total, int64_t wr_total)
+{
+    const int64_t rd2 = rd_total / 2;
+    const int rd2_per_thread = int((rd2 + int64_t(n_tiles) * kBlock - 1) / (int64_t(n_tiles) * kBlock));
+    const int wr_per_thread = int((wr_total + int64_t(n_tiles) * kBlock - 1) / (int64_t(n_tiles) * kBlock));
+    hipLaunchKernelGGL(k_stream_tiles, dim3(n_tiles), dim3(kBlock), 0, st, reinterpret_cast<const double2 *>(src), dst, rd2, wr_total, rd2_per_thread, wr_per_thread);
+}
+
 void launch_indirect_rw(hipStream_t st, const DevicePlan &p, const double *q, double *fluxes, int variant)
 {
     // through the flux kernel's LDS tiles where the level allows it (no halo node left outside LDS, no long rows);
@@ -2608,6 +2720,6 @@ extern "C" void mgcfd_debug_phases(unsigned long long *out, int reset)
 extern "C" void mgcfd_debug_phase_abs(unsigned long long *out)
 {
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mgcfd::MGCFD_KERNEL_NS::g_phase_abs), sizeof(unsigned long long) * 4096 * 2);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mgcfd::MGCFD_KERNEL_NS::g_phase_abs), sizeof(unsigned long long) * 4096 * 8);
 }
 #endif

@@ -17,6 +17,7 @@
                      int classes, int accumulate, int variant, const FusedStep *fused,                               \
                      const StagePush *push = nullptr);                                                               \
     void launch_indirect_rw(hipStream_t, const DevicePlan &, const double *q, double *fluxes, int variant);                       \
+    void launch_stream_tiles(hipStream_t, int n_tiles, const double *src, double *dst, int64_t rd_total, int64_t wr_total);      \
     void launch_time_step(hipStream_t, int64_t nel, int64_t stride, int j, double *sf, double *fluxes,               \
                           const double *old_variables, double *q, const int32_t *old_of_new,                         \
                           unsigned long long *err, int check, const double *partial_min, int n_partial,              \

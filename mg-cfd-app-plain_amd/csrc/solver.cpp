@@ -1876,6 +1876,36 @@ int mgcfd_bench_indirect_rw(mgcfd_solver *s, int level, int launches, double *av
     });
 }
 
+// The practical ceiling of that launch's data movement: a tile-shaped stream of exactly the bytes SURVEY.md §8d prices
+// (40 B per internal edge + 40 B per node read from a scratch buffer of that size, 40 B per node written into `fluxes`), one
+// workgroup per tile of the level, nothing dependent and nothing computed (kernels.hip: k_stream_tiles).
+int mgcfd_bench_stream_ceiling(mgcfd_solver *s, int level, int launches, double *avg_seconds)
+{
+    REQUIRE(s); REQUIRE(avg_seconds);
+    return guarded([&] {
+        s->use_device();
+        DeviceLevel &lv = s->level(level);
+        s->settle_fluxes(lv);
+        const int64_t rd_total = (5 * int64_t(lv.info.n_internal) + 5 * lv.dp.nel + 1) & ~int64_t(1), wr_total = 5 * lv.dp.nel;
+        double *src = dev_alloc<double>(static_cast<size_t>(rd_total) + 512);
+        HIP_CHECK(hipMemsetAsync(src, 0, (static_cast<size_t>(rd_total) + 512) * sizeof(double), s->stream));
+        hipEvent_t a = s->get_event(), b = s->get_event();
+        auto go = [&] { exact::launch_stream_tiles(s->stream, lv.dp.n_tiles, src, lv.fluxes, rd_total, wr_total); };
+        go();
+        HIP_CHECK(hipEventRecord(a, s->stream));
+        for (int k = 0; k < launches; k++) go();
+        HIP_CHECK(hipEventRecord(b, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        s->free_events.push_back(a);
+        s->free_events.push_back(b);
+        HIP_CHECK(hipFree(src));
+        lv.fluxes_zero = false;
+        *avg_seconds = launches > 0 ? double(ms) * 1e-3 / launches : 0.0;
+    });
+}
+
 } // extern "C"
 
 // ==========================================================================================================

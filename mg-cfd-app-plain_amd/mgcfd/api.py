@@ -109,6 +109,7 @@ _SIGNATURES = [
     ("mgcfd_get_flux_kernel_time", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
     ("mgcfd_bench_flux", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_bench_indirect_rw", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    ("mgcfd_bench_stream_ceiling", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_step_factor_local", C.c_int, [_vp, C.c_int]),
     ("mgcfd_step_factor_min_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_step_factor_partials_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]),
@@ -497,6 +498,12 @@ class Solver:
     def bench_flux(self, l: int, launches: int) -> float:
         t = C.c_double()
         self._c(self.lib.mgcfd_bench_flux(self.handle, l, launches, C.byref(t)))
+        return t.value
+
+    def bench_stream_ceiling(self, l: int, launches: int) -> float:
+        """Mean seconds per launch of a tile-shaped stream of exactly the flux launch's algorithmic bytes (mgcfd_bench_stream_ceiling)."""
+        t = C.c_double(0.0)
+        self._c(self.lib.mgcfd_bench_stream_ceiling(self.handle, l, launches, C.byref(t)))
         return t.value
 
     def bench_indirect_rw(self, l: int, launches: int) -> float:

@@ -371,11 +371,20 @@ def test_bench_line_at_the_drivers_arguments():
     assert 0.3 < roof["frac"] < 0.8 and 10.0 < roof["empirical_ceiling_us"] < roof["avg_kernel_us"]
     assert roof["traffic"] is None or (roof["traffic"] >= roof["algorithmic_bytes_per_launch"] and "profiles/" in roof["traffic_source"])
     assert roof["fused_stage"]["launches"] == 60
+    # a fused stage priced on what it must move (40 E + 128 N) beside the two-loop figure, and the traffic ratios as numbers
+    fs = roof["fused_stage"]
+    assert fs["bytes_a_fused_stage_must_move"] == 40 * 888822 + 128 * 300763 and 0.3 < fs["frac_of_bytes_a_fused_stage_must_move"] < fs["frac"]
+    assert roof["traffic"] is None or abs(roof["traffic_over_algorithmic"] - roof["traffic"] / roof["algorithmic_bytes_per_launch"]) < 1e-3
+    # the practical ceiling: a tile-shaped stream of exactly the algorithmic bytes, faster than the kernel and slower than the chip's peak
+    assert 7.45 < roof["practical_ceiling_us"] < roof["avg_kernel_us"] and abs(roof["flux_over_practical_ceiling"] - roof["avg_kernel_us"] / roof["practical_ceiling_us"]) < 2e-3
     # (FMA contraction allowed: the same launch, a little faster, reported beside the bit-identical figure)
     assert 10.0 < roof["fma_contracted"]["avg_kernel_us"] < 1.05 * roof["avg_kernel_us"] and "1e-12" in roof["fma_contracted"]["numerics"]
     assert 0.0002 < d["vcycle"]["wall_s_per_cycle"] < 0.001
     cpu = d["cpu_baseline"]
     assert cpu["unit"] == "Medges/s" and cpu["cores"] == 1 and cpu["kind"] in ("reference", "port") and cpu["value"] > 1 and cpu["sample"] and cpu["cpu_model"]
+    # (the threaded figure says how many threads it ran and how many cores the process may use)
+    mt = cpu["multi_thread"]
+    assert 1 <= mt["threads"] <= mt["cores_usable_by_this_process"] and mt["value"] > cpu["value"]
 
 
 def test_bench_rehearsal_two_ranks_on_this_gpu():
@@ -410,30 +419,70 @@ def test_bench_rehearsal_two_ranks_on_this_gpu():
 
 
 @pytest.mark.parametrize("fail,expect", [("attach", "the library's rank loop not used"), ("phase", "not used"),
-                                         ("ipc-start", "differs from the torch path"), ("ipc-end", "discarded after the run")])
+                                         ("ipc-start", "differs from the torch path"), ("ipc-end", "discarded after the run"),
+                                         ("vcycle-setup", "the library's cycle loop not used"), ("vcycle-cycles", "mgcfd_rank_cycles not used"),
+                                         ("group-setup", "injected failure (group-setup)"), ("group-end", "counts")])
 def test_bench_form_ladder_survives_injected_failures(fail, expect):
     """What the first run on several GPUs will execute, with something breaking on ONE rank at every rung of bench.py's ladder
     (MGCFD_BENCH_FAIL, rehearsal: both ranks on this device over gloo): the library's rank set-up raising, its start-up sweep
-    raising mid-phase, the IPC form failing its start-up check, the IPC form's final state failing its check.  Every time the
-    run must END — within the bound, never a stuck rank — with a valid line from a fall-back (ultimately the torch path)."""
+    raising mid-phase, the IPC form failing its start-up check, the IPC form's final state failing its check; in the V-cycle leg
+    the library's set-up raising and a rank finding something wrong just before mgcfd_rank_cycles (every rank must then stay out
+    of that loop: round 3's advisor finding); in the in-process group leg its set-up raising and its final state failing the
+    check.  Every time the run must END — within the bound, never a stuck rank — with a valid line from a fall-back."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MGCFD_BENCH_REHEARSAL="1", MGCFD_BENCH_FAIL=fail, MGCFD_BENCH_WATCHDOG_S="240")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--lattice", "30", "--no-vcycle"],
+    env = dict(os.environ, MGCFD_BENCH_REHEARSAL="1", MGCFD_BENCH_FAIL=fail, MGCFD_BENCH_WATCHDOG_S="240", MGCFD_BENCH_LEG_S="200")
+    legs = ["--vcycle-hierarchy", "tiny", "--no-group"] if fail.startswith("vcycle") else (["--no-vcycle"] if fail.startswith("group") else ["--no-vcycle", "--no-group"])
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--lattice", "30"] + legs,
                        capture_output=True, text=True, env=env, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["workload_kind"] == "partitioned"
     ex = line["config"]["exchange"]
+    if fail.startswith("vcycle"):
+        # the V-cycle leg ended on the torch orchestration, said why, and nobody was left inside the library's loop
+        vc = line["vcycle"]
+        assert any(expect in n for n in vc["notes"]), vc["notes"]
+        assert vc["wall_s_per_cycle"] > 0 and vc["state_valid"] and vc["form"].startswith("torch.distributed")
+        return
+    if fail.startswith("group"):
+        g = line["in_process_group"]
+        if fail == "group-setup":
+            assert expect in g["error"], g
+        else:
+            assert g["sweeps"]["counts"] is False and g["sweeps"]["nodes_differing_from_the_unpartitioned_level"] == 1, g
+        return
     assert expect in ex, ex
     # what the library itself says it is a rank of (not what the launcher said)
     assert line["config"]["halo_bytes_per_stage_rank0_sent"] > 0
     if fail == "attach":
         assert ex.startswith("torch.distributed")                           # nothing of the library's loop was usable: the torch path ran
     assert line["config"]["library_ranks"]["ranks"] == 2                    # (rank 0's own attachment succeeded in every case)
+
+
+def test_bench_in_process_group_leg_on_this_gpu():
+    """`bench.py --gpus 2` (rehearsal: both ranks and both group members on this device): beside the ranks' figure the line
+    carries `in_process_group` — the level and the hierarchy swept by ONE process through mgcfd_group_sweeps / mgcfd_group_cycles —
+    and its sweeps' final state equals the unpartitioned level's bit for bit (a figure that fails that check says so)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGCFD_BENCH_REHEARSAL="1", MGCFD_BENCH_WATCHDOG_S="300")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--lattice", "30", "--vcycle-hierarchy", "tiny"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    g = line["in_process_group"]
+    assert "error" not in g, g
+    assert g["ranks"] == 2 and "REHEARSAL" in g["form"]
+    assert g["sweeps"]["counts"] is True and g["sweeps"]["nodes_differing_from_the_unpartitioned_level"] == 0 and g["sweeps"]["value"] > 0
+    assert g["vcycle"]["wall_s_per_cycle"] > 0 and g["vcycle"]["state_valid"]
+    assert line["vcycle"]["wall_s_per_cycle"] > 0                              # (the ranks' own V-cycle leg beside it)
 
 
 def _group_sweeps_check(mg, n_parts, sweeps, partitioner="rcb"):

@@ -63,17 +63,36 @@ def run():
         nn = a[lo:hi, 7].sum()
         if nn > 0: print(f"  {nm}: " + " | ".join(f"{a[lo:hi, k].sum() / nn / 100.0:.2f}" for k in range(6)))
     if hasattr(lib, "mgcfd_debug_phase_abs"):
-        ab = (C.c_ulonglong * (4096 * 2))()
+        # the LAST launch: absolute times of every mark (100 MHz ticks) and where each workgroup ran
+        ab = (C.c_ulonglong * (4096 * 8))()
         lib.mgcfd_debug_phase_abs(ab)
         nb = min(4096, s.nel(0) // 256 + (1 if s.nel(0) % 256 else 0))
-        b = np.ctypeslib.as_array(ab).reshape(4096, 2)[:nb].astype(np.int64)
+        b = np.ctypeslib.as_array(ab).reshape(4096, 8)[:nb].astype(np.int64)
+        nmark = max(k for k in range(6) if b[:, 1 + k].max() > 0) + 1
         t0 = b[:, 0].min()
-        st, en = (b[:, 0] - t0) / 100.0, (b[:, 1] - t0) / 100.0
+        st, en = (b[:, 0] - t0) / 100.0, (b[:, nmark] - t0) / 100.0
         print(f"  last launch: workgroups begin 0 .. {st.max():.2f} us, end {en.min():.2f} .. {en.max():.2f} us; lifetime mean {np.mean(en - st):.2f} max {np.max(en - st):.2f}")
         hist, edges = np.histogram(st, bins=12)
         print("  begin-time histogram:", " ".join(f"{e:.1f}:{h}" for h, e in zip(hist, edges[:-1])))
         hist, edges = np.histogram(en, bins=12)
         print("  end-time histogram:  ", " ".join(f"{e:.1f}:{h}" for h, e in zip(hist, edges[:-1])))
+        first = st < 1.0
+        for nm, sel in (("first round (begin < 1 us)", first), ("later rounds", ~first)):
+            if sel.sum() == 0: continue
+            print(f"  {nm}: {sel.sum()} workgroups; time of each mark since the launch's first workgroup began, us (min / 10% / median / 90% / max)")
+            for k in range(nmark + 1):
+                v = (b[sel, k] - t0) / 100.0
+                q = np.percentile(v, [0, 10, 50, 90, 100])
+                print(f"    {'begin' if k == 0 else 'mark %d' % (k - 1):8s} " + " / ".join(f"{x:6.2f}" for x in q))
+        hw = b[:, 7] & 0xFFFFFFFF; xcc = (b[:, 7] >> 32) & 0xF
+        cu = (xcc << 16) | (hw & 0xFF00)                      # XCC_ID, SE_ID/SH_ID/CU_ID of HW_ID
+        ids, cnt = np.unique(cu, return_counts=True)
+        last_end = np.array([en[cu == c].max() for c in ids])
+        print(f"  {len(ids)} CUs ran the launch; workgroups per CU: " + " ".join(f"{k}:{(cnt == k).sum()}" for k in sorted(set(cnt))))
+        for k in sorted(set(cnt)):
+            print(f"    CUs with {k} workgroups: last end mean {last_end[cnt == k].mean():.2f} max {last_end[cnt == k].max():.2f} us")
+        per_x = [f"{x}:{(xcc == x).sum()}/{en[xcc == x].max():.1f}" for x in sorted(set(xcc))]
+        print("  per XCD workgroups / last end:", " ".join(per_x))
 
 if __name__ == "__main__":
     (build if sys.argv[1] == "build" else run)()

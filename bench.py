@@ -206,9 +206,9 @@ def cpu_baseline(levels, sample_seconds: float):
     # process-wide statistics nobody reads here; its arithmetic touches only the arrays passed in).
     try:
         import threading
-        # every core this process may use, up to 64 (the pass count per thread is fixed, so the sample's wall time does not
-        # grow with the thread count as long as the cores are there; a one-GPU box's share may be 16 of them)
-        cores = max(1, min(cores_usable, int(os.environ.get("MGCFD_BENCH_CPU_THREADS", "64"))))
+        # 16 threads unless MGCFD_BENCH_CPU_THREADS says otherwise: a one-GPU box's CPU share is 16 cores whatever the host has and
+        # whatever the affinity mask says (64 threads there: 186 Medges/s in 42 s against 377 in 11 s with 16, profiles/r4_*)
+        cores = max(1, min(cores_usable, int(os.environ.get("MGCFD_BENCH_CPU_THREADS", "16"))))
         per = max(2, int(sample_seconds / 4.0 / max(one, 1e-6)))
         state = [(q.copy(), np.zeros_like(q)) for _ in range(cores)]
         if have_ref and os.environ.get("MGCFD_BENCH_ALLCORES_PORT") != "1":
@@ -231,6 +231,7 @@ def cpu_baseline(levels, sample_seconds: float):
         dt_all = time.perf_counter() - t0
         out["multi_thread"] = {"value": round(n_int * per * cores / dt_all / 1e6, 3), "unit": "Medges/s", "threads": cores, "cores": cores, "kind": all_kind,
                                "cores_usable_by_this_process": cores_usable, "host_cores": cores_total,
+                               "threads_note": "16 by default = the CPU share of a one-GPU box (MGCFD_BENCH_CPU_THREADS overrides); not the host's core count",
                                "sample": f"{cores} threads x {per} passes, one private copy of the level's state per thread ({dt_all:.1f} s), {all_how}"}
     except Exception as e:                                   # the single-core figure stands on its own
         out["multi_thread"] = {"error": str(e)}
@@ -507,9 +508,11 @@ def in_process_group_leg(args, world, lattice, level_built, sizes, hierarchy_bui
             ff = sv.far_field()[:5]
             for l in range(len(lv)):
                 sv.set(l, "variables", np.tile(ff, (int(lv[l]["nel"]), 1)))
-                sv.rank_set_halo(l, H.levels[l])
             solvers.append(sv)
         g = mgcfd.Group(solvers)
+        for H, sv in zip(Hs, solvers):
+            for l in range(len(sizes)):
+                sv.rank_set_halo(l, H.levels[l])
         for l in range(len(sizes)):
             g.exchange(l)
         g.cycles(cycles, rms=False); g.synchronize()

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <numeric>
 #include <deque>
@@ -260,6 +261,15 @@ void adjust_and_dampen(const mgcfd_level_desc &L, int mesh_variant, std::vector<
 void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &edges,
                       const PlanOptions &opt, LevelPlan &P)
 {
+    // MGCFD_PLAN_TIMING=1: where the host time of a level's plan goes (stderr)
+    const bool timing = std::getenv("MGCFD_PLAN_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mgcfd plan %ld nodes] %-28s %7.1f ms\n", (long)L.nel, what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const int64_t nel = L.nel;
     if (nel <= 0 || nel >= (int64_t(1) << 29)) throw std::runtime_error("level size out of range for 29-bit node ids");
     for (int64_t e = L.internal_start; e < L.internal_start + L.n_internal; e++)
@@ -279,6 +289,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         return owned(v) ? g.ptr[static_cast<size_t>(v) + 1] - g.ptr[static_cast<size_t>(v)] : 0;
     };
 
+    lap("adjacency");
     // ---- node order ----
     // A partitioned level (n_owned < nel): the OWNED nodes are clustered among themselves and numbered first, the ghosts
     // follow in their given order.  Tiles past the owned nodes hold only ghosts and are never launched, and a launch that
@@ -320,6 +331,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     }
     else if (opt.ordering == 1) order = cuthill_mckee(g, nel);
     else { order.resize(static_cast<size_t>(nel)); std::iota(order.begin(), order.end(), 0); }
+    lap("node order");
     // ---- half rows (preprocess.hpp): which end point evaluates an internal edge.  An edge whose end points share a
     //      tile (and are both owned) is evaluated by ONE of them; any other edge by each owned end point in its own tile.
     //      Orientation: greedy to the less loaded end, then flips from a node to a neighbour at least two below it until
@@ -352,6 +364,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             if (!moved) break;
         }
     }
+    lap("half-row orientation");
     std::vector<int32_t> bnd_count(static_cast<size_t>(nel), 0);
     for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++) if (owned(edges[e].b)) bnd_count[static_cast<size_t>(edges[e].b)]++;
     for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++) if (owned(edges[e].b)) bnd_count[static_cast<size_t>(edges[e].b)]++;
@@ -388,6 +401,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             });
         }
     }
+    lap("degree / facing sort");
     P.old_of_new = order;
     P.new_of_old.assign(static_cast<size_t>(nel), 0);
     for (int64_t n = 0; n < nel; n++) P.new_of_old[static_cast<size_t>(order[static_cast<size_t>(n)])] = static_cast<int32_t>(n);
@@ -452,6 +466,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     for (int64_t e = L.boundary_start; e < L.boundary_start + L.n_boundary; e++) add_face(edges[static_cast<size_t>(e)], kCodeWall, 1.0);
     for (int64_t e = L.wall_start; e < L.wall_start + L.n_wall; e++) add_face(edges[static_cast<size_t>(e)], kCodeFar, 0.5);
 
+    lap("rows filled");
     // ---- tiles: halo lists and 16-bit tile-local neighbour codes ----
     P.nbr16.assign(P.nbr.size(), static_cast<uint16_t>(kT16Pad));
     P.tile_halo_ptr.assign(static_cast<size_t>(P.n_tiles) + 1, 0);
@@ -719,6 +734,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         }
     }
 
+    lap("tile loop");
     // two-phase design point: per-edge arrays in original order and the rows' edge references
     {
         const size_t ne = static_cast<size_t>(L.n_internal);
@@ -737,6 +753,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             if (entry_edge[e] >= 0)
                 P.row_edge[e] = static_cast<int32_t>(static_cast<uint32_t>(entry_edge[e]) | ((P.nbr[e] & kRoleB) ? 0x80000000u : 0u));
     }
+    lap("fission arrays");
     // ---- long rows: per tile, the row limit that minimises the estimated time of its workgroup ----
     // Units: one pair of rows of the per-node loop = 1.  The four waves walk their slices side by side, so the loop
     // costs the longest slice; the workgroup's list costs a fixed part (barrier, scratch round trip), a part per round
@@ -819,6 +836,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     if (!P.free_rows) { P.hr_row0.clear(); P.hr_code.clear(); P.hr_w.clear(); P.hg16.clear(); P.hr_entries = 0; P.hr_foreign = 0; }
     else P.hr_padding = int64_t(P.hr_row0.back()) * kSlice - P.hr_entries;
 
+    lap("long rows");
     P.n_internal_entries = useful;
     int64_t int_slots = 0;
     for (int32_t s = 0; s < P.n_slices; s++) int_slots += static_cast<int64_t>(P.rows_int[static_cast<size_t>(s)]) * kSlice;

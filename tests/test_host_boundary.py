@@ -137,6 +137,42 @@ def test_reader_accepts_what_operator_extraction_accepts(mgcfd_mod, tmp_path):
     want.close()
 
 
+def test_reader_rounds_every_spelling_of_a_number_as_strtod_does(mgcfd_mod, tmp_path):
+    """The readers convert numbers with std::from_chars (round 4: the 75 MB level file is most of the drop-in's start-up) and
+    fall back to strtod for what from_chars does not take.  Every spelling must give the bits strtod gives — Python's float()
+    is the same correctly rounded conversion: long mantissas, halfway cases, subnormals, overflow to infinity, a leading '+',
+    capital exponents, hexadecimal floats, a file without a final newline, form feeds and vertical tabs between tokens."""
+    import random
+    rng = random.Random(5)
+    spell = ["1", "-1", "+1.5", "1E5", "1e+5", "-1.25e-3", "0.1", "0.30000000000000004", "2.2250738585072014e-308", "4.9e-324",
+             "2.4703282292062328e-324", "1.7976931348623157e308", "1e400", "-1e400", "1e-400", "9007199254740993", "9007199254740992.5",
+             "0.000000000000000000000000000000123456789012345678901234567890", "123456789012345678901234567890.123456789",
+             "5e-1", ".5", "5.", "0x1.8p1", "-0X1P-3", "1.0000000000000002220446049250313", "1.00000000000000011102230246251565404236316680908203125",
+             "1.00000000000000011102230246251565404236316680908203126", "8.5e-1"]
+    for _ in range(400):
+        spell.append(f"{'-' if rng.random() < 0.5 else ''}{rng.randrange(10 ** rng.randrange(1, 25))}.{rng.randrange(10 ** rng.randrange(1, 25))}e{rng.randrange(-330, 310)}")
+    want = [float.fromhex(t) if "x" in t.lower() else float(t) for t in spell]
+    n = len(spell)
+    # a level of n nodes without edges: the volumes carry the spellings; separators of every kind, no newline at the end
+    seps = [" ", "\t", "\n", "\r\n", " \v ", "\f", "  "]
+    body = f"{n} 0"
+    for t in spell:
+        body += rng.choice(seps) + t + rng.choice(seps) + "0"
+    (tmp_path / "lvl").write_bytes(body.encode())
+    (tmp_path / "in.dat").write_text("size = 1\nnum_levels = 1\nmesh_name = fvcorr\n[levels]\n0 = lvl\n")
+    m = mgcfd_mod.Mesh("in.dat", str(tmp_path))
+    got = m.level(0)["volumes"]
+    assert got.shape == (n,)
+    assert np.array_equal(got.view(np.int64), np.asarray(want, dtype=np.float64).view(np.int64)), [(t, g, w) for t, g, w in zip(spell, got, want) if not (g == w or (g != g and w != w))][:5]
+    m.close()
+    # integers: a leading '+', and a count that runs into the end of the file
+    (tmp_path / "lvl2").write_bytes(b"+2 +0 1.0 +0 2.0 0")
+    (tmp_path / "in2.dat").write_text("size = 1\nnum_levels = 1\nmesh_name = fvcorr\n[levels]\n0 = lvl2\n")
+    m = mgcfd_mod.Mesh("in2.dat", str(tmp_path))
+    assert list(m.level(0)["volumes"]) == [1.0, 2.0]
+    m.close()
+
+
 def test_dump_format_and_validation_rule(mgcfd_mod, tmp_path):
     lib = mgcfd_mod.load_library()
     a = np.array([[1.4, 1.68, 0.0, -1e-300, 3.508], [np.pi, -np.e, 1e22, 5e-324, 2.0]])

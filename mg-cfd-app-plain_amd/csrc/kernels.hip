@@ -1511,7 +1511,13 @@ constexpr int kFreeCap4 = 546;
 // LONG: some slice of the level holds more half rows than the prologue requests (the loop behind the unrolled pairs exists)
 // WIDE: some tile's halo exceeds the shared table's 303 ids: the halo comes from the kernel's own table, two ids per thread
 //       (tile_halo then points at it, stride kFreeHaloStride; CAP = kTile + kFreeHaloStride)
-template <bool FUSE, bool ACC, int CAP, bool LONG, bool WIDE = false>
+// ROLE (fused stages, round 4): -1 = the generic epilogue (finish_node: every optional path behind a run-time test, the
+// step-factor partials reduced before anything else is requested); 0 ... 3 = k_flux_tile's role specialisation — 0 the first
+// stage (finishes compute_step_factor: the partials are requested with the prologue and reduced under the staging barrier; the
+// sweep's start state IS this stage's input, nothing of it is loaded twice), 1 a middle stage, 2 the last stage (residual or
+// its squares), 3 the last stage that also leaves the next sweep's step-factor minima — with the time_step operands requested
+// right behind the staging barrier, so that they arrive while the half rows are evaluated.
+template <bool FUSE, bool ACC, int CAP, bool LONG, bool WIDE = false, int ROLE = -1>
 __global__ void __launch_bounds__(kBlock, CAP <= kFreeCap4 ? 4 : 3)
 k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue's first loads need)
             const double *__restrict__ q, const int32_t *__restrict__ tile_halo, uint32_t n_tiles, int32_t hr_pad_row,
@@ -1526,8 +1532,13 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
     __shared__ double acc[5 * kTile];               // the sums neighbours leave for this tile's own nodes, [field][node]
 
     PH_BEGIN();
+    constexpr bool SPEC = FUSE && ROLE >= 0;
+    static_assert(ROLE < 0 || FUSE, "roles belong to the fused stages");
     double min_dt = 0.0;
-    if (FUSE && fs.partial_min) min_dt = block_min_of_partials(fs.partial_min, fs.n_partial);
+    if (FUSE && !SPEC && fs.partial_min) min_dt = block_min_of_partials(fs.partial_min, fs.n_partial);
+    constexpr int kPartPre = 6;                     // step-factor partials per thread held in registers (1,536 tiles)
+    __shared__ double s_pm[kBlock / 64];
+    double pmv[kPartPre];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1586,6 +1597,13 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
     double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0, u4 = 0.0;
     if (WIDE) { u0 = q[hnode2]; u1 = q[stride + hnode2]; u2 = q[2 * stride + hnode2]; u3 = q[3 * stride + hnode2]; u4 = q[4 * stride + hnode2]; }
 
+    if (SPEC && ROLE == 0) {                        // (requested last: wanted only at the staging barrier)
+#pragma unroll
+        for (int u = 0; u < kPartPre; u++) {
+            const int k = threadIdx.x + u * kBlock;
+            pmv[u] = fs.partial_min[k < fs.n_partial ? k : fs.n_partial - 1];     // clamped: a repeat does not change a minimum
+        }
+    }
 #pragma unroll
     for (int f = 0; f < 5; f++) acc[f * kTile + tid] = 0.0;
     const NodeF me = make_nodef(o0, o1, o2, o3, o4);
@@ -1602,9 +1620,35 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
         a0 = fluxes[i]; a1 = fluxes[stride + i]; a2 = fluxes[2 * stride + i];
         a3 = fluxes[3 * stride + i]; a4 = fluxes[4 * stride + i];
     }
+    if (SPEC && ROLE == 0) {
+        double pm = pmv[0];
+#pragma unroll
+        for (int u = 1; u < kPartPre; u++) pm = fmin(pm, pmv[u]);
+        for (int k = threadIdx.x + kPartPre * kBlock; k < fs.n_partial; k += kBlock) pm = fmin(pm, fs.partial_min[k]);
+        pm = wave_min(pm);
+        if (lane == 0) s_pm[tid >> 6] = pm;
+    }
     PH_MARK(0);
     __syncthreads();
     PH_MARK(1);
+    // role-specialised stages: the time_step operands go out behind the first pair of half rows (whose registers they take)
+    // and arrive under the others
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, sfv = 0.0;
+    auto request_operands = [&](int part) {        // part 0 behind the first pair, part 1 behind the second (the register budget of four waves per SIMD)
+        if (ROLE == 0) {
+            // the first stage's input IS the sweep's start state (the launcher checks q == old_variables): rho and E are in the
+            // node's record, the momenta are rho v again (this kernel's results are not the reference's bits anyway)
+            if (part == 0) { r0 = me.rho; r1 = mo.mx; r2 = mo.my; r3 = mo.mz; r4 = me.en; sfv = fs.volumes[i]; }
+        } else if (part == 0) {
+            r0 = fs.old_variables[i]; r1 = fs.old_variables[stride + i]; r2 = fs.old_variables[2 * stride + i];
+            r3 = fs.old_variables[3 * stride + i];
+        } else {
+            r4 = fs.old_variables[4 * stride + i];
+            sfv = fs.step_factors[i];
+        }
+    };
+    if (SPEC && n_h <= 0) request_operands(0);      // (uniform over the wave: a slice without half rows)
+    if (SPEC && n_h <= 2) request_operands(1);
 
     // ---- this lane's half rows, two at a time (independent arithmetic; a half row the slice does not have was read from the
     //      padding row: zero weights, nothing added) ----
@@ -1649,6 +1693,8 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
             eval(er[j], false);
             if (two) eval(er[j + 1 < kHalfMaxRows ? j + 1 : j], false);
         }
+        if (SPEC && j == 0) request_operands(0);
+        if (SPEC && j == 2) request_operands(1);
     }
     // a slice with more half rows than the prologue requests (tetrahedral regions, hubs: the plan spreads a high-degree node's
     // evaluations over the tile's lanes, preprocess.hpp kFreeMaxRows): the rest one at a time, two in flight
@@ -1689,7 +1735,61 @@ k_flux_free(// (the first 16 dwords are preloaded into SGPRs: what the prologue'
             }
         }
     }
-    finish_node<FUSE>(i, nel, stride, a0, a1, a2, a3, a4, fluxes, fs, min_dt, t);
+    if (!SPEC) {
+        finish_node<FUSE>(i, nel, stride, a0, a1, a2, a3, a4, fluxes, fs, min_dt, t);
+        PH_MARK(4);
+        return;
+    }
+    // ---- fused time_step, role-specialised (k_flux_tile's epilogue: the same operations as k_time_step, cfd_loops.cpp:241-268) ----
+    double sf_next = __longlong_as_double(0x7FF0000000000000LL);          // +inf: lanes past nel
+    double ss = 0.0;                                                      // this node's share of the residual sum of squares
+    if (i < nel) {
+        double sf = sfv;
+        if (ROLE == 0) {                            // finish compute_step_factor (cfd_loops.cpp:137-156)
+            min_dt = s_pm[0];
+            for (int wv = 1; wv < kBlock / 64; wv++) min_dt = fmin(min_dt, s_pm[wv]);
+            sf = min_dt / sfv;                      // sfv holds the volume
+            MGCFD_ST_STAGE(fs.step_factors + i, sf);
+        }
+        const double factor = sf / fs.rk_div;
+        const double rho = r0 + factor * a0, mx = r1 + factor * a1, my = r2 + factor * a2, mz = r3 + factor * a3,
+                     en = r4 + factor * a4;
+        store_conserved(fs.q_out, stride, i, rho, mx, my, mz, en);
+        if (ROLE >= 2) {                            // last stage: residual (validation.cpp:77-89)
+            const double d0 = rho - r0, d1 = mx - r1, d2 = my - r2, d3 = mz - r3, d4 = en - r4;
+            if (fs.residuals) {                      // (null: the caller writes it on demand, solver.cpp settle_residuals)
+                MGCFD_ST_STAGE(fs.residuals + i, d0); MGCFD_ST_STAGE(fs.residuals + stride + i, d1); MGCFD_ST_STAGE(fs.residuals + 2 * stride + i, d2);
+                MGCFD_ST_STAGE(fs.residuals + 3 * stride + i, d3); MGCFD_ST_STAGE(fs.residuals + 4 * stride + i, d4);
+            }
+            if (fs.sumsq_partial) ss = (((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3) + d4 * d4;
+        }
+        if (fs.check) {
+            const bool finite = isfinite(rho) && isfinite(mx) && isfinite(my) && isfinite(mz) && isfinite(en);
+            int code = 0;
+            if (!finite) code = 1;
+            else if (rho < 0.0) code = 2;
+            else if (en < 0.0) code = 3;
+            if (code) atomicMin(fs.err, err_key(fs.check, fs.old_of_new[i], code));
+        }
+        if (ROLE == 3) {                            // look-ahead: the next sweep's compute_step_factor starts from the state just produced
+            const Derived d = derive(rho, mx, my, mz, en);
+            const double dt = fs.cbrt_vol[i] / (d.speed + d.c);          // k_step_factor_local
+            sf_next = 0.5 * dt;
+        }
+    }
+    if (ROLE == 3 || (ROLE == 2 && fs.sumsq_partial)) {                // uniform: every thread of the workgroup takes part
+        __shared__ double s_next[2][kBlock / 64];
+        if (ROLE == 3) sf_next = wave_min(sf_next);
+        if (fs.sumsq_partial) ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) { s_next[0][threadIdx.x >> 6] = sf_next; s_next[1][threadIdx.x >> 6] = ss; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double m = s_next[0][0], sum = s_next[1][0];
+            for (int wv = 1; wv < kBlock / 64; wv++) { m = fmin(m, s_next[0][wv]); sum += s_next[1][wv]; }
+            if (ROLE == 3) fs.next_partial_min[t] = m;
+            if (fs.sumsq_partial) fs.sumsq_partial[t] = sum;
+        }
+    }
     PH_MARK(4);
 }
 #endif // MGCFD_ORDER_FREE
@@ -2519,9 +2619,25 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
 #define MGCFD_FREE_LAUNCH(FUSE, ACC)                                                                            \
     do { if (p.free_wide) MGCFD_FREE_LAUNCH_W(FUSE, ACC);                                                       \
          else if (p.halo_max <= kFreeCap4 - kTile && !wg3) MGCFD_FREE_LAUNCH_C(FUSE, ACC, kFreeCap4); else MGCFD_FREE_LAUNCH_C(FUSE, ACC, kTileCap); } while (0)
-        if (fused) MGCFD_FREE_LAUNCH(true, false);
+        // fused stages of levels on the fast path (halos within the smaller LDS image, at most five half rows per lane): the
+        // role-specialised instantiations; fvcorr's look-ahead and every other configuration: the generic epilogue
+        const int role_f = !fused ? -1 : (fs.next_legacy_sf ? -1 : (fs.partial_min ? 0 : (fs.next_partial_min ? 3 : ((fs.residuals || fs.sumsq_partial) ? 2 : 1))));
+        static const bool no_roles = std::getenv("MGCFD_FREE_NO_ROLES") && std::atoi(std::getenv("MGCFD_FREE_NO_ROLES")) != 0;   // (A/B)
+        const bool fast_path = !p.free_wide && p.halo_max <= kFreeCap4 - kTile && !wg3 && p.hr_max_rows <= kHalfMaxRows;
+#define MGCFD_FREE_LAUNCH_ROLE(ROLE)                                                                            \
+    hipLaunchKernelGGL((k_flux_free<true, false, kFreeCap4, false, false, ROLE>), grid, block, 0, st, q, p.tile_halo, uint32_t(p.n_tiles), \
+                       p.hr_pad_row, p.stride, p.nel, p.hr_row0, p.hr_code, p.hr_w, p.slice_row0,               \
+                       p.rows_int, p.rows_bnd, p.nbr16, p.w, ff, fluxes, classes, fs)
+        if (fused && role_f >= 0 && fast_path && !no_roles && !(role_f == 0 && q != fs.old_variables)) {
+            if (role_f == 0) MGCFD_FREE_LAUNCH_ROLE(0);
+            else if (role_f == 2) MGCFD_FREE_LAUNCH_ROLE(2);
+            else if (role_f == 3) MGCFD_FREE_LAUNCH_ROLE(3);
+            else MGCFD_FREE_LAUNCH_ROLE(1);
+        }
+        else if (fused) MGCFD_FREE_LAUNCH(true, false);
         else if (accumulate) MGCFD_FREE_LAUNCH(false, true);
         else MGCFD_FREE_LAUNCH(false, false);
+#undef MGCFD_FREE_LAUNCH_ROLE
 #undef MGCFD_FREE_LAUNCH_C
 #undef MGCFD_FREE_LAUNCH_L
 #undef MGCFD_FREE_LAUNCH_W

@@ -16,6 +16,7 @@
 #include <queue>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 namespace mgcfd {
 
@@ -480,250 +481,322 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     P.te_w.clear();
     P.edge_once = true;
     {
-        std::vector<int32_t> halo, tile_edges;
-        std::vector<std::array<int64_t, 4>> half_ents;      // {edge, entry index, thread of the node, its half row or -1}
-        std::vector<std::pair<int32_t, int32_t>> half_where;
+        // The tiles are independent of each other: contiguous ranges of them are worked through by a thread each into a part of
+        // its own (appended lists, prefix arrays counted from the range's start), and the parts are joined in tile order — the
+        // plan is the same whatever the number of threads (round 4: this loop was most of the drop-in's start-up time).
+        struct Part {
+            std::vector<int32_t> tile_halo, tile_ovf, tile_halo_ptr, tile_ovf_ptr, te_chunk_ptr, hr_row0;
+            std::vector<uint16_t> te_slots;
+            std::vector<double> te_w, hr_w;
+            std::vector<uint32_t> hr_code;
+            bool edge_once = true, free_rows = true, free_wide = false;
+            int32_t halo_max = 0, te_max = 0, hr_max_rows = 0, hr_max_tile_rows = 0;
+            int64_t halo_total = 0, te_total = 0, halo_overflow_refs = 0, hr_entries = 0, hr_foreign = 0;
+            std::exception_ptr error;
+        };
         P.free_rows = true;
         P.hr_max_rows = P.hr_max_tile_rows = 0;
         P.free_wide = false;
-        P.free_halo.clear();
-        std::vector<int32_t> halo_all;                  // a tile's halo ids, ALL of them ascending (the order-free kernel's own numbering)
+        P.free_halo.assign(static_cast<size_t>(P.n_tiles) * kFreeHaloStride, -1);
         P.hr_row0.assign(static_cast<size_t>(P.n_slices) + 1, 0);
         P.hr_code.clear(); P.hr_w.clear(); P.hr_foreign = 0;
         P.hg16.assign(P.nbr.size(), static_cast<uint16_t>(kT16Pad));
         P.hr_entries = 0;
-        int64_t te_total = 0;
         const int32_t halo_cap = kTileCap - kTile;
         const int32_t ovf_cap = int32_t(kT16Far) - kTileCap;          // overflow slots a 15-bit code can name
-        int64_t halo_total = 0;
-        for (int32_t t = 0; t < P.n_tiles; t++) {
-            const int32_t base = t * kTile;
-            const int32_t s0 = t * (kTile / kSlice), s1 = s0 + kTile / kSlice;
-            const int64_t e0 = int64_t(P.slice_row0[static_cast<size_t>(s0)]) * kSlice;
-            const int64_t e1 = int64_t(P.slice_row0[static_cast<size_t>(s1)]) * kSlice;
-            halo.clear();
-            for (int64_t e = e0; e < e1; e++) {
-                const int32_t code = P.nbr[static_cast<size_t>(e)];
-                if (code < 0) continue;
-                const int32_t id = code & kIdMask;
-                if (id < base || id >= base + kTile) halo.push_back(id);
-            }
-            std::sort(halo.begin(), halo.end());
-            const int32_t n_refs = static_cast<int32_t>(halo.size());
-            halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
-            const int32_t n_halo = static_cast<int32_t>(halo.size());
-            const int32_t staged = std::min<int32_t>(n_halo, halo_cap);
-            if (n_halo > staged) {
-                // more halo nodes than the LDS tile holds: stage the most referenced ones, leave the least
-                // referenced to the overflow table (each use of those is a gather from HBM); both parts ascending
-                std::vector<std::pair<int32_t, int32_t>> by_refs;                // (-references, id)
-                by_refs.reserve(static_cast<size_t>(n_halo));
-                {
-                    std::vector<int32_t> all;
-                    all.reserve(static_cast<size_t>(n_refs));
-                    for (int64_t e = e0; e < e1; e++) {
-                        const int32_t code = P.nbr[static_cast<size_t>(e)];
-                        if (code < 0) continue;
-                        const int32_t id = code & kIdMask;
-                        if (id < base || id >= base + kTile) all.push_back(id);
-                    }
-                    std::sort(all.begin(), all.end());
-                    for (size_t i = 0; i < all.size();) {
-                        size_t j = i;
-                        while (j < all.size() && all[j] == all[i]) j++;
-                        by_refs.emplace_back(-static_cast<int32_t>(j - i), all[i]);
-                        i = j;
-                    }
-                }
-                std::sort(by_refs.begin(), by_refs.end());
-                for (int32_t k = 0; k < n_halo; k++) halo[static_cast<size_t>(k)] = by_refs[static_cast<size_t>(k)].second;
-                std::sort(halo.begin(), halo.begin() + staged);
-                std::sort(halo.begin() + staged, halo.end());
-            }
-            // position of a halo id in `halo` (staged part first, then the overflow part; each ascending)
-            auto halo_pos = [&](int32_t id) -> int32_t {
-                auto it = std::lower_bound(halo.begin(), halo.begin() + staged, id);
-                if (it != halo.begin() + staged && *it == id) return static_cast<int32_t>(it - halo.begin());
-                return static_cast<int32_t>(std::lower_bound(halo.begin() + staged, halo.end(), id) - halo.begin());
-            };
-            if (n_halo - staged > ovf_cap) throw std::runtime_error("tile halo exceeds what 15-bit slots can address");
-            halo_total += n_halo;
-            P.halo_max = std::max<int32_t>(P.halo_max, n_halo);
-            for (int64_t e = e0; e < e1; e++) {
-                const int32_t code = P.nbr[static_cast<size_t>(e)];
-                uint32_t c16;
-                if (code == kCodeWall) c16 = kT16Wall;
-                else if (code == kCodeFar) c16 = kT16Far;
-                else if (code < 0) c16 = kT16Pad;
-                else {
-                    const int32_t id = code & kIdMask;
-                    uint32_t slot;
-                    if (id >= base && id < base + kTile) slot = static_cast<uint32_t>(id - base);
-                    else {
-                        // the first `staged` halo ids live in LDS, the rest in the overflow table
-                        const int32_t pos = halo_pos(id);
-                        slot = static_cast<uint32_t>(kTile + pos);        // pos >= staged  =>  slot >= kTileCap
-                        if (pos >= staged) P.halo_overflow_refs++;
-                    }
-                    c16 = slot | ((code & kRoleB) ? kT16RoleB : 0u);
-                }
-                P.nbr16[static_cast<size_t>(e)] = static_cast<uint16_t>(c16);
-            }
-            // edge-once list: the tile's internal edges, once each, ascending original index.  A node's
-            // incident edges keep their relative order in it, so summing a node's entries by position
-            // is the reference's accumulation order.
-            tile_edges.clear();
-            for (int64_t e = e0; e < e1; e++)
-                if (entry_edge[static_cast<size_t>(e)] >= 0) tile_edges.push_back(entry_edge[static_cast<size_t>(e)]);
-            std::sort(tile_edges.begin(), tile_edges.end());
-            tile_edges.erase(std::unique(tile_edges.begin(), tile_edges.end()), tile_edges.end());
-            const int32_t n_te = static_cast<int32_t>(tile_edges.size());
-            P.te_count[static_cast<size_t>(t)] = n_te;
-            P.te_max = std::max(P.te_max, n_te);
-            te_total += n_te;
-            if (n_te > kMaxEdgeChunks * kEdgeChunk) P.edge_once = false;
-            if (P.edge_once) {
-                auto slot_of = [&](int32_t id) -> uint16_t {
-                    if (id >= base && id < base + kTile) return static_cast<uint16_t>(id - base);
-                    return static_cast<uint16_t>(kTile + halo_pos(id));   // >= kTileCap: overflow table, as in nbr16
-                };
-                const size_t chunk0 = static_cast<size_t>(P.te_chunk_ptr[static_cast<size_t>(t)]);
-                const size_t n_chunks = (static_cast<size_t>(n_te) + kEdgeChunk - 1) / kEdgeChunk;
-                P.te_slots.resize((chunk0 + n_chunks) * 2 * kEdgeChunk, static_cast<uint16_t>(kT16Pad));
-                P.te_w.resize((chunk0 + n_chunks) * 4 * kEdgeChunk, 0.0);
-                for (int32_t p = 0; p < n_te; p++) {
-                    const mgcfd_edge &E = edges[static_cast<size_t>(L.internal_start + tile_edges[static_cast<size_t>(p)])];
-                    const size_t c = chunk0 + static_cast<size_t>(p / kEdgeChunk), ln = static_cast<size_t>(p % kEdgeChunk);
-                    P.te_slots[(c * 2 + 0) * kEdgeChunk + ln] = slot_of(P.new_of_old[static_cast<size_t>(E.a)]);
-                    P.te_slots[(c * 2 + 1) * kEdgeChunk + ln] = slot_of(P.new_of_old[static_cast<size_t>(E.b)]);
-                    const double ewt = std::sqrt(E.x * E.x + E.y * E.y + E.z * E.z);
-                    P.te_w[(c * 4 + 0) * kEdgeChunk + ln] = -0.5 * E.x;
-                    P.te_w[(c * 4 + 1) * kEdgeChunk + ln] = -0.5 * E.y;
-                    P.te_w[(c * 4 + 2) * kEdgeChunk + ln] = -0.5 * E.z;
-                    P.te_w[(c * 4 + 3) * kEdgeChunk + ln] = -ewt * kSmoothing * 0.5;
-                }
+        auto work = [&](int32_t t_begin, int32_t t_end, Part &Q) {
+            try {
+            const int32_t s_begin = t_begin * (kTile / kSlice);
+            Q.tile_halo_ptr.assign(static_cast<size_t>(t_end - t_begin) + 1, 0);
+            Q.tile_ovf_ptr.assign(static_cast<size_t>(t_end - t_begin) + 1, 0);
+            Q.te_chunk_ptr.assign(static_cast<size_t>(t_end - t_begin) + 1, 0);
+            Q.hr_row0.assign(static_cast<size_t>(t_end - t_begin) * (kTile / kSlice) + 1, 0);
+            std::vector<int32_t> halo, tile_edges;
+            std::vector<std::array<int64_t, 4>> half_ents;      // {edge, entry index, thread of the node, its half row or -1}
+            std::vector<std::pair<int32_t, int32_t>> half_where;
+            std::vector<int32_t> halo_all;                  // a tile's halo ids, ALL of them ascending (the order-free kernel's own numbering)
+            for (int32_t t = t_begin; t < t_end; t++) {
+                const int32_t base = t * kTile;
+                const int32_t s0 = t * (kTile / kSlice), s1 = s0 + kTile / kSlice;
+                const int64_t e0 = int64_t(P.slice_row0[static_cast<size_t>(s0)]) * kSlice;
+                const int64_t e1 = int64_t(P.slice_row0[static_cast<size_t>(s1)]) * kSlice;
+                halo.clear();
                 for (int64_t e = e0; e < e1; e++) {
-                    const int32_t ge = entry_edge[static_cast<size_t>(e)];
-                    if (ge < 0) continue;
-                    const uint32_t p = static_cast<uint32_t>(std::lower_bound(tile_edges.begin(), tile_edges.end(), ge) - tile_edges.begin());
-                    P.gat16[static_cast<size_t>(e)] = static_cast<uint16_t>(p | ((P.nbr[static_cast<size_t>(e)] & kRoleB) ? kT16RoleB : 0u));
+                    const int32_t code = P.nbr[static_cast<size_t>(e)];
+                    if (code < 0) continue;
+                    const int32_t id = code & kIdMask;
+                    if (id < base || id >= base + kTile) halo.push_back(id);
                 }
-                P.te_chunk_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(chunk0 + n_chunks);
-            }
-            // half rows: every entry of this tile whose node OWNS the evaluation of its edge (half_eval_a, decided before
-            // the nodes were ordered) is placed in a (half row, lane) slot of the tile: in the node's own lane while its
-            // slice has rows left (the evaluator then has its record in registers), otherwise in any lane with a free
-            // slot ("foreign": that lane reads the owner's record from LDS as well).  A tile gets ceil(evaluations / 64)
-            // half rows, spread over its slices in proportion to what their nodes own, so slots are ~98 % used.
-            if (P.free_rows) {
-                // the order-free kernel stages EVERY halo node (no overflow table): up to kHaloStride from the shared table, beyond
-                // that — up to kFreeHaloStride — from a table of its own, slots counted in the ascending list of all of them
-                halo_all.assign(halo.begin(), halo.end());
-                std::sort(halo_all.begin(), halo_all.end());
-                if (n_halo > kFreeHaloStride) P.free_rows = false;
-                if (n_halo > staged) P.free_wide = true;
-                P.free_halo.resize(static_cast<size_t>(t + 1) * kFreeHaloStride, -1);
-                if (P.free_rows) std::copy(halo_all.begin(), halo_all.end(), P.free_halo.begin() + static_cast<size_t>(t) * kFreeHaloStride);
-                const int32_t n_here = static_cast<int32_t>(std::min<int64_t>(kTile, nel - base));
-                int32_t own[kTile] = {0};
-                half_ents.clear();
-                for (int32_t tid = 0; tid < n_here; tid++) {
-                    const int32_t n = base + tid;
-                    const int32_t s = n / kSlice, lane = n % kSlice;
-                    for (int32_t r = 0; r < P.rows_int[static_cast<size_t>(s)]; r++) {
-                        const int64_t e = (int64_t(P.slice_row0[static_cast<size_t>(s)]) + r) * kSlice + lane;
+                std::sort(halo.begin(), halo.end());
+                const int32_t n_refs = static_cast<int32_t>(halo.size());
+                halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
+                const int32_t n_halo = static_cast<int32_t>(halo.size());
+                const int32_t staged = std::min<int32_t>(n_halo, halo_cap);
+                if (n_halo > staged) {
+                    // more halo nodes than the LDS tile holds: stage the most referenced ones, leave the least
+                    // referenced to the overflow table (each use of those is a gather from HBM); both parts ascending
+                    std::vector<std::pair<int32_t, int32_t>> by_refs;                // (-references, id)
+                    by_refs.reserve(static_cast<size_t>(n_halo));
+                    {
+                        std::vector<int32_t> all;
+                        all.reserve(static_cast<size_t>(n_refs));
+                        for (int64_t e = e0; e < e1; e++) {
+                            const int32_t code = P.nbr[static_cast<size_t>(e)];
+                            if (code < 0) continue;
+                            const int32_t id = code & kIdMask;
+                            if (id < base || id >= base + kTile) all.push_back(id);
+                        }
+                        std::sort(all.begin(), all.end());
+                        for (size_t i = 0; i < all.size();) {
+                            size_t j = i;
+                            while (j < all.size() && all[j] == all[i]) j++;
+                            by_refs.emplace_back(-static_cast<int32_t>(j - i), all[i]);
+                            i = j;
+                        }
+                    }
+                    std::sort(by_refs.begin(), by_refs.end());
+                    for (int32_t k = 0; k < n_halo; k++) halo[static_cast<size_t>(k)] = by_refs[static_cast<size_t>(k)].second;
+                    std::sort(halo.begin(), halo.begin() + staged);
+                    std::sort(halo.begin() + staged, halo.end());
+                }
+                // position of a halo id in `halo` (staged part first, then the overflow part; each ascending)
+                auto halo_pos = [&](int32_t id) -> int32_t {
+                    auto it = std::lower_bound(halo.begin(), halo.begin() + staged, id);
+                    if (it != halo.begin() + staged && *it == id) return static_cast<int32_t>(it - halo.begin());
+                    return static_cast<int32_t>(std::lower_bound(halo.begin() + staged, halo.end(), id) - halo.begin());
+                };
+                if (n_halo - staged > ovf_cap) throw std::runtime_error("tile halo exceeds what 15-bit slots can address");
+                Q.halo_total += n_halo;
+                Q.halo_max = std::max<int32_t>(Q.halo_max, n_halo);
+                for (int64_t e = e0; e < e1; e++) {
+                    const int32_t code = P.nbr[static_cast<size_t>(e)];
+                    uint32_t c16;
+                    if (code == kCodeWall) c16 = kT16Wall;
+                    else if (code == kCodeFar) c16 = kT16Far;
+                    else if (code < 0) c16 = kT16Pad;
+                    else {
+                        const int32_t id = code & kIdMask;
+                        uint32_t slot;
+                        if (id >= base && id < base + kTile) slot = static_cast<uint32_t>(id - base);
+                        else {
+                            // the first `staged` halo ids live in LDS, the rest in the overflow table
+                            const int32_t pos = halo_pos(id);
+                            slot = static_cast<uint32_t>(kTile + pos);        // pos >= staged  =>  slot >= kTileCap
+                            if (pos >= staged) Q.halo_overflow_refs++;
+                        }
+                        c16 = slot | ((code & kRoleB) ? kT16RoleB : 0u);
+                    }
+                    P.nbr16[static_cast<size_t>(e)] = static_cast<uint16_t>(c16);
+                }
+                // edge-once list: the tile's internal edges, once each, ascending original index.  A node's
+                // incident edges keep their relative order in it, so summing a node's entries by position
+                // is the reference's accumulation order.
+                tile_edges.clear();
+                for (int64_t e = e0; e < e1; e++)
+                    if (entry_edge[static_cast<size_t>(e)] >= 0) tile_edges.push_back(entry_edge[static_cast<size_t>(e)]);
+                std::sort(tile_edges.begin(), tile_edges.end());
+                tile_edges.erase(std::unique(tile_edges.begin(), tile_edges.end()), tile_edges.end());
+                const int32_t n_te = static_cast<int32_t>(tile_edges.size());
+                P.te_count[static_cast<size_t>(t)] = n_te;
+                Q.te_max = std::max(Q.te_max, n_te);
+                Q.te_total += n_te;
+                if (n_te > kMaxEdgeChunks * kEdgeChunk) Q.edge_once = false;
+                if (Q.edge_once) {
+                    auto slot_of = [&](int32_t id) -> uint16_t {
+                        if (id >= base && id < base + kTile) return static_cast<uint16_t>(id - base);
+                        return static_cast<uint16_t>(kTile + halo_pos(id));   // >= kTileCap: overflow table, as in nbr16
+                    };
+                    const size_t chunk0 = static_cast<size_t>(Q.te_chunk_ptr[static_cast<size_t>(t - t_begin)]);
+                    const size_t n_chunks = (static_cast<size_t>(n_te) + kEdgeChunk - 1) / kEdgeChunk;
+                    Q.te_slots.resize((chunk0 + n_chunks) * 2 * kEdgeChunk, static_cast<uint16_t>(kT16Pad));
+                    Q.te_w.resize((chunk0 + n_chunks) * 4 * kEdgeChunk, 0.0);
+                    for (int32_t p = 0; p < n_te; p++) {
+                        const mgcfd_edge &E = edges[static_cast<size_t>(L.internal_start + tile_edges[static_cast<size_t>(p)])];
+                        const size_t c = chunk0 + static_cast<size_t>(p / kEdgeChunk), ln = static_cast<size_t>(p % kEdgeChunk);
+                        Q.te_slots[(c * 2 + 0) * kEdgeChunk + ln] = slot_of(P.new_of_old[static_cast<size_t>(E.a)]);
+                        Q.te_slots[(c * 2 + 1) * kEdgeChunk + ln] = slot_of(P.new_of_old[static_cast<size_t>(E.b)]);
+                        const double ewt = std::sqrt(E.x * E.x + E.y * E.y + E.z * E.z);
+                        Q.te_w[(c * 4 + 0) * kEdgeChunk + ln] = -0.5 * E.x;
+                        Q.te_w[(c * 4 + 1) * kEdgeChunk + ln] = -0.5 * E.y;
+                        Q.te_w[(c * 4 + 2) * kEdgeChunk + ln] = -0.5 * E.z;
+                        Q.te_w[(c * 4 + 3) * kEdgeChunk + ln] = -ewt * kSmoothing * 0.5;
+                    }
+                    for (int64_t e = e0; e < e1; e++) {
                         const int32_t ge = entry_edge[static_cast<size_t>(e)];
                         if (ge < 0) continue;
-                        const int8_t who = half_eval_a[static_cast<size_t>(ge)];        // -1: both end points (each in its tile), 1: a, 0: b
-                        const bool is_a = (P.nbr[static_cast<size_t>(e)] & kRoleB) == 0;
-                        const bool evaluates = who < 0 || (who == 1) == is_a;
-                        if (evaluates) own[tid]++;
-                        half_ents.push_back({ge, e, tid, evaluates ? 1 : 0});
+                        const uint32_t p = static_cast<uint32_t>(std::lower_bound(tile_edges.begin(), tile_edges.end(), ge) - tile_edges.begin());
+                        P.gat16[static_cast<size_t>(e)] = static_cast<uint16_t>(p | ((P.nbr[static_cast<size_t>(e)] & kRoleB) ? kT16RoleB : 0u));
                     }
+                    Q.te_chunk_ptr[static_cast<size_t>(t - t_begin) + 1] = static_cast<int32_t>(chunk0 + n_chunks);
                 }
-                int32_t n_eval = 0, own_slice[kTile / kSlice] = {0}, lanes[kTile / kSlice] = {0};
-                for (int32_t tid = 0; tid < n_here; tid++) { n_eval += own[tid]; own_slice[tid / kSlice] += own[tid]; lanes[tid / kSlice]++; }
-                // rows per slice: proportional to what the slice's nodes own, then one more wherever the capacity is short
-                int32_t rows_h[kTile / kSlice] = {0};
-                int32_t cap_total = 0;
-                for (int32_t sl = 0; sl < kTile / kSlice; sl++) {
-                    // floor of the slice's mean — never more than a lane keeps in registers (k_flux_half walks kHalfMaxRows half
-                    // rows at most: what a slice cannot hold goes to the other slices' lanes, or the level runs the node gather)
-                    rows_h[sl] = lanes[sl] ? std::min<int32_t>(kFreeMaxRows, own_slice[sl] / lanes[sl]) : 0;
-                    cap_total += rows_h[sl] * lanes[sl];
-                }
-                while (cap_total < n_eval) {
-                    int32_t best = -1; double need = -1.0;
+                // half rows: every entry of this tile whose node OWNS the evaluation of its edge (half_eval_a, decided before
+                // the nodes were ordered) is placed in a (half row, lane) slot of the tile: in the node's own lane while its
+                // slice has rows left (the evaluator then has its record in registers), otherwise in any lane with a free
+                // slot ("foreign": that lane reads the owner's record from LDS as well).  A tile gets ceil(evaluations / 64)
+                // half rows, spread over its slices in proportion to what their nodes own, so slots are ~98 % used.
+                if (Q.free_rows) {
+                    // the order-free kernel stages EVERY halo node (no overflow table): up to kHaloStride from the shared table, beyond
+                    // that — up to kFreeHaloStride — from a table of its own, slots counted in the ascending list of all of them
+                    halo_all.assign(halo.begin(), halo.end());
+                    std::sort(halo_all.begin(), halo_all.end());
+                    if (n_halo > kFreeHaloStride) Q.free_rows = false;
+                    if (n_halo > staged) Q.free_wide = true;
+                    if (Q.free_rows) std::copy(halo_all.begin(), halo_all.end(), P.free_halo.begin() + static_cast<size_t>(t) * kFreeHaloStride);
+                    const int32_t n_here = static_cast<int32_t>(std::min<int64_t>(kTile, nel - base));
+                    int32_t own[kTile] = {0};
+                    half_ents.clear();
+                    for (int32_t tid = 0; tid < n_here; tid++) {
+                        const int32_t n = base + tid;
+                        const int32_t s = n / kSlice, lane = n % kSlice;
+                        for (int32_t r = 0; r < P.rows_int[static_cast<size_t>(s)]; r++) {
+                            const int64_t e = (int64_t(P.slice_row0[static_cast<size_t>(s)]) + r) * kSlice + lane;
+                            const int32_t ge = entry_edge[static_cast<size_t>(e)];
+                            if (ge < 0) continue;
+                            const int8_t who = half_eval_a[static_cast<size_t>(ge)];        // -1: both end points (each in its tile), 1: a, 0: b
+                            const bool is_a = (P.nbr[static_cast<size_t>(e)] & kRoleB) == 0;
+                            const bool evaluates = who < 0 || (who == 1) == is_a;
+                            if (evaluates) own[tid]++;
+                            half_ents.push_back({ge, e, tid, evaluates ? 1 : 0});
+                        }
+                    }
+                    int32_t n_eval = 0, own_slice[kTile / kSlice] = {0}, lanes[kTile / kSlice] = {0};
+                    for (int32_t tid = 0; tid < n_here; tid++) { n_eval += own[tid]; own_slice[tid / kSlice] += own[tid]; lanes[tid / kSlice]++; }
+                    // rows per slice: proportional to what the slice's nodes own, then one more wherever the capacity is short
+                    int32_t rows_h[kTile / kSlice] = {0};
+                    int32_t cap_total = 0;
                     for (int32_t sl = 0; sl < kTile / kSlice; sl++) {
-                        if (!lanes[sl] || rows_h[sl] >= kFreeMaxRows) continue;
-                        const double d = double(own_slice[sl]) / lanes[sl] - rows_h[sl];      // how far the slice's mean is above its rows
-                        if (d > need) { need = d; best = sl; }
+                        // floor of the slice's mean — never more than a lane keeps in registers (k_flux_half walks kHalfMaxRows half
+                        // rows at most: what a slice cannot hold goes to the other slices' lanes, or the level runs the node gather)
+                        rows_h[sl] = lanes[sl] ? std::min<int32_t>(kFreeMaxRows, own_slice[sl] / lanes[sl]) : 0;
+                        cap_total += rows_h[sl] * lanes[sl];
                     }
-                    if (best < 0) { P.free_rows = false; break; }
-                    rows_h[best]++; cap_total += lanes[best];
+                    while (cap_total < n_eval) {
+                        int32_t best = -1; double need = -1.0;
+                        for (int32_t sl = 0; sl < kTile / kSlice; sl++) {
+                            if (!lanes[sl] || rows_h[sl] >= kFreeMaxRows) continue;
+                            const double d = double(own_slice[sl]) / lanes[sl] - rows_h[sl];      // how far the slice's mean is above its rows
+                            if (d > need) { need = d; best = sl; }
+                        }
+                        if (best < 0) { Q.free_rows = false; break; }
+                        rows_h[best]++; cap_total += lanes[best];
+                    }
+                    for (int32_t sl = 0; sl < kTile / kSlice; sl++)
+                        Q.hr_row0[static_cast<size_t>(s0 - s_begin + sl) + 1] = Q.hr_row0[static_cast<size_t>(s0 - s_begin + sl)] + rows_h[sl];
+                    for (int32_t sl = 0; sl < kTile / kSlice; sl++) Q.hr_max_rows = std::max(Q.hr_max_rows, rows_h[sl]);
+                    Q.hr_max_tile_rows = std::max(Q.hr_max_tile_rows, Q.hr_row0[static_cast<size_t>(s1 - s_begin)] - Q.hr_row0[static_cast<size_t>(s0 - s_begin)]);
+                    if (Q.free_rows) {
+                        const size_t rows_end = static_cast<size_t>(Q.hr_row0[static_cast<size_t>(s1 - s_begin)]);
+                        Q.hr_code.resize(rows_end * kSlice, kHalfPad);
+                        Q.hr_w.resize(rows_end * 3 * kSlice, 0.0);
+                        int32_t used[kTile] = {0};
+                        half_where.clear();                                   // (edge, position of its flux terms) of this tile's evaluations
+                        auto place = [&](const std::array<int64_t, 4> &en, int32_t host) {
+                            const int32_t owner = static_cast<int32_t>(en[2]);
+                            const int32_t sl = host / kSlice, lane = host % kSlice, j = used[host]++;
+                            const size_t hrow = static_cast<size_t>(Q.hr_row0[static_cast<size_t>(s0 - s_begin + sl)]) + static_cast<size_t>(j);
+                            const int64_t e = en[1];
+                            const bool only = half_eval_a[static_cast<size_t>(en[0])] >= 0;     // (an edge inside the tile: nobody else evaluates it)
+                            // (the other end's LDS slot: own nodes as in nbr16; a halo node by its position among ALL the tile's halo ids —
+                            //  the same slot as nbr16's wherever the tile has no overflow entries)
+                            const int32_t other = P.nbr[static_cast<size_t>(e)] & kIdMask;
+                            const uint32_t oslot = (other >= base && other < base + kTile) ? uint32_t(other - base)
+                                                 : uint32_t(kTile + (std::lower_bound(halo_all.begin(), halo_all.end(), other) - halo_all.begin()));
+                            const uint32_t c16 = oslot | ((P.nbr[static_cast<size_t>(e)] & kRoleB) ? kT16RoleB : 0u);
+                            Q.hr_code[hrow * kSlice + lane] = c16 | (uint32_t(owner) << 16) | (host != owner ? kHalfForeign : 0u)
+                                                              | (only ? kHalfMirror : 0u);
+                            const EdgeW &W = P.w[static_cast<size_t>(e)];
+                            Q.hr_w[(hrow * 3 + 0) * kSlice + lane] = W.x;
+                            Q.hr_w[(hrow * 3 + 1) * kSlice + lane] = W.y;
+                            Q.hr_w[(hrow * 3 + 2) * kSlice + lane] = W.z;
+                            const int32_t pos = static_cast<int32_t>(hrow - static_cast<size_t>(Q.hr_row0[static_cast<size_t>(s0 - s_begin)])) * kSlice + lane;
+                            P.hg16[static_cast<size_t>(e)] = static_cast<uint16_t>(pos);
+                            half_where.emplace_back(static_cast<int32_t>(en[0]), pos);
+                            Q.hr_entries++;
+                            if (host != owner) Q.hr_foreign++;
+                        };
+                        // own lane first (entries come node by node, in the node's row order) ...
+                        for (auto &en : half_ents) {
+                            if (en[3] != 1) continue;
+                            const int32_t tid = static_cast<int32_t>(en[2]);
+                            if (used[tid] < rows_h[tid / kSlice]) { place(en, tid); en[3] = 2; }
+                        }
+                        // ... the rest wherever a slot is free
+                        int32_t host = 0;
+                        for (auto &en : half_ents) {
+                            if (en[3] != 1) continue;
+                            while (host < n_here && used[host] >= rows_h[host / kSlice]) host++;
+                            if (host >= n_here) throw std::logic_error("half rows: no free slot left in the tile");
+                            place(en, host);
+                            en[3] = 2;
+                        }
+                        std::sort(half_where.begin(), half_where.end());
+                        for (const auto &en : half_ents) {
+                            if (en[3] != 0) continue;                        // the other end point owns the evaluation: its position, negated
+                            auto it = std::lower_bound(half_where.begin(), half_where.end(), std::make_pair(static_cast<int32_t>(en[0]), int32_t(-1)));
+                            if (it == half_where.end() || it->first != static_cast<int32_t>(en[0])) throw std::logic_error("half rows: an edge without an evaluator in its tile");
+                            P.hg16[static_cast<size_t>(en[1])] = static_cast<uint16_t>(uint32_t(it->second) | kT16RoleB);
+                        }
+                    }
                 }
-                for (int32_t sl = 0; sl < kTile / kSlice; sl++)
-                    P.hr_row0[static_cast<size_t>(s0 + sl) + 1] = P.hr_row0[static_cast<size_t>(s0 + sl)] + rows_h[sl];
-                for (int32_t sl = 0; sl < kTile / kSlice; sl++) P.hr_max_rows = std::max(P.hr_max_rows, rows_h[sl]);
-                P.hr_max_tile_rows = std::max(P.hr_max_tile_rows, P.hr_row0[static_cast<size_t>(s1)] - P.hr_row0[static_cast<size_t>(s0)]);
-                if (P.free_rows) {
-                    const size_t rows_end = static_cast<size_t>(P.hr_row0[static_cast<size_t>(s1)]);
-                    P.hr_code.resize(rows_end * kSlice, kHalfPad);
-                    P.hr_w.resize(rows_end * 3 * kSlice, 0.0);
-                    int32_t used[kTile] = {0};
-                    half_where.clear();                                   // (edge, position of its flux terms) of this tile's evaluations
-                    auto place = [&](const std::array<int64_t, 4> &en, int32_t host) {
-                        const int32_t owner = static_cast<int32_t>(en[2]);
-                        const int32_t sl = host / kSlice, lane = host % kSlice, j = used[host]++;
-                        const size_t hrow = static_cast<size_t>(P.hr_row0[static_cast<size_t>(s0 + sl)]) + static_cast<size_t>(j);
-                        const int64_t e = en[1];
-                        const bool only = half_eval_a[static_cast<size_t>(en[0])] >= 0;     // (an edge inside the tile: nobody else evaluates it)
-                        // (the other end's LDS slot: own nodes as in nbr16; a halo node by its position among ALL the tile's halo ids —
-                        //  the same slot as nbr16's wherever the tile has no overflow entries)
-                        const int32_t other = P.nbr[static_cast<size_t>(e)] & kIdMask;
-                        const uint32_t oslot = (other >= base && other < base + kTile) ? uint32_t(other - base)
-                                             : uint32_t(kTile + (std::lower_bound(halo_all.begin(), halo_all.end(), other) - halo_all.begin()));
-                        const uint32_t c16 = oslot | ((P.nbr[static_cast<size_t>(e)] & kRoleB) ? kT16RoleB : 0u);
-                        P.hr_code[hrow * kSlice + lane] = c16 | (uint32_t(owner) << 16) | (host != owner ? kHalfForeign : 0u)
-                                                          | (only ? kHalfMirror : 0u);
-                        const EdgeW &W = P.w[static_cast<size_t>(e)];
-                        P.hr_w[(hrow * 3 + 0) * kSlice + lane] = W.x;
-                        P.hr_w[(hrow * 3 + 1) * kSlice + lane] = W.y;
-                        P.hr_w[(hrow * 3 + 2) * kSlice + lane] = W.z;
-                        const int32_t pos = static_cast<int32_t>(hrow - static_cast<size_t>(P.hr_row0[static_cast<size_t>(s0)])) * kSlice + lane;
-                        P.hg16[static_cast<size_t>(e)] = static_cast<uint16_t>(pos);
-                        half_where.emplace_back(static_cast<int32_t>(en[0]), pos);
-                        P.hr_entries++;
-                        if (host != owner) P.hr_foreign++;
-                    };
-                    // own lane first (entries come node by node, in the node's row order) ...
-                    for (auto &en : half_ents) {
-                        if (en[3] != 1) continue;
-                        const int32_t tid = static_cast<int32_t>(en[2]);
-                        if (used[tid] < rows_h[tid / kSlice]) { place(en, tid); en[3] = 2; }
-                    }
-                    // ... the rest wherever a slot is free
-                    int32_t host = 0;
-                    for (auto &en : half_ents) {
-                        if (en[3] != 1) continue;
-                        while (host < n_here && used[host] >= rows_h[host / kSlice]) host++;
-                        if (host >= n_here) throw std::logic_error("half rows: no free slot left in the tile");
-                        place(en, host);
-                        en[3] = 2;
-                    }
-                    std::sort(half_where.begin(), half_where.end());
-                    for (const auto &en : half_ents) {
-                        if (en[3] != 0) continue;                        // the other end point owns the evaluation: its position, negated
-                        auto it = std::lower_bound(half_where.begin(), half_where.end(), std::make_pair(static_cast<int32_t>(en[0]), int32_t(-1)));
-                        if (it == half_where.end() || it->first != static_cast<int32_t>(en[0])) throw std::logic_error("half rows: an edge without an evaluator in its tile");
-                        P.hg16[static_cast<size_t>(en[1])] = static_cast<uint16_t>(uint32_t(it->second) | kT16RoleB);
-                    }
-                }
+                Q.tile_halo.insert(Q.tile_halo.end(), halo.begin(), halo.begin() + staged);
+                Q.tile_halo_ptr[static_cast<size_t>(t - t_begin) + 1] = static_cast<int32_t>(Q.tile_halo.size());
+                Q.tile_ovf.insert(Q.tile_ovf.end(), halo.begin() + staged, halo.end());
+                Q.tile_ovf_ptr[static_cast<size_t>(t - t_begin) + 1] = static_cast<int32_t>(Q.tile_ovf.size());
             }
-            P.tile_halo.insert(P.tile_halo.end(), halo.begin(), halo.begin() + staged);
-            P.tile_halo_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(P.tile_halo.size());
-            P.tile_ovf.insert(P.tile_ovf.end(), halo.begin() + staged, halo.end());
-            P.tile_ovf_ptr[static_cast<size_t>(t) + 1] = static_cast<int32_t>(P.tile_ovf.size());
+            } catch (...) { Q.error = std::current_exception(); }
+        };
+        int n_threads = opt.threads > 0 ? opt.threads : int(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())));
+        n_threads = std::max(1, std::min<int>(n_threads, P.n_tiles / 64));          // (a range of fewer than 64 tiles is not worth a thread)
+        if (const char *o = std::getenv("MGCFD_PLAN_THREADS")) n_threads = std::max(1, std::min<int>(std::atoi(o), P.n_tiles));   // (tests: any split)
+        std::vector<Part> parts(static_cast<size_t>(n_threads));
+        {
+            std::vector<std::thread> workers;
+            auto range_begin = [&](int k) { return static_cast<int32_t>(int64_t(P.n_tiles) * k / n_threads); };
+            for (int k = 1; k < n_threads; k++) workers.emplace_back(work, range_begin(k), range_begin(k + 1), std::ref(parts[static_cast<size_t>(k)]));
+            work(range_begin(0), range_begin(1), parts[0]);
+            for (std::thread &w : workers) w.join();
+        }
+        for (const Part &Q : parts) if (Q.error) std::rethrow_exception(Q.error);     // (the lowest tile range's error first)
+        // join the parts in tile order
+        int64_t halo_total = 0, te_total = 0;
+        {
+            int32_t t0 = 0;
+            for (int k = 0; k < n_threads; k++) {
+                const Part &Q = parts[static_cast<size_t>(k)];
+                const int32_t nt = static_cast<int32_t>(Q.tile_halo_ptr.size()) - 1;
+                const int32_t halo0 = static_cast<int32_t>(P.tile_halo.size()), ovf0 = static_cast<int32_t>(P.tile_ovf.size());
+                const int32_t chunk0 = P.te_chunk_ptr[static_cast<size_t>(t0)], row0 = P.hr_row0[static_cast<size_t>(t0) * (kTile / kSlice)];
+                for (int32_t t = 0; t < nt; t++) {
+                    P.tile_halo_ptr[static_cast<size_t>(t0 + t) + 1] = halo0 + Q.tile_halo_ptr[static_cast<size_t>(t) + 1];
+                    P.tile_ovf_ptr[static_cast<size_t>(t0 + t) + 1] = ovf0 + Q.tile_ovf_ptr[static_cast<size_t>(t) + 1];
+                    P.te_chunk_ptr[static_cast<size_t>(t0 + t) + 1] = chunk0 + Q.te_chunk_ptr[static_cast<size_t>(t) + 1];
+                }
+                for (size_t q = 1; q < Q.hr_row0.size(); q++) P.hr_row0[static_cast<size_t>(t0) * (kTile / kSlice) + q] = row0 + Q.hr_row0[q];
+                P.tile_halo.insert(P.tile_halo.end(), Q.tile_halo.begin(), Q.tile_halo.end());
+                P.tile_ovf.insert(P.tile_ovf.end(), Q.tile_ovf.begin(), Q.tile_ovf.end());
+                // (a part's lists end where its last tile's chunks / half rows end: resize() inside the loop keeps them exact)
+                P.te_slots.insert(P.te_slots.end(), Q.te_slots.begin(), Q.te_slots.end());
+                P.te_w.insert(P.te_w.end(), Q.te_w.begin(), Q.te_w.end());
+                P.hr_code.insert(P.hr_code.end(), Q.hr_code.begin(), Q.hr_code.end());
+                P.hr_w.insert(P.hr_w.end(), Q.hr_w.begin(), Q.hr_w.end());
+                P.edge_once = P.edge_once && Q.edge_once;
+                if (P.free_rows) {
+                    // (one thread stops looking at half rows at the first tile that cannot have them; a part stopped at ITS first
+                    //  such tile, so the parts up to and including the first failing one are what one thread would have seen)
+                    P.free_wide = P.free_wide || Q.free_wide;
+                    P.hr_max_rows = std::max(P.hr_max_rows, Q.hr_max_rows);
+                    P.hr_max_tile_rows = std::max(P.hr_max_tile_rows, Q.hr_max_tile_rows);
+                    P.hr_entries += Q.hr_entries;
+                    P.hr_foreign += Q.hr_foreign;
+                    P.free_rows = Q.free_rows;
+                }
+                P.halo_max = std::max(P.halo_max, Q.halo_max);
+                P.te_max = std::max(P.te_max, Q.te_max);
+                P.halo_overflow_refs += Q.halo_overflow_refs;
+                halo_total += Q.halo_total;
+                te_total += Q.te_total;
+                t0 += nt;
+            }
         }
         P.halo_mean = P.n_tiles ? double(halo_total) / double(P.n_tiles) : 0.0;
         P.halo_total = halo_total;
@@ -980,6 +1053,27 @@ void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge
 // k_flux_free, k_flux_edge_once, k_restrict, k_prolong_tile).  Returns "" when everything is in range, else one line
 // per kind of violation (the first few of each).  Host only: tests/test_host_plan_audit.py, tools/plan_stats.cpp.
 // ------------------------------------------------------------------------------------------
+// A digest of every array the per-tile part of the plan produces (FNV-1a over their bytes): the plan must not depend on how many
+// host threads built it (tests/test_host_plan_audit.py; mgcfd_plan_audit appends it to its report when MGCFD_PLAN_DIGEST is set).
+uint64_t plan_digest(const LevelPlan &P)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto eat = [&](const void *p, size_t n) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    auto vec = [&](const auto &v) { const uint64_t n = v.size(); eat(&n, sizeof(n)); if (n) eat(v.data(), n * sizeof(v[0])); };
+    vec(P.old_of_new); vec(P.slice_row0); vec(P.rows_int); vec(P.rows_bnd); vec(P.nbr); vec(P.nbr16);
+    vec(P.tile_halo_ptr); vec(P.tile_halo); vec(P.tile_ovf_ptr); vec(P.tile_ovf);
+    vec(P.te_chunk_ptr); vec(P.te_count); vec(P.te_slots); vec(P.te_w); vec(P.gat16);
+    vec(P.free_halo); vec(P.hr_row0); vec(P.hr_code); vec(P.hr_w); vec(P.hg16);
+    vec(P.rows_main); vec(P.tail_tile_ptr); vec(P.tail_rec); vec(P.tail_begin); vec(P.tail_count);
+    const int64_t scalars[] = {P.halo_max, P.te_max, P.hr_max_rows, P.hr_max_tile_rows, P.halo_overflow_refs, P.hr_entries, P.hr_foreign, P.halo_total,
+                               int64_t(P.edge_once), int64_t(P.free_rows), int64_t(P.free_wide), int64_t(P.half), int64_t(P.has_tail)};
+    eat(scalars, sizeof(scalars));
+    return h;
+}
+
 std::string audit_level_plan(const mgcfd_level_desc &L, const LevelPlan &P, int64_t nel_coarse)
 {
     std::string rep;

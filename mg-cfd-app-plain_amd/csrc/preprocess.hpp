@@ -172,6 +172,7 @@ struct PlanOptions {
     bool degree_sort = true;           // inside each tile, sort nodes by degree (less ELL padding per slice)
     int64_t n_owned = -1;              // -1: every node is owned
     bool long_rows = true;             // cut rows at a per-tile limit and evaluate the rest workgroup-wide (LevelPlan::tail_*)
+    int threads = 0;                   // host threads for the per-tile part of the plan (0: up to 8, MGCFD_PLAN_THREADS overrides); the plan does not depend on it
 };
 
 // `edges` are the level's final edge weights (after adjust/dampen).  coarse_new_of_old is
@@ -179,6 +180,7 @@ struct PlanOptions {
 // on the last level.
 void build_level_plan(const mgcfd_level_desc &lvl, const std::vector<mgcfd_edge> &edges,
                       const PlanOptions &opt, LevelPlan &plan);
+uint64_t plan_digest(const LevelPlan &plan);
 // child_order_key (may be null): per fine node, the key by which a coarse node's children are summed (ascending);
 // null = the node's own index, the reference's order.  A partitioned level passes global ids, so the mean over the
 // children keeps the whole mesh's summation order whatever the local numbering.  n_owned_fine < nel: fine nodes with

@@ -321,6 +321,52 @@ struct mgcfd_solver {
         lv.iters[MGCFD_LOOP_COMPUTE_STEP] += lv.info.nel;
         return apply_pending;
     }
+    // The parts of a level's plan that only a non-default option reaches are uploaded when an option first asks for them
+    // (at creation: nothing but the 32-bit neighbour codes of levels whose indirect_rw probe runs the L1-gather form).  Called
+    // at the end of creation and from mgcfd_set_option — never from a launch path, so never inside a stream capture.
+    void upload_optional_plans(DeviceLevel &lv)
+    {
+        LevelPlan &P = lv.plan;
+        const int v = opt_variant;
+        auto take = [](auto &vec) { auto *p = dev_upload(vec); vec.clear(); vec.shrink_to_fit(); return p; };
+        // order-free / half rows: MGCFD_OPT_EXACT = 0 (the automatic variant takes the order-free kernel), or bits 5 / 6
+        if (lv.dp.free_rows && !lv.dp.hr_code && (!opt_exact || (v >= 0 && (v & (32 | 64))))) {
+            lv.dp.hr_row0 = dev_upload(P.hr_row0);
+            lv.dp.hr_code = take(P.hr_code);
+            lv.dp.hr_w = take(P.hr_w);
+            if (lv.dp.free_wide) lv.dp.free_halo = take(P.free_halo);
+        }
+        if (lv.dp.free_rows && !lv.dp.hg16 && v >= 0 && (v & 32)) lv.dp.hg16 = take(P.hg16);
+        // edge-once tiles (bit 1) and indexed weights (bit 4)
+        if (lv.dp.edge_once && !lv.dp.gat16 && v >= 0 && (v & (2 | 16))) {
+            lv.dp.te_chunk_ptr = dev_upload(P.te_chunk_ptr);
+            lv.dp.te_count = dev_upload(P.te_count);
+            lv.dp.gat16 = take(P.gat16);
+            {   // the a-side weights as 24-byte records, one per listed edge (k_flux_tile WMODE 2: indexed weights)
+                const size_t n_chunks = P.te_w.size() / (4 * kEdgeChunk);
+                std::vector<double> w3(n_chunks * kEdgeChunk * 3);
+                for (size_t c = 0; c < n_chunks; c++)
+                    for (size_t ln = 0; ln < size_t(kEdgeChunk); ln++)
+                        for (size_t k = 0; k < 3; k++) w3[(c * kEdgeChunk + ln) * 3 + k] = P.te_w[(c * 4 + k) * kEdgeChunk + ln];
+                lv.dp.te_w3 = dev_upload(w3);
+            }
+            lv.dp.te_slots = take(P.te_slots);
+            lv.dp.te_w = take(P.te_w);
+        }
+        // the two-phase design point (bit 2)
+        if (!lv.dp.fe_ab && v >= 0 && (v & 4)) {
+            lv.dp.fe_ab = take(P.fe_ab);
+            lv.dp.fe_w = take(P.fe_w);
+            lv.dp.row_edge = take(P.row_edge);
+        }
+        // 32-bit neighbour codes: the L1-gather form of the indirect_rw probe (bit 3, or a level the tile form cannot run on)
+        if (!lv.dp.nbr && ((v >= 0 && (v & 8)) || !lv.dp.lds_complete || lv.dp.has_tail)) lv.dp.nbr = take(P.nbr);
+    }
+    void upload_optional_plans()
+    {
+        use_device();
+        for (DeviceLevel &lv : L) upload_optional_plans(lv);
+    }
     // MGCFD_OPT_FLUX_VARIANT = -1 (auto): the edge-length factor is recomputed from the weights (8 of 34 bytes per entry
     // less to stream, one sqrt more per entry).  The fused stages run equally fast either way while a level's rows fit the
     // Infinity Cache (bench level: 20.15 against 20.2 us) and 13-17 % faster without the stream beyond it (1.5-2.4 M
@@ -656,8 +702,12 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
                             order_keys ? order_keys[l] : nullptr, s->L[static_cast<size_t>(l)].n_owned);
         s->L[static_cast<size_t>(l)].has_transfer = true;
     });
-    // device upload
-    for (int l = 0; l < nlevels; l++) {
+    // device upload: a host thread per level again (repacking into the device layouts and the copies out of pageable
+    // memory are host work; every thread selects the device for itself, the state's initialisation goes to the one stream).
+    // What only a non-default option reaches — the order-free / half-row plan, the edge-once lists, the two-phase arrays, the
+    // 32-bit neighbour codes — stays on the host until an option asks for it (upload_optional_plans): 60 % of the bytes.
+    run_per_level(nlevels, [&](int l) {
+        s->use_device();
         const mgcfd_level_desc &d = levels[l];
         DeviceLevel &lv = s->L[static_cast<size_t>(l)];
         lv.info = d;
@@ -698,7 +748,6 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.dp.slice_row0 = dev_upload(P.slice_row0);
         lv.dp.rows_int = dev_upload(P.rows_int);
         lv.dp.rows_bnd = dev_upload(P.rows_bnd);
-        lv.dp.nbr = dev_upload(P.nbr);
         {
             // edge weights as [row][component][lane] so each component load of a wave is one
             // contiguous 512-byte run
@@ -731,13 +780,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.dp.pad_chunk = P.te_chunk_ptr.empty() ? 0 : P.te_chunk_ptr.back();
         lv.dp.n_edges = d.n_internal;
         lv.dp.n_edges_pad = (d.n_internal + 255) / 256 * 256;
-        lv.dp.fe_ab = dev_upload(P.fe_ab);
-        lv.dp.fe_w = dev_upload(P.fe_w);
         lv.plan.row_edge.resize(P.row_edge.size() + 2 * kSlice, -1);                     // two rows of padding
-        lv.dp.row_edge = dev_upload(P.row_edge);
-        lv.plan.fe_ab.clear(); lv.plan.fe_ab.shrink_to_fit();
-        lv.plan.fe_w.clear(); lv.plan.fe_w.shrink_to_fit();
-        lv.plan.row_edge.clear(); lv.plan.row_edge.shrink_to_fit();
         lv.dp.has_tail = P.has_tail ? 1 : 0;
         if (lv.dp.has_tail) {
             lv.dp.tail.rows_main = dev_upload(P.rows_main);
@@ -754,45 +797,30 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.dp.halo_max = P.halo_max;
         lv.dp.edge_once = (P.edge_once && !std::getenv("MGCFD_NO_EDGE_ONCE")) ? 1 : 0;
         if (lv.dp.edge_once) {
-            lv.dp.te_chunk_ptr = dev_upload(P.te_chunk_ptr);
-            lv.dp.te_count = dev_upload(P.te_count);
             lv.plan.te_slots.resize(P.te_slots.size() + 2 * kEdgeChunk, static_cast<uint16_t>(kT16Pad));   // one chunk of padding
             lv.plan.te_w.resize(P.te_w.size() + 4 * kEdgeChunk, 0.0);
-            lv.dp.te_slots = dev_upload(P.te_slots);
-            lv.dp.te_w = dev_upload(P.te_w);
-            {   // the same weights as 24-byte records, one per listed edge (k_flux_tile WMODE 2: indexed weights)
-                const size_t n_chunks = P.te_w.size() / (4 * kEdgeChunk);
-                std::vector<double> w3(n_chunks * kEdgeChunk * 3);
-                for (size_t c = 0; c < n_chunks; c++)
-                    for (size_t ln = 0; ln < size_t(kEdgeChunk); ln++)
-                        for (size_t k = 0; k < 3; k++) w3[(c * kEdgeChunk + ln) * 3 + k] = P.te_w[(c * 4 + k) * kEdgeChunk + ln];
-                lv.dp.te_w3 = dev_upload(w3);
-            }
             lv.plan.gat16.resize(P.gat16.size() + 2 * kSlice, static_cast<uint16_t>(kT16Pad));   // two rows of padding
-            lv.dp.gat16 = dev_upload(P.gat16);
         }
         lv.dp.half = (P.half && !std::getenv("MGCFD_NO_HALF_ROWS")) ? 1 : 0;
         lv.dp.free_rows = (P.free_rows && !std::getenv("MGCFD_NO_HALF_ROWS")) ? 1 : 0;
         lv.dp.hr_max_rows = P.hr_max_rows;
         lv.dp.free_wide = (lv.dp.free_rows && P.free_wide) ? 1 : 0;
-        if (lv.dp.free_wide) lv.dp.free_halo = dev_upload(P.free_halo);
-        lv.plan.free_halo.clear(); lv.plan.free_halo.shrink_to_fit();
+        if (!lv.dp.free_wide) { lv.plan.free_halo.clear(); lv.plan.free_halo.shrink_to_fit(); }
         if (lv.dp.free_rows) {
             lv.dp.hr_pad_row = P.hr_row0.back();
-            lv.dp.hr_row0 = dev_upload(P.hr_row0);
             lv.plan.hr_code.resize(P.hr_code.size() + 2 * kSlice, kHalfPad);      // two half rows of padding
             lv.plan.hr_w.resize(P.hr_w.size() + 2 * 3 * kSlice, 0.0);
             lv.plan.hg16.resize(P.hg16.size() + 2 * kSlice, static_cast<uint16_t>(kT16Pad));
-            lv.dp.hr_code = dev_upload(P.hr_code);
-            lv.dp.hr_w = dev_upload(P.hr_w);
-            lv.dp.hg16 = dev_upload(P.hg16);
+        } else {
+            lv.plan.hr_code.clear(); lv.plan.hr_code.shrink_to_fit();
+            lv.plan.hr_w.clear(); lv.plan.hr_w.shrink_to_fit();
+            lv.plan.hg16.clear(); lv.plan.hg16.shrink_to_fit();
         }
-        lv.plan.hr_code.clear(); lv.plan.hr_code.shrink_to_fit();
-        lv.plan.hr_w.clear(); lv.plan.hr_w.shrink_to_fit();
-        lv.plan.hg16.clear(); lv.plan.hg16.shrink_to_fit();
-        lv.plan.te_slots.clear(); lv.plan.te_slots.shrink_to_fit();
-        lv.plan.te_w.clear(); lv.plan.te_w.shrink_to_fit();
-        lv.plan.gat16.clear(); lv.plan.gat16.shrink_to_fit();
+        if (!lv.dp.edge_once) {
+            lv.plan.te_slots.clear(); lv.plan.te_slots.shrink_to_fit();
+            lv.plan.te_w.clear(); lv.plan.te_w.shrink_to_fit();
+            lv.plan.gat16.clear(); lv.plan.gat16.shrink_to_fit();
+        }
         lv.plan.nbr16.clear(); lv.plan.nbr16.shrink_to_fit();
         if (lv.has_transfer) {
             lv.dp.child_ptr = dev_upload(P.child_ptr);
@@ -832,8 +860,8 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
             // the per-entry host copies are not needed again
             lv.plan.pro.clear(); lv.plan.pro.shrink_to_fit();
         }
-        lv.plan.nbr.clear(); lv.plan.nbr.shrink_to_fit();
         lv.plan.w.clear(); lv.plan.w.shrink_to_fit();
+        s->upload_optional_plans(lv);
         // initial state: far field everywhere, fluxes/residuals/old/step factors zero
         HIP_CHECK(hipMemsetAsync(lv.old_variables, 0, sizeof(double) * 5 * stride, s->stream));
         HIP_CHECK(hipMemsetAsync(lv.fluxes, 0, sizeof(double) * 5 * stride, s->stream));
@@ -842,7 +870,8 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         HIP_CHECK(hipMemsetAsync(lv.sf_alt, 0, sizeof(double) * stride, s->stream));
         exact::launch_init_variables(s->stream, stride, s->ff, lv.q);
         exact::launch_init_variables(s->stream, stride, s->ff, lv.q_alt);     // valid numbers in the padded tail
-    }
+    });
+    s->use_device();
     HIP_CHECK(hipStreamSynchronize(s->stream));
     HIP_CHECK(hipGetLastError());
     return s;
@@ -948,6 +977,11 @@ int mgcfd_plan_audit(const mgcfd_level_desc *levels, int nlevels, int mesh_varia
         for (int l = 0; l < nlevels; l++) {
             const std::string r = audit_level_plan(levels[l], plans[static_cast<size_t>(l)], l + 1 < nlevels ? levels[l + 1].nel : -1);
             if (!r.empty()) rep += "level " + std::to_string(l) + ":\n" + r;
+            if (std::getenv("MGCFD_PLAN_DIGEST")) {          // (diagnostic: the report then always holds text)
+                char buf[64];
+                std::snprintf(buf, sizeof(buf), "digest level %d: %016llx\n", l, (unsigned long long)plan_digest(plans[static_cast<size_t>(l)]));
+                rep += buf;
+            }
         }
     });
     if (rc != MGCFD_OK) return rc;
@@ -990,7 +1024,7 @@ int mgcfd_set_option(mgcfd_solver *s, int option, int value)
     REQUIRE(s);
     return guarded([&] {
         switch (option) {
-            case MGCFD_OPT_EXACT: s->opt_exact = value != 0; break;
+            case MGCFD_OPT_EXACT: s->opt_exact = value != 0; s->upload_optional_plans(); break;
             case MGCFD_OPT_TIMING:
                 if (value < 0 || value > 4) throw std::invalid_argument("MGCFD_OPT_TIMING is 0 ... 4");
                 s->use_device(); s->fold_events(); s->opt_timing = value == 3 ? 2 : value; s->timing_stride = value == 3 ? 1 : (value == 4 ? 32 : 8);
@@ -998,7 +1032,7 @@ int mgcfd_set_option(mgcfd_solver *s, int option, int value)
                 break;
             case MGCFD_OPT_INDIRECT_RW: s->opt_indirect_rw = value != 0; break;
             case MGCFD_OPT_CHECK_INVALID: s->opt_check = value != 0; break;
-            case MGCFD_OPT_FLUX_VARIANT: s->opt_variant = value; break;
+            case MGCFD_OPT_FLUX_VARIANT: s->opt_variant = value; s->upload_optional_plans(); break;
             case MGCFD_OPT_FUSE_UPDATE: s->opt_fuse = value != 0; break;
             case MGCFD_OPT_GRAPH: s->opt_graph = value != 0; break;
             case MGCFD_OPT_RANK_SPLIT: s->opt_rank_split = value < 0 ? 0 : (value > 2 ? 2 : value); break;

@@ -63,3 +63,26 @@ def test_the_audit_sees_a_broken_plan():
     bad[0]["mg_map"] = m
     with pytest.raises(mgcfd.MgcfdError):
         mgcfd.plan_audit(bad, mg.mesh_variant)
+
+
+@pytest.mark.parametrize("name", ["lattice 24^3 (54 tiles)", "tetrahedra, two levels", "random graph, degree 10 (long rows)", "lattice 40^3 (250 tiles)", "mixed elements 36^3"])
+def test_the_plan_does_not_depend_on_the_number_of_host_threads(name, monkeypatch):
+    """Round 4 builds the per-tile part of a plan (halo lists, tile-local codes, edge-once lists, half rows) on several host
+    threads, each over a contiguous range of tiles, and joins the parts in tile order: every array and every counter must come
+    out the same as from one thread (a digest over all of them, mgcfd_plan_audit with MGCFD_PLAN_DIGEST)."""
+    more = {"lattice 40^3 (250 tiles)": lambda: meshgen.make_multigrid((40,), "m6wing", seed=1, jitter=0.2, area_noise=0.02, volume_noise=0.02, permute=True),
+            "mixed elements 36^3": lambda: meshgen.make_mixed_multigrid((36,), "m6wing", seed=2, jitter=0.2, area_noise=0.02, volume_noise=0.02, permute=True)}
+    mg = (CASES.get(name) or more[name])()
+    levels = _levels(mg)
+    monkeypatch.setenv("MGCFD_PLAN_DIGEST", "1")
+    digests = {}
+    for threads in ("1", "2", "3", "7"):
+        monkeypatch.setenv("MGCFD_PLAN_THREADS", threads)
+        try:
+            rep = mgcfd.plan_audit(levels, mg.mesh_variant)
+        except mgcfd.MgcfdError as e:               # (with the digest in it the report is never empty: the call says "not clean")
+            rep = str(e)
+        lines = [ln for ln in rep.splitlines() if ln.startswith("digest level") or "digest level" in ln]
+        assert len(lines) == len(levels) and not [ln for ln in rep.splitlines() if ln.strip() and "digest level" not in ln and "plan audit" not in ln and not ln.startswith("level ")], rep
+        digests[threads] = [ln.split("digest level")[1] for ln in lines]
+    assert digests["1"] == digests["2"] == digests["3"] == digests["7"], digests

@@ -1508,6 +1508,7 @@ __device__ __forceinline__ void lds_add(double *p, double v) { unsafeAtomicAdd(p
 
 // CAP: nodes a tile may stage.  kFreeCap4 (halos of at most 290 nodes) lets four workgroups share a CU, kTileCap three.
 constexpr int kFreeCap4 = 546;
+static_assert(kFreeCap4 - kTile == kFreeCap4Halo, "preprocess.hpp: kFreeCap4Halo");
 // LONG: some slice of the level holds more half rows than the prologue requests (the loop behind the unrolled pairs exists)
 // WIDE: some tile's halo exceeds the shared table's 303 ids: the halo comes from the kernel's own table, two ids per thread
 //       (tile_halo then points at it, stride kFreeHaloStride; CAP = kTile + kFreeHaloStride)
@@ -2602,7 +2603,9 @@ void launch_flux(hipStream_t st, const DevicePlan &p, const double *q, const Far
     }
 #ifdef MGCFD_ORDER_FREE
     // variant bit 6 (64), this namespace only: order-free accumulation over the half-row plan (k_flux_free)
-    if ((variant & 64) && p.free_rows && (classes & 1) && !(fused && fs.vin_flux) && !part) {
+    // (not for a launch that must leave the ghost slots alone — fs.nel_active, a partitioned level in direct mode: this kernel
+    //  writes every node of the level)
+    if ((variant & 64) && p.free_rows && (classes & 1) && !(fused && fs.vin_flux) && !part && !(fused && fs.nel_active > 0)) {
 #define MGCFD_FREE_LAUNCH_L(FUSE, ACC, CAP, LONG)                                                               \
     hipLaunchKernelGGL((k_flux_free<FUSE, ACC, CAP, LONG>), grid, block, 0, st, q, p.tile_halo, uint32_t(p.n_tiles), \
                        p.hr_pad_row, p.stride, p.nel, p.hr_row0, p.hr_code, p.hr_w, p.slice_row0,               \

@@ -121,6 +121,17 @@ std::vector<Part> partition_level(const mgcfd_level_desc &L, const std::vector<i
 std::vector<std::vector<Part>> partition_hierarchy(const std::vector<mgcfd_level_desc> &L, const std::vector<int> &part0, int n_parts)
 {
     const int n = static_cast<int>(L.size());
+    // (what the library's create path checks as well: a map as long as its level, every entry a node of the coarser level —
+    //  a shorter, longer or out-of-range map would index outside `owner` below; round 3's advisor finding)
+    if (n == 0 || static_cast<int64_t>(part0.size()) != L[0].nel) throw std::invalid_argument("partition_hierarchy: one part per node of level 0 expected");
+    for (int p : part0) if (p < 0 || p >= n_parts) throw std::invalid_argument("partition_hierarchy: a part index outside [0, n_parts)");
+    for (int l = 0; l + 1 < n; l++) {
+        const mgcfd_level_desc &D = L[static_cast<size_t>(l)];
+        if (!D.mg_map || D.mgc != D.nel) throw std::invalid_argument("partition_hierarchy: the multigrid map of level " + std::to_string(l) + " must have one entry per node");
+        const int64_t nc = L[static_cast<size_t>(l) + 1].nel;
+        for (int64_t i = 0; i < D.mgc; i++)
+            if (D.mg_map[i] < 0 || D.mg_map[i] >= nc) throw std::invalid_argument("partition_hierarchy: the multigrid map of level " + std::to_string(l) + " names a node outside the coarser level");
+    }
     std::vector<std::vector<int>> owner(static_cast<size_t>(n));
     owner[0] = part0;
     for (int l = 0; l + 1 < n; l++) {

@@ -43,6 +43,7 @@ constexpr uint32_t kHalfPad = 0x00007FFFu;   // (low 15 bits = kT16Pad)
 constexpr int kHalfMaxRows = 5;            // half rows (edges a node evaluates) a thread keeps the results of in registers
 constexpr int kFreeHaloStride = 2 * kTile; // halo ids a tile of the order-free kernel can stage from its OWN table (two per thread: 56-byte LDS images,
                                            // 768 of them + the sums = 53,248 B, three workgroups per CU) where some tile's halo exceeds kHaloStride
+constexpr int kFreeCap4Halo = 290;         // the largest halo with which four workgroups of the order-free kernel share a CU (kernels.hip: kFreeCap4 - kTile)
 constexpr int kFreeMaxRows = 32;           // ... and what a slice may hold at all: the order-free kernel walks the rows beyond five in a loop
 constexpr int kHalfTileRows = 21;          // half rows of a tile's four slices together (21 * 64 * 40 B = the whole LDS tile)
 constexpr int kHalfSlots = kHalfTileRows * kSlice;   // flux-term slots of a tile in LDS: 5 fields x 1344 x 8 B = 52.5 KiB (its own array in k_flux_half)

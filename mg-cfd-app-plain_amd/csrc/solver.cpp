@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -378,7 +379,11 @@ struct mgcfd_solver {
     int variant_for(const DeviceLevel &lv, bool fused = false) const
     {
         if (opt_variant >= 0) return opt_variant;
-        if (!opt_exact && lv.dp.free_rows && (!fused || lv.dp.free_wide || lv.dp.has_tail)) return 1 | 64;
+        // (round 4: the order-free stages are role-specialised where a level is on the kernel's fast path — halos within the
+        //  smaller LDS image, at most five half rows per lane — and lead there too: bench level 47.1 against 51.1 us per sweep,
+        //  the 4-level V-cycle 0.256 against 0.271 ms, profiles/r4_fast_mode.txt)
+        const bool free_fast_path = !lv.dp.free_wide && lv.dp.halo_max <= kFreeCap4Halo && lv.dp.hr_max_rows <= kHalfMaxRows;
+        if (!opt_exact && lv.dp.free_rows && (!fused || lv.dp.free_wide || lv.dp.has_tail || free_fast_path)) return 1 | 64;
         return 1;
     }
     // classes: bit0 internal, bit1 solid wall (-1), bit2 far field (-2)
@@ -644,6 +649,15 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
     HIP_CHECK(hipMemset(s->err, 0xFF, sizeof(unsigned long long)));
 
     s->L.resize(static_cast<size_t>(nlevels));
+    const bool timing = std::getenv("MGCFD_PLAN_TIMING") != nullptr;      // where the host time of a solver's creation goes (stderr)
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mgcfd create] %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    lap("device, stream");
     PlanOptions popt;
     if (const char *o = std::getenv("MGCFD_ORDERING")) popt.ordering = std::atoi(o);   // diagnostic override
     // host-side plans first (coarse permutations are needed by the fine level's transfer plan).  The levels' plans are
@@ -693,6 +707,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
                          double(rows_full) / double(lv.plan.rows_int.size()), double(rows_cut) / double(lv.plan.rows_int.size()));
         }
     });
+    lap("level plans (a thread per level)");
     // (a transfer plan writes its own fine level's plan and only READS the coarse level's permutation)
     run_per_level(nlevels - 1, [&](int l) {
         const mgcfd_level_desc &d = levels[l];
@@ -702,6 +717,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
                             order_keys ? order_keys[l] : nullptr, s->L[static_cast<size_t>(l)].n_owned);
         s->L[static_cast<size_t>(l)].has_transfer = true;
     });
+    lap("transfer plans");
     // device upload: a host thread per level again (repacking into the device layouts and the copies out of pageable
     // memory are host work; every thread selects the device for itself, the state's initialisation goes to the one stream).
     // What only a non-default option reaches — the order-free / half-row plan, the edge-once lists, the two-phase arrays, the
@@ -874,6 +890,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
     s->use_device();
     HIP_CHECK(hipStreamSynchronize(s->stream));
     HIP_CHECK(hipGetLastError());
+    lap("repack + upload (a thread per level)");
     return s;
 }
 
@@ -2449,7 +2466,10 @@ static void group_sweep_once(mgcfd_group *g, int level)
             if (direct) stage_boundary_direct(g, s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1);
             else stage_boundary(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1);
         }
-        if (!direct) group_deliver(g, level, j);
+        // (set 0 is also the set of the transfers' exchanges, outside the sweeps' rotation: a destination's copies of stage 0 wait
+        //  for its OWN pack of this stage, which lies behind its unpack of such an exchange — with the local time step nothing
+        //  else orders a peer's stage-0 message behind that unpack; round 3's advisor finding)
+        if (!direct) group_deliver(g, level, j, j == 0);
         for (mgcfd_solver *s : g->ranks) { s->use_device(); stage_interior(s, level, j, global_dt ? 3 : 0, s->level(level).hx->gmin, 1); }
     }
     // (direct mode: the last stage's pushes went into the buffer that is `variables` now; whoever reads ghosts next waits for bdone[2])

@@ -34,10 +34,11 @@ def _group_over(levels, mesh_variant, n_parts, direct=True):
     return H, solvers, g
 
 
-def _check_against_whole(levels, mesh_variant, n_parts, cycles, exact=True):
+def _check_against_whole(levels, mesh_variant, n_parts, cycles, exact=True, whole_variant=-1, rel=0.0):
     import mgcfd
     whole = mgcfd.Solver.from_arrays(levels, mesh_variant)
     whole.set_option("exact", int(exact))
+    whole.set_option("flux_variant", whole_variant)
     want_rms = whole.run_cycles(cycles)
     want = [(whole.get(l, "variables"), whole.get(l, "residuals")) for l in range(len(levels))]
     want_iters = [whole.loop_iters(l) for l in range(len(levels))]
@@ -50,6 +51,12 @@ def _check_against_whole(levels, mesh_variant, n_parts, cycles, exact=True):
         for l in range(len(levels)):
             P = h.levels[l]
             own = P.global_ids[:P.n_owned]
+            if rel > 0.0:
+                for k, nm in ((0, "variables"), (1, "residuals")):
+                    got, ref = s.get(l, nm)[:P.n_owned], want[l][k][own]
+                    scale = np.abs(want[l][0]).max()              # (residuals are differences of the variables: same scale)
+                    assert np.abs(got - ref).max() <= rel * scale, f"{n_parts} parts, rank {h.rank}, level {l}: owned {nm} differ by {np.abs(got - ref).max() / scale:.2e} relative"
+                continue
             _bits_equal(s.get(l, "variables")[:P.n_owned], want[l][0][own], f"{n_parts} parts, rank {h.rank}, level {l}: owned variables")
             _bits_equal(s.get(l, "residuals")[:P.n_owned], want[l][1][own], f"{n_parts} parts, rank {h.rank}, level {l}: owned residuals")
     assert np.allclose(rms, want_rms, rtol=1e-12, atol=0.0), (rms, want_rms)
@@ -98,12 +105,16 @@ def test_group_cycles_on_a_tetrahedral_hierarchy_and_with_the_local_time_step():
 
 
 def test_group_cycles_with_contraction_allowed_stay_within_tolerance():
-    """MGCFD_OPT_EXACT = 0 on every rank: the partitioned cycles are the same operations, so they still equal the whole
-    hierarchy's contracted run bit for bit."""
+    """MGCFD_OPT_EXACT = 0 on every rank.  The partitioned cycles run the contracted NODE GATHER (a launch over part of a level,
+    or one that must leave the ghost slots alone, never takes the order-free kernel): against the whole hierarchy swept by the same
+    kernel (variant 1) they are the same operations, bit for bit; against the whole hierarchy in its automatic variant — since
+    round 4 the order-free stages on lattice-like levels too, sums associated differently and not reproducible from run to run —
+    within the fast mode's bound (tests/test_gpu_parity.py REL_FAST)."""
     import mgcfd
     from mgcfd import meshgen
     mg = meshgen.make_multigrid((12, 6, 3), "m6wing", seed=9, jitter=0.2, area_noise=0.05, volume_noise=0.05)
-    _check_against_whole(mgcfd.generated_to_levels(mg), mg.mesh_variant, 3, cycles=2, exact=False)
+    _check_against_whole(mgcfd.generated_to_levels(mg), mg.mesh_variant, 3, cycles=2, exact=False, whole_variant=1)
+    _check_against_whole(mgcfd.generated_to_levels(mg), mg.mesh_variant, 3, cycles=2, exact=False, rel=1e-12)
 
 
 def test_group_cycles_at_full_size_in_three_and_eight_parts():

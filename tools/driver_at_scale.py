@@ -20,7 +20,7 @@ for extra in ([], ["--loop-timers"], ["--no-timers"]):
     lines = [l for l in r.stdout.splitlines() if "Total runtime" in l or "RMS" in l]
     print(" ".join(["euler3d_gpu_double -g 25"] + extra), "-> rc", r.returncode, f"process wall {wall:.2f} s;", lines[-1] if lines else r.stdout[-200:], "|", (lines[-2] if len(lines) > 1 else ""))
     for ln in r.stderr.splitlines():
-        if "input files read" in ln or "mgcfd plan" in ln: print("   ", ln.strip())
+        if "input files read" in ln or "mgcfd plan" in ln or "mgcfd create" in ln: print("   ", ln.strip())
     if r.returncode != 0:
         print(r.stdout[-500:], r.stderr[-500:])
     elif extra != ["--no-timers"]:

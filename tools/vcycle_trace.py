@@ -2,9 +2,13 @@
 """Per-launch view of one V-cycle from a rocprofv3 --kernel-trace of tools/vcycle_bench.py: mean duration by (kernel, grid size),
 i.e. per LEVEL, and the gaps between consecutive launches.   python tools/vcycle_trace.py <dir with *_kernel_trace.csv>"""
 import csv, glob, os, sys, collections
+if len(sys.argv) < 2 or not os.path.isdir(sys.argv[1]):
+    sys.exit("usage: python tools/vcycle_trace.py <directory holding a rocprofv3 --kernel-trace of tools/vcycle_bench.py (*_kernel_trace.csv)>")
 rows = []
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
     rows += list(csv.DictReader(open(f)))
+if not rows:
+    sys.exit(f"no *kernel_trace.csv under {sys.argv[1]}")
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
     n = n.replace("void ", "").replace("mgcfd::exact::", "").replace("mgcfd::fast::", "")

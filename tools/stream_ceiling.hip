@@ -41,6 +41,53 @@ __global__ void __launch_bounds__(256) k_stream(const double *__restrict__ in, d
     for (int k = 0; k < wr_per_thread; k++) dst[k * 256] = acc + k;
 }
 
+// The same stream with the reads as LDS-DMA (round 4: `global_load_lds_dwordx4`, 16 bytes per lane = 1 KiB per wave-instruction
+// straight into LDS, no destination registers): eight transfers in flight per wave into an 8 KiB ring of its own, the data never
+// read back — what the memory side of a tile costs when nothing passes through the register file.
+template <int LDS_BYTES>
+__global__ void __launch_bounds__(256) k_stream_dma(const double *__restrict__ in, double *__restrict__ out, int rd_per_thread,
+                                                    int wr_per_thread, long in_stride_wg, long out_stride_wg)
+{
+    __shared__ double lds[LDS_BYTES / 8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const char *src = reinterpret_cast<const char *>(in + long(blockIdx.x) * in_stride_wg) + wave * 1024 + lane * 16;
+    auto *ring = (__attribute__((address_space(3))) char *)(lds) + wave * 8192;
+    const int n_xfer = rd_per_thread / 2;                   // 16 bytes per lane and transfer; a workgroup's four waves interleave 1 KiB pieces
+    for (int k = 0; k < n_xfer; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = k + u < n_xfer ? k + u : 0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + long(j) * 4096),
+                                             (__attribute__((address_space(3))) void *)(ring + u * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    double acc = lds[(threadIdx.x * 7) & 1023];            // (one LDS word, so the ring is not dead)
+    if (acc == 2.3456e300) out[0] = acc;
+    double *dst = out + long(blockIdx.x) * out_stride_wg + threadIdx.x;
+    for (int k = 0; k < wr_per_thread; k++) dst[k * 256] = acc + k;
+}
+
+template <int LDS_BYTES>
+double run_dma(int grid, int rd_per_thread, int wr_per_thread, int reps)
+{
+    const long in_wg = long(rd_per_thread) * 256, out_wg = long(wr_per_thread) * 256;
+    const long in_n = in_wg * grid + 4096, out_n = out_wg * grid + 256;
+    double *in, *out;
+    hipMalloc(&in, in_n * 8); hipMalloc(&out, out_n * 8);
+    hipMemset(in, 0, in_n * 8);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 5; i++)
+        hipLaunchKernelGGL((k_stream_dma<LDS_BYTES>), dim3(grid), dim3(256), 0, 0, in, out, rd_per_thread, wr_per_thread, in_wg, out_wg);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < reps; i++)
+        hipLaunchKernelGGL((k_stream_dma<LDS_BYTES>), dim3(grid), dim3(256), 0, 0, in, out, rd_per_thread, wr_per_thread, in_wg, out_wg);
+    hipEventRecord(b, 0); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    hipFree(in); hipFree(out);
+    return ms * 1e3 / reps;
+}
+
 template <int LDS_BYTES, int INFLIGHT, bool WIDE>
 double run(int grid, int rd_per_thread, int wr_per_thread, int reps, bool cold)
 {
@@ -65,6 +112,18 @@ double run(int grid, int rd_per_thread, int wr_per_thread, int reps, bool cold)
 
 int main(int argc, char **argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "--dma") {
+        // the order-free kernel's tile: ~47 KB read (24 x 2 KiB) + 10 KB written, register loads (8 B and 16 B per lane) against LDS-DMA
+        printf("cache-resident data; 24 x 2 KiB read + 5 x 2 KiB written per workgroup; us per launch (TB/s of rd+wr bytes)\n");
+        printf("grid    registers 8B x8    registers 16B x4   LDS-DMA 16B x8 (40 KB LDS)   LDS-DMA 16B x8 (33 KB LDS)\n");
+        for (int g : {768, 1024, 1175, 2350}) {
+            const double bytes = double(24 + 5) * 2048.0 * g;
+            const double t0 = run<40960, 8, false>(g, 24, 5, 300, false), t1 = run<40960, 4, true>(g, 24, 5, 300, false),
+                         t2 = run_dma<40960>(g, 24, 5, 300), t3 = run_dma<33792>(g, 24, 5, 300);
+            printf("%5d  %6.2f (%5.2f)     %6.2f (%5.2f)     %6.2f (%5.2f)              %6.2f (%5.2f)\n", g, t0, bytes / t0 / 1e6, t1, bytes / t1 / 1e6, t2, bytes / t2 / 1e6, t3, bytes / t3 / 1e6);
+        }
+        return 0;
+    }
     const bool cold = argc > 1 && std::string(argv[1]) == "--cold";
     // per-workgroup bytes of the flux kernel today: ~63 KB read (51 rows + 10 own state + ids), 10 KB written; the
     // edge-once layout: ~38 KB read, 10 KB written.  1 double per thread = 2 KiB per workgroup.

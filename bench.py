@@ -64,7 +64,7 @@ LATTICE = 67                 # 67^3 = 300,763 nodes, 888,822 internal edges
 LATTICE_8X = 134             # the level tiled 8x (connected): 2,406,104 nodes / 7,164,444 internal edges
 HIERARCHY = (67, 55, 48, 43) # 300,763 / 166,375 / 110,592 / 79,507 nodes
 HIERARCHY_8X = (134, 110, 96, 86)   # the same hierarchy tiled 8x (connected): 2,406,104 / 1,331,000 / 884,736 / 636,056 nodes
-TRAFFIC_PROFILE = os.path.join("profiles", "r3_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r4_traffic.json")
 ROOFLINE_LAUNCHES = 1000     # back-to-back launches of the standalone flux kernel / of its data-movement probe per measurement
 
 
@@ -1101,6 +1101,8 @@ def main():
                                                   "(tests/test_gpu_order_free.py); what MGCFD_OPT_EXACT = 0 launches for this loop — the line's other figures are the bit-identical mode"}
             if flux_avg > 0:
                 a2 = (bytes_flux + bytes_ts) / flux_avg / 1e9
+                # (--fast: the sweeps run the role-specialised order-free stages where the level has the plan)
+                stage_traffic = ((traffic.get("fused_stage_order_free") if (args.fast and order_free_here) else traffic.get("fused_stage")) or {}).get("bytes")
                 roof["fused_stage"] = {"kernel": "one whole Runge-Kutta stage per launch = compute_flux_edge + boundary + far-field + time_step: what the timed sweeps run",
                                        "launches": flux_launches, "avg_kernel_us": round(flux_avg * 1e6, 3),
                                        "timed_by": "one hipEvent pair around the K timed steps (3 launches each, back to back) on the launch stream",
@@ -1114,8 +1116,8 @@ def main():
                                                                               "the new state 40, step factor or volume 8 (the flux never leaves registers)",
                                        "frac_of_bytes_a_fused_stage_must_move": round((40 * n_int + 128 * nel) / flux_avg / 1e9 / HBM_PEAK_GBS, 4),
                                        "frac_if_priced_as_flux_only": round(bytes_flux / flux_avg / 1e9 / HBM_PEAK_GBS, 4),
-                                       "traffic": traffic.get("fused_stage", {}).get("bytes"),
-                                       "traffic_over_bytes_a_fused_stage_must_move": round(traffic["fused_stage"]["bytes"] / (40 * n_int + 128 * nel), 3) if traffic.get("fused_stage", {}).get("bytes") else None}
+                                       "traffic": stage_traffic,
+                                       "traffic_over_bytes_a_fused_stage_must_move": round(stage_traffic / (40 * n_int + 128 * nel), 3) if stage_traffic else None}
             out["roofline"] = roof
     solver.close()
     if rank == 0 and world == 1 and workload == "level0" and args.mesh == "lattice" and lattice == LATTICE and not args.no_vcycle and "roofline" in out:

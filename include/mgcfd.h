@@ -133,6 +133,10 @@ typedef struct mgcfd_solver mgcfd_solver;  /* device-resident solver            
 
 const char *mgcfd_last_error(void);
 int mgcfd_abi_version(void);
+/* Optional: start bringing up the HIP runtime and `device`'s context on a thread of the library's own and return at once, so
+ * that it happens WHILE the caller reads its input files (0.1 s of a drop-in run's start-up); mgcfd_create* waits for it.
+ * No reference counterpart (a CPU code has no device to wake).  Errors surface in mgcfd_create*, not here. */
+int mgcfd_device_warm_up(int device);
 
 /* ---------------------------------------------------------------------------------
  * File boundary (host only, no GPU needed)

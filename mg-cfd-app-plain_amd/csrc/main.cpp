@@ -405,6 +405,7 @@ int main(int argc, char **argv)
     }
 
     const auto t_start = std::chrono::steady_clock::now();
+    if (conf.gpus <= 1) mgcfd_device_warm_up(conf.device);      // (the runtime comes up while the files are read)
     mgcfd_mesh *mesh = nullptr;
     if (mgcfd_mesh_load_ex(conf.input_file.c_str(), conf.input_file_directory.c_str(), conf.mesh_duplicate_count,
                            conf.legacy_ordering ? MGCFD_MESH_LEGACY_ORDERING : 0, &mesh) != MGCFD_OK)

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -968,19 +969,44 @@ void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge
         const int32_t s = node_new / kSlice, lane = node_new % kSlice;
         return (static_cast<int64_t>(P.slice_row0[static_cast<size_t>(s)]) + row_in_slice) * kSlice + lane;
     };
+    // The four inverse distances of every edge (a square root and a division each: most of this function's time) are
+    // computed by several host threads over ranges of edges; the pass that places them — a node's sum of weights grows in
+    // edge order, as the reference's does — stays serial.
+    const int64_t n_int = F.n_internal;
+    std::vector<double> invd(static_cast<size_t>(n_int) * 4, 0.0);          // per edge: a own, a other, b own, b other
+    {
+        int n_threads = int(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())));
+        n_threads = std::max(1, std::min<int>(n_threads, int(n_int / 50000)));
+        if (const char *o = std::getenv("MGCFD_PLAN_THREADS")) n_threads = std::max(1, std::atoi(o));
+        auto work = [&](int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; k++) {
+                const mgcfd_edge &E = fine_edges[static_cast<size_t>(F.internal_start + k)];
+                const int64_t a2 = E.a, b2 = E.b;
+                const int64_t a1 = F.mg_map[a2], b1 = F.mg_map[b2];
+                const double *ca1 = coarse_coords + 3 * a1, *cb1 = coarse_coords + 3 * b1;
+                const double *ca2 = F.coords + 3 * a2, *cb2 = F.coords + 3 * b2;
+                double *w = invd.data() + 4 * k;
+                if (a2 < n_owned && !is_coincident[static_cast<size_t>(a2)]) { w[0] = inv_distance(ca2, ca1); w[1] = inv_distance(cb1, ca2); }   // :754, :768
+                if (b2 < n_owned && !is_coincident[static_cast<size_t>(b2)]) { w[2] = inv_distance(cb2, cb1); w[3] = inv_distance(ca1, cb2); }   // :792, :806
+            }
+        };
+        std::vector<std::thread> workers;
+        for (int t = 1; t < n_threads; t++) workers.emplace_back(work, n_int * t / n_threads, n_int * (t + 1) / n_threads);
+        work(0, n_int / n_threads);
+        for (std::thread &w : workers) w.join();
+    }
     for (int64_t e = F.internal_start; e < F.internal_start + F.n_internal; e++) {
         const int64_t a2 = fine_edges[static_cast<size_t>(e)].a, b2 = fine_edges[static_cast<size_t>(e)].b;
         const int64_t a1 = F.mg_map[a2], b1 = F.mg_map[b2];
-        const double *ca1 = coarse_coords + 3 * a1, *cb1 = coarse_coords + 3 * b1;
-        const double *ca2 = F.coords + 3 * a2, *cb2 = F.coords + 3 * b2;
         const int32_t a1n = coarse_new_of_old[static_cast<size_t>(a1)], b1n = coarse_new_of_old[static_cast<size_t>(b1)];
         const int32_t an = P.new_of_old[static_cast<size_t>(a2)], bn = P.new_of_old[static_cast<size_t>(b2)];
+        const double *iw = invd.data() + 4 * (e - F.internal_start);
         // a2's entry: own parent a1, then b1 (ghosts of a partitioned level hold no rows)
         if (a2 < n_owned) {
             ProlongW w{0.0, 0.0, a1n, b1n};
             if (!is_coincident[static_cast<size_t>(a2)]) {
-                w.w_own = inv_distance(ca2, ca1);      // :754
-                w.w_other = inv_distance(cb1, ca2);    // :768
+                w.w_own = iw[0];                       // :754
+                w.w_other = iw[1];                     // :768
                 P.pro_wsum[static_cast<size_t>(an)] += w.w_own;
                 P.pro_wsum[static_cast<size_t>(an)] += w.w_other;
             }
@@ -990,8 +1016,8 @@ void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge
         if (b2 < n_owned) {
             ProlongW w{0.0, 0.0, b1n, b1n};
             if (!is_coincident[static_cast<size_t>(b2)]) {
-                w.w_own = inv_distance(cb2, cb1);      // :792
-                w.w_other = inv_distance(ca1, cb2);    // :806
+                w.w_own = iw[2];                       // :792
+                w.w_other = iw[3];                     // :806
                 P.pro_wsum[static_cast<size_t>(bn)] += w.w_own;
                 P.pro_wsum[static_cast<size_t>(bn)] += w.w_other;
             }
@@ -1012,9 +1038,13 @@ void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge
     P.pro_tile_ids.assign(static_cast<size_t>(P.n_tiles) * kProCap, -1);
     P.pro_s16.assign(P.pro.size(), 0);
     P.pro_own16.assign(static_cast<size_t>(nel), 0);
-    std::vector<int32_t> ids;
     auto parent_of = [&](int64_t n) { const int32_t p = P.pro_parent[static_cast<size_t>(n)]; return p < 0 ? ~p : p; };
-    for (int32_t t = 0; t < P.n_tiles && P.pro_tiled; t++) {
+    // (the tiles write disjoint parts of every array: ranges of them on host threads; a tile that refers to more coarse nodes
+    //  than the LDS image holds switches the tiled form off for the level, whoever finds it)
+    std::atomic<bool> tiled_ok{true};
+    auto tile_work = [&](int32_t t_begin, int32_t t_end) {
+    std::vector<int32_t> ids;
+    for (int32_t t = t_begin; t < t_end && tiled_ok.load(std::memory_order_relaxed); t++) {
         const int64_t n0 = int64_t(t) * kTile, n1 = std::min<int64_t>(nel, n0 + kTile);
         const int32_t s0 = t * (kTile / kSlice), s1 = s0 + kTile / kSlice;
         ids.clear();
@@ -1029,7 +1059,7 @@ void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge
         }
         std::sort(ids.begin(), ids.end());
         ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-        if (ids.size() > static_cast<size_t>(kProCap)) { P.pro_tiled = false; break; }
+        if (ids.size() > static_cast<size_t>(kProCap)) { tiled_ok.store(false, std::memory_order_relaxed); break; }
         P.pro_tile_n[static_cast<size_t>(t)] = static_cast<int32_t>(ids.size());
         std::copy(ids.begin(), ids.end(), P.pro_tile_ids.begin() + static_cast<size_t>(t) * kProCap);
         auto pos = [&](int32_t id) { return static_cast<uint16_t>(std::lower_bound(ids.begin(), ids.end(), id) - ids.begin()); };
@@ -1043,6 +1073,18 @@ void build_transfer_plan(const mgcfd_level_desc &F, const std::vector<mgcfd_edge
             }
         }
     }
+    };
+    {
+        int n_threads = int(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())));
+        n_threads = std::max(1, std::min<int>(n_threads, P.n_tiles / 64));
+        if (const char *o = std::getenv("MGCFD_PLAN_THREADS")) n_threads = std::max(1, std::min<int>(std::atoi(o), P.n_tiles));
+        std::vector<std::thread> workers;
+        auto range_begin = [&](int k) { return static_cast<int32_t>(int64_t(P.n_tiles) * k / n_threads); };
+        for (int k = 1; k < n_threads; k++) workers.emplace_back(tile_work, range_begin(k), range_begin(k + 1));
+        tile_work(range_begin(0), range_begin(1));
+        for (std::thread &w : workers) w.join();
+    }
+    P.pro_tiled = tiled_ok.load();
     if (!P.pro_tiled) { P.pro_tile_n.clear(); P.pro_tile_ids.clear(); P.pro_s16.clear(); P.pro_own16.clear(); }
 }
 
@@ -1068,6 +1110,8 @@ uint64_t plan_digest(const LevelPlan &P)
     vec(P.te_chunk_ptr); vec(P.te_count); vec(P.te_slots); vec(P.te_w); vec(P.gat16);
     vec(P.free_halo); vec(P.hr_row0); vec(P.hr_code); vec(P.hr_w); vec(P.hg16);
     vec(P.rows_main); vec(P.tail_tile_ptr); vec(P.tail_rec); vec(P.tail_begin); vec(P.tail_count);
+    // ... and the transfer plan (build_transfer_plan: inverse distances and its per-tile part on host threads as well)
+    vec(P.child_ptr); vec(P.child); vec(P.pro); vec(P.pro_parent); vec(P.pro_wsum); vec(P.pro_tile_n); vec(P.pro_tile_ids); vec(P.pro_s16); vec(P.pro_own16);
     const int64_t scalars[] = {P.halo_max, P.te_max, P.hr_max_rows, P.hr_max_tile_rows, P.halo_overflow_refs, P.hr_entries, P.hr_foreign, P.halo_total,
                                int64_t(P.edge_once), int64_t(P.free_rows), int64_t(P.free_wide), int64_t(P.half), int64_t(P.has_tail)};
     eat(scalars, sizeof(scalars));

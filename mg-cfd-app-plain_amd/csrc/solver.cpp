@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <future>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -621,10 +623,21 @@ mgcfd_solver::~mgcfd_solver()
 // ------------------------------------------------------------------------------------------
 // construction
 // ------------------------------------------------------------------------------------------
+// mgcfd_device_warm_up: the runtime's and the device context's start-up on a thread of its own (once per process)
+static std::mutex g_warm_mutex;
+static std::shared_future<void> g_warm;
+static void wait_for_warm_up()
+{
+    std::shared_future<void> f;
+    { std::lock_guard<std::mutex> lk(g_warm_mutex); f = g_warm; }
+    if (f.valid()) f.wait();
+}
+
 static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels, int nlevels, int mesh_variant, int device,
                                                   const int64_t *n_owned = nullptr, const int64_t *const *order_keys = nullptr)
 {
     if (!levels || nlevels <= 0) throw std::invalid_argument("no levels given");
+    wait_for_warm_up();
     if (mesh_variant != MGCFD_MESH_FVCORR && mesh_variant != MGCFD_MESH_M6_WING &&
         mesh_variant != MGCFD_MESH_LA_CASCADE && mesh_variant != MGCFD_MESH_ROTOR_37)
         throw std::invalid_argument("unknown mesh variant");
@@ -920,6 +933,13 @@ extern "C" {
 
 const char *mgcfd_last_error(void) { return g_last_error.c_str(); }
 int mgcfd_abi_version(void) { return 1; }
+int mgcfd_device_warm_up(int device)
+{
+    std::lock_guard<std::mutex> lk(g_warm_mutex);
+    if (!g_warm.valid())
+        g_warm = std::async(std::launch::async, [device] { if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr); }).share();
+    return MGCFD_OK;
+}
 
 // ---- file boundary ----
 int mgcfd_mesh_load(const char *input_dat, const char *directory, int duplicate, mgcfd_mesh **out)

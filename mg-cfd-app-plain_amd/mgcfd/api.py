@@ -110,6 +110,7 @@ _SIGNATURES = [
     ("mgcfd_bench_flux", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_bench_indirect_rw", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_bench_stream_ceiling", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    ("mgcfd_device_warm_up", C.c_int, [C.c_int]),
     ("mgcfd_step_factor_local", C.c_int, [_vp, C.c_int]),
     ("mgcfd_step_factor_min_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_step_factor_partials_devptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]),

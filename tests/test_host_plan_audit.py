@@ -65,7 +65,7 @@ def test_the_audit_sees_a_broken_plan():
         mgcfd.plan_audit(bad, mg.mesh_variant)
 
 
-@pytest.mark.parametrize("name", ["lattice 24^3 (54 tiles)", "tetrahedra, two levels", "random graph, degree 10 (long rows)", "lattice 40^3 (250 tiles)", "mixed elements 36^3"])
+@pytest.mark.parametrize("name", ["lattice 24^3 (54 tiles)", "tetrahedra, two levels", "three lattice levels", "random graph, degree 10 (long rows)", "lattice 40^3 (250 tiles)", "mixed elements 36^3"])
 def test_the_plan_does_not_depend_on_the_number_of_host_threads(name, monkeypatch):
     """Round 4 builds the per-tile part of a plan (halo lists, tile-local codes, edge-once lists, half rows) on several host
     threads, each over a contiguous range of tiles, and joins the parts in tile order: every array and every counter must come

@@ -4,7 +4,7 @@
 #   FETCH_SIZE / WRITE_SIZE passes over the bench command (separate --pmc passes; no trace domain beside --kernel-trace).
 # Usage (GPU box): bash tools/collect_profiles.sh <tag>
 set -u
-tag=${1:-r3}
+tag=${1:-r4}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -15,6 +15,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_vcycle -- python
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 40 --warmup 5 --no-vcycle --cpu-seconds 0 > $out/pmc_$c.log 2>&1
 done
+# the fast mode (MGCFD_OPT_EXACT = 0: order-free stages): its line, its kernel summary, its traffic
+python3 bench.py --fast --steps 2000 --warmup 200 --cpu-seconds 0 > $out/bench_fast.json 2> $out/bench_fast.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_bench_fast -- python3 bench.py --fast --no-vcycle --cpu-seconds 0 > $out/bench_fast_under_rocprof.json 2> $out/kt_bench_fast.log
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmcfast_$c -- python3 bench.py --fast --steps 40 --warmup 5 --no-vcycle --cpu-seconds 0 > $out/pmcfast_$c.log 2>&1
+done
 python3 - "$out" <<'PY'
 import csv, glob, json, os, sys, collections
 out = sys.argv[1]
@@ -23,11 +29,13 @@ def stats(d, dst):
         open(dst, "w").write(open(f).read())
 stats(os.path.join(out, "kt_bench"), os.path.join(out, "bench_default_kernel_stats.csv"))
 stats(os.path.join(out, "kt_vcycle"), os.path.join(out, "vcycle_kernel_stats.csv"))
+stats(os.path.join(out, "kt_bench_fast"), os.path.join(out, "bench_fast_kernel_stats.csv"))
 agg = collections.defaultdict(list)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(os.path.join(out, "pmc_" + c, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for sub in ("pmc_", "pmcfast_"):
+        for f in glob.glob(os.path.join(out, sub + c, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
 lines = [f"{k:70s} {c:12s} launches={len(v):4d} mean={sum(v)/len(v):.6g}" for (k, c), v in sorted(agg.items())]
 open(os.path.join(out, "pmc_bench_traffic.txt"), "w").write("\n".join(lines) + "\n")
 def mean(sub, counter):
@@ -41,7 +49,8 @@ traffic = {"_comment": "HBM-side bytes per launch from rocprofv3 --pmc (separate
            "flux_only": pack(lambda k: "exact::k_flux_tile<" in k and ", false, false," in k),
            "fused_stage": pack(lambda k: "exact::k_flux_tile<" in k and ", true, false," in k),
            "indirect_rw_tile": pack(lambda k: "k_indirect_rw_tile" in k),
-           "flux_order_free": pack(lambda k: "k_flux_free<" in k)}
+           "flux_order_free": pack(lambda k: "k_flux_free<false, false" in k),
+           "fused_stage_order_free": pack(lambda k: "k_flux_free<true, false" in k)}
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=2)
 print(open(os.path.join(out, "pmc_bench_traffic.txt")).read())
 PY

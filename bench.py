@@ -602,7 +602,8 @@ def main():
                     help="level0 workload: the jittered lattice (default; every interior node six neighbours) or the mixed-element level on the same points "
                          "(hexahedral core, prism layers, tetrahedral far field: internal degrees 3 ... 14); the default line reports the mixed level's "
                          "flux-kernel figure beside the lattice's in roofline.mixed_mesh")
-    ap.add_argument("--fast", action="store_true", help="allow FMA contraction (MGCFD_OPT_EXACT=0)")
+    ap.add_argument("--fast", action="store_true", help="the fast mode (MGCFD_OPT_EXACT=0): FMA contraction and order-free flux accumulation — within 1e-12 "
+                                                        "relative of the reference per sweep, not reproducible bit for bit from run to run")
     ap.add_argument("--variant", type=int, default=-1, help="MGCFD_OPT_FLUX_VARIANT (see include/mgcfd.h)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "library", "ipc", "torch"],
                     help="partitioned workload: who runs the sweep loop and the halo exchange — the library with direct stores into the neighbours' memory "
@@ -650,6 +651,17 @@ def main():
     if rehearsal:
         local_rank = 0
 
+    # Host waits spin instead of sleeping (hipDeviceScheduleSpin, set before anything creates the device's context): the timed
+    # region ends in a synchronisation, and a blocked host thread wakes tens of microseconds after the GPU is done — 2-4 us per
+    # step of the driver's 20-step region.  MGCFD_BENCH_SPIN=0 leaves the runtime's default (for A/B).
+    if os.environ.get("MGCFD_BENCH_SPIN", "1") != "0" and not args.plumbing_only:
+        try:
+            import ctypes
+            _hip = ctypes.CDLL("libamdhip64.so")
+            if _hip.hipSetDevice(ctypes.c_int(local_rank)) == 0:
+                _hip.hipSetDeviceFlags(ctypes.c_uint(1))                            # hipDeviceScheduleSpin
+        except OSError:
+            pass
     import torch
     dist = None
     if world > 1:

@@ -58,7 +58,13 @@ enum { MGCFD_ARR_VARIABLES = 0, MGCFD_ARR_OLD_VARIABLES, MGCFD_ARR_FLUXES, MGCFD
 enum {
     MGCFD_OPT_EXACT = 0,       /* 1 (default): kernels compiled without FMA contraction and summing in the
                                   reference's order => bit-identical to the reference built with
-                                  -ffp-contract=off.  0: contraction allowed (faster, ~1e-16 relative). */
+                                  -ffp-contract=off, and the same bits from run to run.
+                                  0: the fast mode — FMA contraction allowed AND, with MGCFD_OPT_FLUX_VARIANT = -1, the
+                                  order-free flux kernel wherever a level has its plan (bit 6 below): within 1e-12 relative
+                                  of the reference per sweep (north_star allows 1e-10), but NOT reproducible bit for bit
+                                  from run to run, nor between a whole level and the same level partitioned (a launch over
+                                  part of a level takes the node gather).  MGCFD_OPT_EXACT = 0 with MGCFD_OPT_FLUX_VARIANT = 1
+                                  is the deterministic contracted mode (the node gather only). */
     MGCFD_OPT_TIMING = 1,      /* 1: bracket every loop with hipEvents (Times.csv columns; every loop its own launch, as the
                                   reference's -DTIME build brackets them, src/Monitoring/timer.cpp:58-195); 2: only the flux launches
                                   of every 8th sweep; 3: as 2 for every sweep (reads back as 2);
@@ -93,8 +99,10 @@ enum {
                                    launch, <= 1e-10 after 25 V-cycles, the reference's -v rule (validation.cpp:159-166) passes;
                                    tests/test_gpu_order_free.py.  Levels without a half-row plan run the node gather.
                                    With MGCFD_OPT_EXACT = 0 the automatic choice (-1) sets this bit where the kernel is the faster
-                                   one: for every standalone flux launch of a level that has the plan, and for the fused stages of
-                                   levels with long rows or tile halos beyond the shared table (tetrahedral levels). */
+                                   one: for every standalone flux launch of a level that has the plan, for the fused stages of
+                                   levels with long rows or tile halos beyond the shared table (tetrahedral levels) and — round 4:
+                                   role-specialised stages — of levels on the kernel's fast path (halos of at most 290 nodes, at
+                                   most five evaluations per lane: the lattice-like levels of the named meshes). */
     MGCFD_OPT_FUSE_UPDATE = 5, /* 1 (default): mgcfd_smooth / mgcfd_run_cycles run each Runge-Kutta stage as ONE
                                   launch (fluxes + time_step, same operations); 0: one launch per loop */
     MGCFD_OPT_GRAPH = 6,       /* 1: replay each smoothing sweep / multigrid cycle from a captured hipGraph (one host

@@ -128,7 +128,8 @@ void print_help()
         "  --loop-timers                    Every loop its own launch between two events (2.7x slower cycles); default: fused\n"
         "                                   stages, per-loop times attributed from every 32nd sweep, which runs per loop\n"
         "  --no-indirect-rw                 Skip the indirect_rw bandwidth probe each RK stage\n"
-        "  --fast                           Allow FMA contraction (results within 1e-12 relative)\n"
+        "  --fast                           Fast mode: FMA contraction and order-free flux accumulation (results within\n"
+        "                                   1e-12 relative of the reference's per sweep, not reproducible bit for bit from run to run)\n"
         "  --legacy-ordering                Sort edges by (a,b,x,y,z) like the reference built with -DLEGACY_ORDERING\n");
 }
 

@@ -84,6 +84,11 @@ def run():
                 v = (b[sel, k] - t0) / 100.0
                 q = np.percentile(v, [0, 10, 50, 90, 100])
                 print(f"    {'begin' if k == 0 else 'mark %d' % (k - 1):8s} " + " / ".join(f"{x:6.2f}" for x in q))
+        # end times by dispatch order (blockIdx): do the workgroups dispatched first also finish first?
+        for lo, hi in ((0, 151), (151, 512), (512, 1024), (1024, nb)):
+            if hi > lo and lo < nb:
+                e = en[lo:min(hi, nb)]
+                print(f"  workgroups {lo}-{min(hi, nb) - 1}: end min / median / max {e.min():.2f} / {np.median(e):.2f} / {e.max():.2f} us")
         hw = b[:, 7] & 0xFFFFFFFF; xcc = (b[:, 7] >> 32) & 0xF
         cu = (xcc << 16) | (hw & 0xFF00)                      # XCC_ID, SE_ID/SH_ID/CU_ID of HW_ID
         ids, cnt = np.unique(cu, return_counts=True)

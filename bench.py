@@ -416,11 +416,15 @@ class leg_guard:
     def fire(self):
         sys.stderr.write(f"bench.py: rank {self.rank}: {self.what} did not end within {self.seconds:.0f} s; leaving with what was measured\n")
         sys.stderr.flush()
-        if self.rank == 0 and self.line is not None:
-            self.line[self.key] = {"error": f"{self.what} did not end within {self.seconds:.0f} s on some rank; the line's other figures were measured before it"}
-            sys.stdout.write(json.dumps(self.line) + "\n")
+        line = self.line() if callable(self.line) else self.line            # (a callable: the line as it stands when the guard fires)
+        if self.rank == 0 and line is not None:
+            line[self.key] = {"error": f"{self.what} did not end within {self.seconds:.0f} s on some rank; the line's other figures were measured before it"}
+            sys.stdout.write(json.dumps(line) + "\n")
             sys.stdout.flush()
-        os._exit(0 if self.line is not None or self.rank != 0 else 1)
+        os._exit(0 if line is not None or self.rank != 0 else 1)
+
+    def cancel(self):
+        self.timer.cancel()
 
     def __enter__(self):
         self.timer.start()
@@ -798,6 +802,8 @@ def main():
 
                 def one_sweep():
                     injected_failure("phase", rank)
+                    if injected("hang") and rank == world - 1:         # (rehearsal of the ladder's guard: this rank never comes back)
+                        time.sleep(1e6)
                     solver.rank_sweeps(0, 1)
                     torch.cuda.synchronize()
                     # (the status first: while waits that gave up are unacknowledged the library refuses to hand out the state)
@@ -868,9 +874,36 @@ def main():
             part_candidates.extend(m for _, m in sorted(timed))
             part_next()
 
+        ladder_guard = None
         if world == 1:
             step, exchange = (lambda: solver.smooth(0, 1)), None
         elif args.exchange != "torch":
+            # Before anything of the library's own loops runs between ranks (none of it has run on several GPUs yet): the torch
+            # path's figure over the same W + K sweeps, kept as the line to print if a later rung never comes back — a rank stuck
+            # inside a collective cannot be interrupted, so a guard prints that line and every rank leaves (leg_guard).
+            part_reset()
+            for _ in range(args.warmup):
+                sw.sweep()
+            torch.cuda.synchronize(); dist.barrier()
+            t0f = time.perf_counter()
+            for _ in range(args.steps):
+                sw.sweep()
+            torch.cuda.synchronize()
+            tf = torch.tensor([time.perf_counter() - t0f], dtype=torch.float64, device=dev)
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            fallback_elapsed = float(tf.item())
+            part_notes.append(f"torch path over the same {args.warmup} + {args.steps} sweeps, measured first: {fallback_elapsed / max(args.steps, 1) * 1e6:.0f} us per sweep")
+            part_reset()
+
+            def fallback_line():
+                return {"metric": "Medges/s (compute_flux_edge)", "value": round(3 * int(L["n_internal"]) * args.steps / fallback_elapsed / 1e6, 3), "unit": "Medges/s",
+                        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(fallback_elapsed / max(args.steps, 1) * 1e3, 6),
+                        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                        "config": {"workload": f"M6-L0-like level tiled 8x ({lattice}^3 jittered lattice): {int(L['nel'])} nodes / {int(L['n_internal'])} internal edges, recursive coordinate bisection into {world} parts",
+                                   "workload_kind": "partitioned", "collectives": backend, "numerics": config.get("numerics"),
+                                   "exchange": torch_exchange + " (the figure of the torch path measured first: a form of the library's own loop did not come back; " + "; ".join(part_notes) + ")"}}
+            ladder_guard = leg_guard(float(os.environ.get("MGCFD_BENCH_LADDER_S", "420")), rank, fallback_line, "library_forms", "the library's rank loop (start-up checks or timed sweeps)")
+            ladder_guard.__enter__()
             setup_error = None
             uid = [None]
             if not rehearsal:
@@ -1026,6 +1059,8 @@ def main():
         step, exchange = sw.sweep, torch_exchange
         part_next()
     if workload == "partitioned":
+        if ladder_guard is not None:
+            ladder_guard.cancel()                                # (the sweeps were measured: the legs that follow have guards of their own)
         config["exchange"] = exchange + ("".join(f" ({n})" for n in part_notes) if world > 1 else "") if exchange else exchange
     flux_launches = 3 * args.steps if live_timing and workload == "level0" else 0
     flux_avg = gpu_seconds / flux_launches if flux_launches else 0.0

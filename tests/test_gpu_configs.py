@@ -463,6 +463,26 @@ def test_bench_form_ladder_survives_injected_failures(fail, expect):
     assert line["config"]["library_ranks"]["ranks"] == 2                    # (rank 0's own attachment succeeded in every case)
 
 
+def test_bench_prints_the_torch_paths_line_when_a_library_form_never_comes_back():
+    """The library's rank loops have run on ONE GPU only, and a rank stuck inside a collective cannot be interrupted: bench.py
+    measures the torch path over the same W + K sweeps FIRST and arms a guard around the library's rungs; if they have not come back
+    in time (here: one rank sleeps for ever inside the start-up sweep, the guard at 40 s) rank 0 prints the torch path's line — a
+    valid line, saying what happened — and every rank leaves."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGCFD_BENCH_REHEARSAL="1", MGCFD_BENCH_FAIL="hang", MGCFD_BENCH_LADDER_S="40", MGCFD_BENCH_WATCHDOG_S="300")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--lattice", "30", "--no-vcycle", "--no-group"],
+                       capture_output=True, text=True, env=env, timeout=400)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stderr[-2000:]
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["steps"] == 5 and line["config"]["workload_kind"] == "partitioned"
+    assert "did not come back" in line["config"]["exchange"] and "did not end within" in line["library_forms"]["error"]
+
+
 def test_bench_in_process_group_leg_on_this_gpu():
     """`bench.py --gpus 2` (rehearsal: both ranks and both group members on this device): beside the ranks' figure the line
     carries `in_process_group` — the level and the hierarchy swept by ONE process through mgcfd_group_sweeps / mgcfd_group_cycles —

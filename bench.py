@@ -655,17 +655,6 @@ def main():
     if rehearsal:
         local_rank = 0
 
-    # Host waits spin instead of sleeping (hipDeviceScheduleSpin, set before anything creates the device's context): the timed
-    # region ends in a synchronisation, and a blocked host thread wakes tens of microseconds after the GPU is done — 2-4 us per
-    # step of the driver's 20-step region.  MGCFD_BENCH_SPIN=0 leaves the runtime's default (for A/B).
-    if os.environ.get("MGCFD_BENCH_SPIN", "1") != "0" and not args.plumbing_only:
-        try:
-            import ctypes
-            _hip = ctypes.CDLL("libamdhip64.so")
-            if _hip.hipSetDevice(ctypes.c_int(local_rank)) == 0:
-                _hip.hipSetDeviceFlags(ctypes.c_uint(1))                            # hipDeviceScheduleSpin
-        except OSError:
-            pass
     import torch
     dist = None
     if world > 1:

@@ -2423,15 +2423,13 @@ k_prolong_tile(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t
     const int32_t slice = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i >> 6));
     const int64_t sc = stride_coarse;
 
-    // stage the tile's coarse residuals (ids first: they head the dependent chain)
-    const int32_t n_ids = pro_tile_n[t];
+    // The tile's coarse residuals are staged behind a dependent chain (ids -> residuals by id): the id of this thread's first staged
+    // node goes out FIRST (a fixed-stride table, -1 padded: the address needs only the tile number), everything that depends on
+    // nothing — the node's own state, residual, weights — behind it, and the gather last, so that the chain's two round trips are
+    // not followed by a third (round 4: the staging loop used to stand in front of every other load).
     const int32_t *ids = pro_tile_ids + int64_t(t) * kProCap;
-    for (int32_t k = tid; k < n_ids; k += kBlock) {
-        const int64_t c = ids[k];
-        double *d = cr + k * 5;
-        d[0] = coarse_residuals[c]; d[1] = coarse_residuals[sc + c]; d[2] = coarse_residuals[2 * sc + c];
-        d[3] = coarse_residuals[3 * sc + c]; d[4] = coarse_residuals[4 * sc + c];
-    }
+    const int32_t c_first = ids[tid];
+    const int32_t n_ids = pro_tile_n[t];
     const bool wave_live = (int64_t(slice) << 6) < nel;
     const int32_t row0 = wave_live ? slice_row0[slice] : 0;
     const int32_t n_int = wave_live ? rows_int[slice] : 0;
@@ -2447,6 +2445,19 @@ k_prolong_tile(int64_t nel, int64_t stride, int64_t stride_coarse, const int32_t
     const uint16_t *sr = pro_s16 + (int64_t(row0) << 6) + lane;
     double wa0 = wr[0], wb0 = wr[64], wa1 = wr[128], wb1 = wr[192];
     uint32_t sl0 = sr[0], sl1 = sr[64];
+    {
+        // (a thread without a staged node of its own gathers node 0 and stores nothing: the load is never conditional)
+        const int64_t c = c_first >= 0 ? c_first : 0;
+        const double d0 = coarse_residuals[c], d1 = coarse_residuals[sc + c], d2 = coarse_residuals[2 * sc + c],
+                     d3 = coarse_residuals[3 * sc + c], d4 = coarse_residuals[4 * sc + c];
+        if (tid < n_ids) { double *d = cr + tid * 5; d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = d4; }
+        for (int32_t k = tid + kBlock; k < n_ids; k += kBlock) {        // (a tile that refers to more than 256 coarse nodes: rare)
+            const int64_t c2 = ids[k];
+            double *d = cr + k * 5;
+            d[0] = coarse_residuals[c2]; d[1] = coarse_residuals[sc + c2]; d[2] = coarse_residuals[2 * sc + c2];
+            d[3] = coarse_residuals[3 * sc + c2]; d[4] = coarse_residuals[4 * sc + c2];
+        }
+    }
     __syncthreads();
 
     const double *od = cr + own_slot * 5;

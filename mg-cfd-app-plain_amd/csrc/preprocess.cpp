@@ -664,23 +664,30 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                     for (int32_t tid = 0; tid < n_here; tid++) { n_eval += own[tid]; own_slice[tid / kSlice] += own[tid]; lanes[tid / kSlice]++; }
                     // rows per slice: proportional to what the slice's nodes own, then one more wherever the capacity is short
                     int32_t rows_h[kTile / kSlice] = {0};
-                    int32_t cap_total = 0;
-                    for (int32_t sl = 0; sl < kTile / kSlice; sl++) {
-                        // floor of the slice's mean — never more than a lane keeps in registers (k_flux_half walks kHalfMaxRows half
-                        // rows at most: what a slice cannot hold goes to the other slices' lanes, or the level runs the node gather)
-                        rows_h[sl] = lanes[sl] ? std::min<int32_t>(kFreeMaxRows, own_slice[sl] / lanes[sl]) : 0;
-                        cap_total += rows_h[sl] * lanes[sl];
-                    }
-                    while (cap_total < n_eval) {
-                        int32_t best = -1; double need = -1.0;
+                    // First with at most kHalfMaxRows rows per slice — what a lane of the ordered half-row kernel keeps in registers
+                    // and what the order-free kernel requests up front: a slice that owns more spills its surplus into the other
+                    // slices' lanes (foreign entries) and the level stays eligible for k_flux_half.  Only a tile whose evaluations do
+                    // not fit 5 rows x its lanes gets longer slices (up to kFreeMaxRows: the order-free kernel walks them in a loop).
+                    // (Round 3 went straight to the long slices and so took non-uniform levels away from k_flux_half: advisor finding.)
+                    auto distribute = [&](int32_t row_cap) {
+                        int32_t cap_total = 0;
                         for (int32_t sl = 0; sl < kTile / kSlice; sl++) {
-                            if (!lanes[sl] || rows_h[sl] >= kFreeMaxRows) continue;
-                            const double d = double(own_slice[sl]) / lanes[sl] - rows_h[sl];      // how far the slice's mean is above its rows
-                            if (d > need) { need = d; best = sl; }
+                            rows_h[sl] = lanes[sl] ? std::min<int32_t>(row_cap, own_slice[sl] / lanes[sl]) : 0;    // floor of the slice's mean
+                            cap_total += rows_h[sl] * lanes[sl];
                         }
-                        if (best < 0) { Q.free_rows = false; break; }
-                        rows_h[best]++; cap_total += lanes[best];
-                    }
+                        while (cap_total < n_eval) {
+                            int32_t best = -1; double need = -1e300;
+                            for (int32_t sl = 0; sl < kTile / kSlice; sl++) {
+                                if (!lanes[sl] || rows_h[sl] >= row_cap) continue;
+                                const double d = double(own_slice[sl]) / lanes[sl] - rows_h[sl];      // how far the slice's mean is above its rows
+                                if (d > need) { need = d; best = sl; }
+                            }
+                            if (best < 0) return false;
+                            rows_h[best]++; cap_total += lanes[best];
+                        }
+                        return true;
+                    };
+                    if (!distribute(kHalfMaxRows) && !distribute(kFreeMaxRows)) Q.free_rows = false;
                     for (int32_t sl = 0; sl < kTile / kSlice; sl++)
                         Q.hr_row0[static_cast<size_t>(s0 - s_begin + sl) + 1] = Q.hr_row0[static_cast<size_t>(s0 - s_begin + sl)] + rows_h[sl];
                     for (int32_t sl = 0; sl < kTile / kSlice; sl++) Q.hr_max_rows = std::max(Q.hr_max_rows, rows_h[sl]);

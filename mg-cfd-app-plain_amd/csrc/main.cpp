@@ -398,6 +398,7 @@ int run_on_several_gpus(const Config &conf, mgcfd_mesh *mesh, int levels, int me
 
 int main(int argc, char **argv)
 {
+    const double epoch_at_main = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
     Config conf;
     if (!parse_arguments(argc, argv, conf)) return 1;
     if (conf.input_file.empty()) {
@@ -424,6 +425,7 @@ int main(int argc, char **argv)
     // where the wall time outside the reference's timed region goes (stderr: stdout stays the reference's, line for line)
     std::fprintf(stderr, "[euler3d_gpu_double] input files read in %.2f s, gather plans built and uploaded in %.2f s\n", t_read,
                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create).count());
+    const auto t_created = std::chrono::steady_clock::now();
     mgcfd_set_option(solver, MGCFD_OPT_EXACT, conf.fast_math ? 0 : 1);
     mgcfd_set_option(solver, MGCFD_OPT_TIMING, conf.timers ? (conf.loop_timers ? 1 : 4) : 0);
     mgcfd_set_option(solver, MGCFD_OPT_INDIRECT_RW, (conf.indirect_rw && conf.timers) ? 1 : 0);
@@ -491,7 +493,15 @@ int main(int argc, char **argv)
     write_csv(ipath, ih, il, levels, iters, false, 0.0);
     std::printf("Loop stats written to: %s\n", ipath.c_str());
 
+    const auto t_out = std::chrono::steady_clock::now();
     mgcfd_destroy(solver);
     mgcfd_mesh_free(mesh);
+    if (std::getenv("MGCFD_PLAN_TIMING"))       // (the two epoch times let a caller see what the process spends before main() and after it)
+        std::fprintf(stderr, "[euler3d_gpu_double] main() began at %.3f and returns at %.3f (seconds of the epoch)\n", epoch_at_main,
+                     std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
+    if (std::getenv("MGCFD_PLAN_TIMING"))
+        std::fprintf(stderr, "[euler3d_gpu_double] since main() began: files read %.3f s, solver created %.3f s, cycles done %.3f s, outputs written %.3f s, freed %.3f s\n",
+                     t_read, std::chrono::duration<double>(t_created - t_start).count(), std::chrono::duration<double>(t0 - t_start).count() + total_compute_time,
+                     std::chrono::duration<double>(t_out - t_start).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
     return 0;
 }

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <functional>
 #include <future>
 
 #include <algorithm>
@@ -58,6 +59,32 @@ template <typename T> static T *dev_upload(const std::vector<T> &v)
     if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return p;
 }
+
+// A level's device arrays live in ONE block (a creation is one hipMalloc and a destruction one hipFree per level instead
+// of 55 of each).  build_solver first lists them — which member points where, from which host array it is filled — with
+// no call into the runtime (so that the listing and the repacking into device layouts can run while the device is still
+// waking up), then allocates the block, sets the members and copies.
+struct LevelStaging {
+    struct Item { std::function<void(char *)> place; const void *src; size_t bytes; size_t offset; };
+    std::vector<Item> items;
+    std::vector<std::shared_ptr<void>> keep;      // arrays repacked for the device, alive until they have been copied
+    size_t total = 0;
+    static constexpr size_t kAlign = 4096;
+    template <typename F> void alloc(F *&field, size_t bytes, const void *src = nullptr)
+    {
+        const size_t off = total;
+        total += (std::max<size_t>(bytes, 1) + kAlign - 1) / kAlign * kAlign;
+        F **where = &field;
+        items.push_back({[where, off](char *base) { *where = reinterpret_cast<F *>(base + off); }, src, src ? bytes : 0, off});
+    }
+    template <typename F, typename T> void upload(F *&field, const std::vector<T> &v) { alloc(field, v.size() * sizeof(T), v.data()); }
+    template <typename F, typename T> void upload(F *&field, std::vector<T> &&v)
+    {
+        auto held = std::make_shared<std::vector<T>>(std::move(v));
+        keep.push_back(held);
+        upload(field, *held);
+    }
+};
 
 struct EventPair { hipEvent_t start, stop; int level, loop; bool is_flux_internal; int launches; };
 
@@ -159,6 +186,9 @@ struct DeviceLevel {
     std::vector<std::pair<int32_t *, int64_t>> halo_plans;   // device id lists of the halo messages
     std::unique_ptr<HaloExchange> hx;    // the C++-side exchange of a partitioned level (mgcfd_rank_set_halo)
     bool has_transfer = false;           // plan to the next-coarser level present
+    void *block = nullptr;               // the one allocation behind every array listed at creation (LevelStaging)
+    size_t block_bytes = 0;
+    bool in_block(const void *p) const { return block && p >= block && p < static_cast<const char *>(block) + block_bytes; }
     int64_t iters[MGCFD_NUM_LOOPS] = {0};
     double times[MGCFD_NUM_LOOPS] = {0};
     double flux_time = 0.0;
@@ -597,7 +627,8 @@ mgcfd_solver::~mgcfd_solver()
                         const_cast<int32_t *>(lv.dp.tail.rows_main), const_cast<int32_t *>(lv.dp.tail.tile_ptr),
                         const_cast<double2 *>(lv.dp.tail.rec), const_cast<int32_t *>(lv.dp.tail.begin),
                         const_cast<int32_t *>(lv.dp.tail.count), lv.dp.tail.flux};
-        for (void *p : ptrs) if (p) (void)hipFree(p);
+        for (void *p : ptrs) if (p && !lv.in_block(p)) (void)hipFree(p);      // (what an option uploaded later has an allocation of its own)
+        if (lv.block) (void)hipFree(lv.block);
         for (auto &hp : lv.halo_plans) if (hp.first) (void)hipFree(hp.first);
         if (lv.hx) {
             HaloExchange &hx = *lv.hx;
@@ -626,6 +657,12 @@ mgcfd_solver::~mgcfd_solver()
 // mgcfd_device_warm_up: the runtime's and the device context's start-up on a thread of its own (once per process)
 static std::mutex g_warm_mutex;
 static std::shared_future<void> g_warm;
+static bool warm_up_under_way()
+{
+    std::shared_future<void> f;
+    { std::lock_guard<std::mutex> lk(g_warm_mutex); f = g_warm; }
+    return f.valid() && f.wait_for(std::chrono::seconds(0)) != std::future_status::ready;
+}
 static void wait_for_warm_up()
 {
     std::shared_future<void> f;
@@ -637,29 +674,31 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
                                                   const int64_t *n_owned = nullptr, const int64_t *const *order_keys = nullptr)
 {
     if (!levels || nlevels <= 0) throw std::invalid_argument("no levels given");
-    wait_for_warm_up();
     if (mesh_variant != MGCFD_MESH_FVCORR && mesh_variant != MGCFD_MESH_M6_WING &&
         mesh_variant != MGCFD_MESH_LA_CASCADE && mesh_variant != MGCFD_MESH_ROTOR_37)
         throw std::invalid_argument("unknown mesh variant");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        throw HipError("no HIP device available: libmgcfd_hip.so has no CPU fallback");
-    if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+    // The device is looked at before any host work, unless a warm-up of it is still under way on its own thread
+    // (mgcfd_device_warm_up): then the gather plans, which need no device, are built beside it and the device's turn
+    // comes before the uploads.
+    auto device_ready = [&]() {
+        wait_for_warm_up();
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            throw HipError("no HIP device available: libmgcfd_hip.so has no CPU fallback");
+        if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+    };
+    const bool device_later = warm_up_under_way();
+    if (!device_later) device_ready();
 
     auto s = std::make_unique<mgcfd_solver>();
     s->device = device;
     s->mesh_variant = mesh_variant;
-    s->use_device();
-    HIP_CHECK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
-    s->stream = s->own_stream;
     far_field_constants(s->ff17);
     std::memcpy(s->ff.var, s->ff17, sizeof(double) * 5);
     std::memcpy(s->ff.fc_mx, s->ff17 + 5, sizeof(double) * 3);
     std::memcpy(s->ff.fc_my, s->ff17 + 8, sizeof(double) * 3);
     std::memcpy(s->ff.fc_mz, s->ff17 + 11, sizeof(double) * 3);
     std::memcpy(s->ff.fc_de, s->ff17 + 14, sizeof(double) * 3);
-    s->err = dev_alloc<unsigned long long>(1);
-    HIP_CHECK(hipMemset(s->err, 0xFF, sizeof(unsigned long long)));
 
     s->L.resize(static_cast<size_t>(nlevels));
     const bool timing = std::getenv("MGCFD_PLAN_TIMING") != nullptr;      // where the host time of a solver's creation goes (stderr)
@@ -670,7 +709,6 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         std::fprintf(stderr, "[mgcfd create] %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    lap("device, stream");
     PlanOptions popt;
     if (const char *o = std::getenv("MGCFD_ORDERING")) popt.ordering = std::atoi(o);   // diagnostic override
     // host-side plans first (coarse permutations are needed by the fine level's transfer plan).  The levels' plans are
@@ -731,12 +769,13 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         s->L[static_cast<size_t>(l)].has_transfer = true;
     });
     lap("transfer plans");
-    // device upload: a host thread per level again (repacking into the device layouts and the copies out of pageable
-    // memory are host work; every thread selects the device for itself, the state's initialisation goes to the one stream).
-    // What only a non-default option reaches — the order-free / half-row plan, the edge-once lists, the two-phase arrays, the
-    // 32-bit neighbour codes — stays on the host until an option asks for it (upload_optional_plans): 60 % of the bytes.
+    // What the device gets, level by level, listed and repacked with no call into the runtime (LevelStaging): a host thread
+    // per level.  What only a non-default option reaches — the order-free / half-row plan, the edge-once lists, the
+    // two-phase arrays, the 32-bit neighbour codes — stays on the host until an option asks for it (upload_optional_plans):
+    // 60 % of the bytes.
+    std::vector<LevelStaging> staging(static_cast<size_t>(nlevels));
     run_per_level(nlevels, [&](int l) {
-        s->use_device();
+        LevelStaging &st = staging[static_cast<size_t>(l)];
         const mgcfd_level_desc &d = levels[l];
         DeviceLevel &lv = s->L[static_cast<size_t>(l)];
         lv.info = d;
@@ -753,30 +792,25 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
             // sees a ghost at the sweep's START state, which must not enter the next sweep's minimum
             if (P.old_of_new[static_cast<size_t>(n)] >= lv.n_owned) cb[static_cast<size_t>(n)] = std::numeric_limits<double>::infinity();
         }
-        lv.volumes = dev_upload(vol);
-        lv.cbrt_vol = dev_upload(cb);
-        lv.q = dev_alloc<double>(static_cast<size_t>(stride) * kNumStateFields);
-        lv.q_alt = dev_alloc<double>(static_cast<size_t>(stride) * 5);
-        lv.old_variables = dev_alloc<double>(static_cast<size_t>(stride) * 5);
-        lv.state[0] = lv.q; lv.state[1] = lv.q_alt; lv.state[2] = lv.old_variables;
-        lv.fluxes = dev_alloc<double>(static_cast<size_t>(stride) * 5);
-        lv.residuals = dev_alloc<double>(static_cast<size_t>(stride) * 5);
-        lv.step_factors = dev_alloc<double>(static_cast<size_t>(stride));
-        lv.sf_alt = dev_alloc<double>(static_cast<size_t>(stride));
-        lv.sfb[0] = lv.step_factors; lv.sfb[1] = lv.sf_alt;
-        lv.min_dt = dev_alloc<double>(1);
+        st.upload(lv.volumes, std::move(vol));
+        st.upload(lv.cbrt_vol, std::move(cb));
+        st.alloc(lv.fluxes, sizeof(double) * (static_cast<size_t>(stride) * 5));
+        st.alloc(lv.residuals, sizeof(double) * (static_cast<size_t>(stride) * 5));
+        st.alloc(lv.step_factors, sizeof(double) * (static_cast<size_t>(stride)));
+        st.alloc(lv.sf_alt, sizeof(double) * (static_cast<size_t>(stride)));
+        st.alloc(lv.min_dt, sizeof(double) * (1));
         // (+inf: a tile that is never launched — the ghost-only tiles of a partitioned level — holds no minimum)
-        lv.partial_min = dev_upload(std::vector<double>(static_cast<size_t>((nel + 255) / 256), std::numeric_limits<double>::infinity()));
-        lv.tile_sumsq = dev_alloc<double>(static_cast<size_t>((nel + 255) / 256));
-        lv.sumsq = dev_alloc<double>(1);
+        st.upload(lv.partial_min, std::vector<double>(static_cast<size_t>((nel + 255) / 256), std::numeric_limits<double>::infinity()));
+        st.alloc(lv.tile_sumsq, sizeof(double) * (static_cast<size_t>((nel + 255) / 256)));
+        st.alloc(lv.sumsq, sizeof(double) * (1));
         lv.n_partials = static_cast<int>(std::min<int64_t>(1024, (nel * 5 + 255) / 256));
-        lv.partials = dev_alloc<double>(static_cast<size_t>(lv.n_partials));
+        st.alloc(lv.partials, sizeof(double) * (static_cast<size_t>(lv.n_partials)));
         lv.dp.nel = nel;
         lv.dp.stride = stride;
         lv.dp.n_slices = P.n_slices;
-        lv.dp.slice_row0 = dev_upload(P.slice_row0);
-        lv.dp.rows_int = dev_upload(P.rows_int);
-        lv.dp.rows_bnd = dev_upload(P.rows_bnd);
+        st.upload(lv.dp.slice_row0, P.slice_row0);
+        st.upload(lv.dp.rows_int, P.rows_int);
+        st.upload(lv.dp.rows_bnd, P.rows_bnd);
         {
             // edge weights as [row][component][lane] so each component load of a wave is one
             // contiguous 512-byte run
@@ -788,22 +822,22 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
                 ws[(row * 4 + 2) * kSlice + lane] = P.w[e].z;
                 ws[(row * 4 + 3) * kSlice + lane] = P.w[e].k;
             }
-            lv.dp.w = dev_upload(ws);
+            st.upload(lv.dp.w, std::move(ws));
         }
-        lv.dp.old_of_new = dev_upload(P.old_of_new);
+        st.upload(lv.dp.old_of_new, P.old_of_new);
         lv.dp.n_tiles = P.n_tiles;
         lv.plan.nbr16.resize(P.nbr16.size() + 2 * kSlice, static_cast<uint16_t>(kT16Pad));   // two rows of padding
-        lv.dp.nbr16 = dev_upload(P.nbr16);
+        st.upload(lv.dp.nbr16, P.nbr16);
         {
             std::vector<int32_t> fixed(static_cast<size_t>(P.n_tiles) * kHaloStride, -1);
             for (int32_t t = 0; t < P.n_tiles; t++)
                 std::copy(P.tile_halo.begin() + P.tile_halo_ptr[static_cast<size_t>(t)],
                           P.tile_halo.begin() + P.tile_halo_ptr[static_cast<size_t>(t) + 1],
                           fixed.begin() + static_cast<size_t>(t) * kHaloStride);
-            lv.dp.tile_halo = dev_upload(fixed);
+            st.upload(lv.dp.tile_halo, std::move(fixed));
         }
-        lv.dp.tile_ovf_ptr = dev_upload(P.tile_ovf_ptr);
-        lv.dp.tile_ovf = dev_upload(P.tile_ovf);
+        st.upload(lv.dp.tile_ovf_ptr, P.tile_ovf_ptr);
+        st.upload(lv.dp.tile_ovf, P.tile_ovf);
         lv.row_bytes = int64_t(P.slice_row0.back()) * kSlice * 34;
         lv.dp.pad_row = P.slice_row0.back();
         lv.dp.pad_chunk = P.te_chunk_ptr.empty() ? 0 : P.te_chunk_ptr.back();
@@ -812,14 +846,14 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
         lv.plan.row_edge.resize(P.row_edge.size() + 2 * kSlice, -1);                     // two rows of padding
         lv.dp.has_tail = P.has_tail ? 1 : 0;
         if (lv.dp.has_tail) {
-            lv.dp.tail.rows_main = dev_upload(P.rows_main);
-            lv.dp.tail.tile_ptr = dev_upload(P.tail_tile_ptr);
-            lv.dp.tail.rec = reinterpret_cast<const double2 *>(dev_upload(P.tail_rec));
+            st.upload(lv.dp.tail.rows_main, P.rows_main);
+            st.upload(lv.dp.tail.tile_ptr, P.tail_tile_ptr);
+            st.upload(lv.dp.tail.rec, P.tail_rec);
             lv.plan.tail_begin.resize(static_cast<size_t>(lv.dp.stride), 0);         // (threads past nel read these too)
             lv.plan.tail_count.resize(static_cast<size_t>(lv.dp.stride), 0);
-            lv.dp.tail.begin = dev_upload(P.tail_begin);
-            lv.dp.tail.count = dev_upload(P.tail_count);
-            lv.dp.tail.flux = reinterpret_cast<double2 *>(dev_alloc<double>(static_cast<size_t>(6 * P.tail_total)));
+            st.upload(lv.dp.tail.begin, P.tail_begin);
+            st.upload(lv.dp.tail.count, P.tail_count);
+            st.alloc(lv.dp.tail.flux, sizeof(double) * static_cast<size_t>(6 * P.tail_total));
         }
         lv.dp.vin_ok = (P.halo_overflow_refs == 0 && P.halo_max <= kTile) ? 1 : 0;
         lv.dp.lds_complete = P.halo_overflow_refs == 0 ? 1 : 0;
@@ -850,17 +884,16 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
             lv.plan.te_w.clear(); lv.plan.te_w.shrink_to_fit();
             lv.plan.gat16.clear(); lv.plan.gat16.shrink_to_fit();
         }
-        lv.plan.nbr16.clear(); lv.plan.nbr16.shrink_to_fit();
         if (lv.has_transfer) {
-            lv.dp.child_ptr = dev_upload(P.child_ptr);
-            lv.dp.child = dev_upload(P.child);
+            st.upload(lv.dp.child_ptr, P.child_ptr);
+            st.upload(lv.dp.child, P.child);
             {
                 const size_t nc = P.child_ptr.size() - 1;
                 std::vector<int32_t> c4(nc * 4, -1);
                 for (size_t c = 0; c < nc; c++)
                     for (int32_t k = P.child_ptr[c]; k < P.child_ptr[c + 1] && k < P.child_ptr[c] + 4; k++)
                         c4[c * 4 + static_cast<size_t>(k - P.child_ptr[c])] = P.child[static_cast<size_t>(k)];
-                lv.dp.child4 = dev_upload(c4);
+                st.upload(lv.dp.child4, std::move(c4));
             }
             {
                 // prolongation entries as [row][component][lane]: every load of a wave is one contiguous run
@@ -873,23 +906,54 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
                     pw[(row * 2 + 1) * kSlice + lane] = P.pro[e].w_other;
                     pp[row * kSlice + lane] = P.pro[e].p_other;
                 }
-                lv.dp.pro_w = dev_upload(pw);
-                lv.dp.pro_p = dev_upload(pp);
+                st.upload(lv.dp.pro_w, std::move(pw));
+                st.upload(lv.dp.pro_p, std::move(pp));
             }
             lv.dp.pro_tiled = P.pro_tiled ? 1 : 0;
             if (P.pro_tiled) {
-                lv.dp.pro_tile_n = dev_upload(P.pro_tile_n);
-                lv.dp.pro_tile_ids = dev_upload(P.pro_tile_ids);
+                st.upload(lv.dp.pro_tile_n, P.pro_tile_n);
+                st.upload(lv.dp.pro_tile_ids, P.pro_tile_ids);
                 lv.plan.pro_s16.resize(P.pro_s16.size() + 4 * kSlice, 0);          // four rows of padding
-                lv.dp.pro_s16 = dev_upload(P.pro_s16);
-                lv.dp.pro_own16 = dev_upload(P.pro_own16);
+                st.upload(lv.dp.pro_s16, P.pro_s16);
+                st.upload(lv.dp.pro_own16, P.pro_own16);
             }
-            lv.dp.pro_parent = dev_upload(P.pro_parent);
-            lv.dp.pro_wsum = dev_upload(P.pro_wsum);
+            st.upload(lv.dp.pro_parent, P.pro_parent);
+            st.upload(lv.dp.pro_wsum, P.pro_wsum);
             // the per-entry host copies are not needed again
             lv.plan.pro.clear(); lv.plan.pro.shrink_to_fit();
         }
         lv.plan.w.clear(); lv.plan.w.shrink_to_fit();
+    });
+    lap("device layouts repacked (a thread per level)");
+    if (device_later) device_ready();
+    s->use_device();
+    HIP_CHECK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    s->stream = s->own_stream;
+    s->err = dev_alloc<unsigned long long>(1);
+    HIP_CHECK(hipMemset(s->err, 0xFF, sizeof(unsigned long long)));
+    lap("device (behind its warm-up), stream");
+    // the copies out of pageable memory are host work too: a thread per level again, every thread selects the device
+    // for itself; the state's initialisation goes to the one stream
+    run_per_level(nlevels, [&](int l) {
+        s->use_device();
+        DeviceLevel &lv = s->L[static_cast<size_t>(l)];
+        LevelStaging &st = staging[static_cast<size_t>(l)];
+        const int64_t stride = lv.dp.stride;
+        HIP_CHECK(hipMalloc(&lv.block, st.total));
+        lv.block_bytes = st.total;
+        for (const LevelStaging::Item &it : st.items) {
+            it.place(static_cast<char *>(lv.block));
+            if (it.bytes) HIP_CHECK(hipMemcpy(static_cast<char *>(lv.block) + it.offset, it.src, it.bytes, hipMemcpyHostToDevice));
+        }
+        st = LevelStaging();
+        // (the three state buffers keep allocations of their own: a partitioned level exports them to its peers'
+        // processes, and an inter-process handle names a whole allocation)
+        lv.q = dev_alloc<double>(static_cast<size_t>(stride) * kNumStateFields);
+        lv.q_alt = dev_alloc<double>(static_cast<size_t>(stride) * 5);
+        lv.old_variables = dev_alloc<double>(static_cast<size_t>(stride) * 5);
+        lv.state[0] = lv.q; lv.state[1] = lv.q_alt; lv.state[2] = lv.old_variables;
+        lv.sfb[0] = lv.step_factors; lv.sfb[1] = lv.sf_alt;
+        lv.plan.nbr16.clear(); lv.plan.nbr16.shrink_to_fit();
         s->upload_optional_plans(lv);
         // initial state: far field everywhere, fluxes/residuals/old/step factors zero
         HIP_CHECK(hipMemsetAsync(lv.old_variables, 0, sizeof(double) * 5 * stride, s->stream));
@@ -903,7 +967,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
     s->use_device();
     HIP_CHECK(hipStreamSynchronize(s->stream));
     HIP_CHECK(hipGetLastError());
-    lap("repack + upload (a thread per level)");
+    lap("one block per level, copies (a thread per level)");
     return s;
 }
 

@@ -616,6 +616,7 @@ def main():
                          "figure counts only if its final state equals the torch path's after the same sweeps — it has been rehearsed on one GPU only")
     ap.add_argument("--rank-graphs", action="store_true",
                     help="partitioned workload, library exchange: replay every rank's sweep from a captured hipGraph (MGCFD_OPT_GRAPH)")
+    ap.add_argument("--no-rank-graphs", action="store_true", help="N > 1: skip the leg that times the RCCL form's sweeps replayed from hipGraphs (`rank_graphs` in the line)")
     ap.add_argument("--no-group", action="store_true", help="N > 1: skip the in-process group leg (one process sweeping all N devices: `in_process_group` in the line)")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle leg (a rocprofv3 summary of the command then holds only the timed workload's launches)")
     ap.add_argument("--vcycle", action="store_true", help="(default now; kept so older command lines still parse)")
@@ -737,6 +738,7 @@ def main():
         part_mode = "torch"
         part_notes = []
         ipc_gave_up = False
+        library_passed = [False]                             # the buffered RCCL form reproduced the torch path's sweep at start-up
 
         def part_reset():
             """every rank back at the perturbed start state, ghosts current (whatever runs the loop)"""
@@ -810,6 +812,8 @@ def main():
                 if float(verdict[0].item()) != 1.0:
                     raise RuntimeError("the library's sweep differs from the torch path's on some rank" + (", or a wait for a neighbour's message gave up" if ipc_gave_up else ""))
                 step = lambda: solver.rank_sweeps(0, 1)
+                if mode == "library":
+                    library_passed[0] = True
                 info = solver.rank_halo_info(0)
                 exchange = (("libmgcfd_hip (mgcfd_rank_sweeps, HIP IPC): one launch per stage stores a rank's nodes into its neighbours' ghost slots and raises "
                              "their flags, the time-step all-reduce through the same flags"
@@ -862,6 +866,83 @@ def main():
             part_candidates.clear()
             part_candidates.extend(m for _, m in sorted(timed))
             part_next()
+
+        def rank_graphs_leg():
+            """Beside the timed form's figure, never as it: the RCCL form's sweeps captured once per buffer rotation and replayed
+            from hipGraphs (MGCFD_OPT_GRAPH = 1: one host call per sweep instead of ~25; 10 us of host time against 84 with the one
+            rank a one-GPU box offers, tools/hostcost_rccl.py).  ncclSend / ncclRecv inside a capture has never run between two
+            devices here, so the form is no candidate of the ladder: it runs after the line's figure is complete, under a guard
+            that prints that line, and counts only if (i) the library says sweeps really were replayed and (ii) the state after
+            seven sweeps — two passes through the three buffer rotations — equals the torch path's bit for bit on every rank."""
+            nonlocal part_mode
+            rec = {}
+            try:
+                def agree(what, fn):
+                    err = None
+                    try:
+                        res = fn()
+                    except Exception as e:
+                        res, err = None, e
+                    t = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    if float(t.item()) != 1.0:
+                        raise RuntimeError(f"{what} failed on some rank" + (f" (here: {err})" if err else ""))
+                    return res
+
+                def to_library_form():
+                    injected_failure("rank-graphs-setup", rank)
+                    solver.rank_ipc_detach(0)
+                    solver.set_option("rank_split", 1)
+                    solver.set_option("graph", 0)
+                agree("going back to the buffered RCCL form", to_library_form)
+                n_check = 7
+                part_mode = "torch"; part_reset()
+                for _ in range(n_check):
+                    sw.sweep()
+                torch.cuda.synchronize()
+                want = solver.get(0, "variables")
+                part_mode = "library"; part_reset()
+
+                def replayed():
+                    injected_failure("rank-graphs-sweeps", rank)
+                    solver.set_option("graph", 1)
+                    solver.rank_sweeps(0, n_check)
+                    torch.cuda.synchronize()
+                    return solver.get(0, "variables"), solver.rank_graph_status(0)
+                got, status = agree("the captured sweeps", replayed)
+                same = bool(np.array_equal(got.view(np.int64), want.view(np.int64)))
+                verdict = torch.tensor([1.0 if same else 0.0, 1.0 if (status["sweeps_replayed"] > 0 and not status["capture_refused"]) else 0.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+                rec["graph_status_rank0"] = status
+                if float(verdict[0].item()) != 1.0:
+                    raise RuntimeError(f"the state after {n_check} sweeps differs from the torch path's on some rank")
+                if float(verdict[1].item()) != 1.0:
+                    raise RuntimeError("a capture was refused on some rank (the sweeps ran call by call, with the right results): no replayed figure")
+                for _ in range(args.warmup):
+                    solver.rank_sweeps(0, 1)
+                torch.cuda.synchronize(); dist.barrier()
+                t0g = time.perf_counter()
+                for _ in range(args.steps):
+                    solver.rank_sweeps(0, 1)
+                t_host = time.perf_counter() - t0g
+                torch.cuda.synchronize(); dist.barrier()
+                tg = torch.tensor([time.perf_counter() - t0g, t_host], dtype=torch.float64, device=dev)
+                dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+                e = float(tg[0].item())
+                rec.update({"us_per_sweep": round(e / max(args.steps, 1) * 1e6, 3), "host_us_per_sweep": round(float(tg[1].item()) / max(args.steps, 1) * 1e6, 3),
+                            "medges_per_s": round(3 * int(L["n_internal"]) * args.steps / e / 1e6, 3), "steps": args.steps, "warmup": args.warmup,
+                            "graph_status_rank0": solver.rank_graph_status(0),
+                            "what": "mgcfd_rank_sweeps with MGCFD_OPT_GRAPH = 1: every sweep of an RCCL rank (boundary tiles, pack, grouped ncclSend / ncclRecv on a "
+                                    "second stream, interior tiles, unpack, the all-reduce of the time step) replayed from a hipGraph captured once per buffer "
+                                    f"rotation; the state after {n_check} sweeps equals the torch path's bit for bit on every rank; max over ranks, barriers on both sides"})
+            except Exception as e:
+                rec["error"] = f"{type(e).__name__}: {e}"
+            finally:
+                try:
+                    solver.set_option("graph", 0)
+                except Exception:
+                    pass
+            return rec
 
         ladder_guard = None
         if world == 1:
@@ -1155,6 +1236,11 @@ def main():
                                        "traffic": stage_traffic,
                                        "traffic_over_bytes_a_fused_stage_must_move": round(stage_traffic / (40 * n_int + 128 * nel), 3) if stage_traffic else None}
             out["roofline"] = roof
+    if workload == "partitioned" and world > 1 and not args.no_rank_graphs and not args.rank_graphs and (library_passed[0] or (rehearsal and injected("rank-graphs-rehearsal"))):
+        with leg_guard(float(os.environ.get("MGCFD_BENCH_LEG_S", "420")), rank, out, "rank_graphs", "the RCCL ranks' sweeps replayed from hipGraphs"):
+            graphs_rec = rank_graphs_leg()
+        if rank == 0:
+            out["rank_graphs"] = graphs_rec
     solver.close()
     if rank == 0 and world == 1 and workload == "level0" and args.mesh == "lattice" and lattice == LATTICE and not args.no_vcycle and "roofline" in out:
         out["roofline"]["mixed_mesh"] = mixed_mesh_roofline(make_solver, args.fast)

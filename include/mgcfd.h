@@ -421,6 +421,10 @@ int mgcfd_rank_halo_info(const mgcfd_solver *s, int level, int64_t out[4]);   /*
  * (0 none, 1 an RCCL communicator, 2 an in-process group, 3 plain attachment: HIP IPC messages only), out[3] the size the RCCL
  * communicator itself reports (ncclCommCount; -1 without one). */
 int mgcfd_rank_info(const mgcfd_solver *s, int out[4]);
+/* MGCFD_OPT_GRAPH = 1 on an RCCL rank (mgcfd_rank_sweeps): out[0] = sweep graphs instantiated for the level (0..3, one per
+ * buffer rotation), out[1] = 1 when a capture was refused — the sweeps then run call by call, with the same results —,
+ * out[2] = sweeps replayed from a graph so far.  A caller that times the replayed form asks before it believes the figure. */
+int mgcfd_rank_graph_status(const mgcfd_solver *s, int level, int64_t out[3]);
 int mgcfd_rank_exchange(mgcfd_solver *s, int level);          /* ghosts of `variables` <- owners (after mgcfd_set_array) */
 int mgcfd_rank_sweeps(mgcfd_solver *s, int level, int sweeps); /* the per-level body of the cycle loop, `sweeps` times; asynchronous */
 int mgcfd_rank_residual_sumsq(mgcfd_solver *s, int level, double *sum_all_ranks);

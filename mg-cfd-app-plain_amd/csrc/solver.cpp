@@ -116,6 +116,7 @@ struct HaloExchange {
     hipGraphExec_t sweep_graph[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [rotation (+ 3 x parity of the minima: in-process groups)]
     int64_t graph_iters[6][MGCFD_NUM_LOOPS] = {{0}};
     bool graph_failed = false;
+    int64_t sweeps_replayed = 0;          // ... launched from one of them so far (mgcfd_rank_graph_status)
     // in-process groups, direct mode: a rank's message is stored by ONE launch straight into its peers' ghost slots
     // (k_halo_push) — no message buffers, no second stream, no unpack; a stage's boundary tiles wait for the peers'
     // previous-stage events instead
@@ -3035,6 +3036,7 @@ int mgcfd_rank_sweeps(mgcfd_solver *s, int level, int sweeps)
                     lv.min_ahead = ahead_before;
                 }
                 HIP_CHECK(hipGraphLaunch(hx.sweep_graph[rot], s->stream));
+                hx.sweeps_replayed++;
                 after_replayed_sweep(s, level, hx.graph_iters[rot]);
             } else {
                 rank_sweep_once(s, level);
@@ -3647,6 +3649,18 @@ int mgcfd_rank_info(const mgcfd_solver *s, int out[4])
     const mgcfd_comm &c = it->second;
     out[0] = c.rank; out[1] = c.world; out[2] = c.rccl ? 1 : (c.group ? 2 : 3);
     if (c.rccl && g_rccl.CommCount) { int n = -1; if (g_rccl.CommCount(c.rccl, &n) == 0) out[3] = n; }
+    return MGCFD_OK;
+}
+
+int mgcfd_rank_graph_status(const mgcfd_solver *s, int level, int64_t out[3])
+{
+    REQUIRE(s); REQUIRE(out);
+    if (level < 0 || level >= static_cast<int>(s->L.size()) || !s->L[static_cast<size_t>(level)].hx) { g_last_error = "the level has no halo lists"; return MGCFD_ERR_ARG; }
+    const HaloExchange &hx = *s->L[static_cast<size_t>(level)].hx;
+    out[0] = 0;
+    for (hipGraphExec_t ge : hx.sweep_graph) if (ge) out[0]++;
+    out[1] = hx.graph_failed ? 1 : 0;
+    out[2] = hx.sweeps_replayed;
     return MGCFD_OK;
 }
 

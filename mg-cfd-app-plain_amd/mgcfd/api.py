@@ -139,6 +139,7 @@ _SIGNATURES = [
     ("mgcfd_rank_ipc_attach", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("mgcfd_rank_ipc_status", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mgcfd_rank_info", C.c_int, [_vp, C.POINTER(C.c_int)]),
+    ("mgcfd_rank_graph_status", C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
     ("mgcfd_group_cycles", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_rank_cycles", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     ("mgcfd_rank_ipc_detach", C.c_int, [_vp, C.c_int]),
@@ -565,6 +566,12 @@ class Solver:
         out = (_i64 * 4)()
         self._c(self.lib.mgcfd_rank_halo_info(self.handle, l, out))
         return dict(zip(("boundary_tiles", "interior_tiles", "nodes_sent", "nodes_received"), [int(v) for v in out]))
+
+    def rank_graph_status(self, l: int) -> dict:
+        """MGCFD_OPT_GRAPH on an RCCL rank: graphs instantiated, whether a capture was refused, sweeps replayed (mgcfd_rank_graph_status)."""
+        out = (_i64 * 3)()
+        self._c(self.lib.mgcfd_rank_graph_status(self.handle, l, out))
+        return {"graphs": int(out[0]), "capture_refused": bool(out[1]), "sweeps_replayed": int(out[2])}
 
     def rank_info(self) -> dict:
         """What this solver is a rank of, as the library sees it (mgcfd_rank_info)."""

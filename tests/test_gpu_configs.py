@@ -421,14 +421,15 @@ def test_bench_rehearsal_two_ranks_on_this_gpu():
 @pytest.mark.parametrize("fail,expect", [("attach", "the library's rank loop not used"), ("phase", "not used"),
                                          ("ipc-start", "differs from the torch path"), ("ipc-end", "discarded after the run"),
                                          ("vcycle-setup", "the library's cycle loop not used"), ("vcycle-cycles", "mgcfd_rank_cycles not used"),
-                                         ("group-setup", "injected failure (group-setup)"), ("group-end", "counts")])
+                                         ("group-setup", "injected failure (group-setup)"), ("group-end", "counts"),
+                                         ("rank-graphs-rehearsal", "Error"), ("rank-graphs-rehearsal,rank-graphs-setup", "going back to the buffered RCCL form failed on some rank")])
 def test_bench_form_ladder_survives_injected_failures(fail, expect):
     """What the first run on several GPUs will execute, with something breaking on ONE rank at every rung of bench.py's ladder
     (MGCFD_BENCH_FAIL, rehearsal: both ranks on this device over gloo): the library's rank set-up raising, its start-up sweep
     raising mid-phase, the IPC form failing its start-up check, the IPC form's final state failing its check; in the V-cycle leg
     the library's set-up raising and a rank finding something wrong just before mgcfd_rank_cycles (every rank must then stay out
     of that loop: round 3's advisor finding); in the in-process group leg its set-up raising and its final state failing the
-    check.  Every time the run must END — within the bound, never a stuck rank — with a valid line from a fall-back."""
+    check; the rank-graphs leg entered without an RCCL form, and with its set-up raising on one rank.  Every time the run must END — within the bound, never a stuck rank — with a valid line from a fall-back."""
     import json
     import os
     import subprocess
@@ -447,6 +448,12 @@ def test_bench_form_ladder_survives_injected_failures(fail, expect):
         vc = line["vcycle"]
         assert any(expect in n for n in vc["notes"]), vc["notes"]
         assert vc["wall_s_per_cycle"] > 0 and vc["state_valid"] and vc["form"].startswith("torch.distributed")
+        return
+    if fail.startswith("rank-graphs"):
+        # the leg that replays the RCCL form's sweeps from hipGraphs, entered although this rehearsal has no RCCL form (both ranks on
+        # one device): it must end with an error record on every rank at the same place and leave the line's figure alone
+        assert expect in line["rank_graphs"]["error"], line["rank_graphs"]
+        assert "us_per_sweep" not in line["rank_graphs"]
         return
     if fail.startswith("group"):
         g = line["in_process_group"]
@@ -671,6 +678,9 @@ def test_rccl_loads_and_a_one_rank_communicator_sweeps():
     s.rank_exchange(0)
     s.rank_sweeps(0, 7)
     _bits_equal(s.get(0, "variables"), ref.get(0, "variables"), "one-rank RCCL sweeps replayed from hipGraphs")
+    # (what bench.py's rank_graphs leg asks before it believes a replayed figure: graphs exist, none refused, sweeps really replayed)
+    st = s.rank_graph_status(0)
+    assert st["graphs"] == 3 and not st["capture_refused"] and st["sweeps_replayed"] >= 4, st
     assert s.loop_iters(0)["flux"] == ref.loop_iters(0)["flux"] + 3 * 3 * L["n_internal"]
     ref.close()
     s.rank_detach()

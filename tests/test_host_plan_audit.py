@@ -38,6 +38,24 @@ def test_every_plan_index_is_in_range(name):
     assert report == "", f"{name}:\n{report}"
 
 
+@pytest.mark.parametrize("tile_order", ["2", "1"])
+def test_levels_of_more_tiles_than_one_round_are_in_range_with_their_tiles_reordered(tile_order, monkeypatch):
+    """A level of more than 768 tiles has the cheapest tiles of every XCD's range moved to the range's end (preprocess.cpp,
+    "dispatch order of the tiles"; MGCFD_TILE_ORDER=1: the whole range by cost): the permutation must stay one — every node
+    once — and every index of the plan in range, on the mixed-element level (rows of 3 ... 14) and a partitioned lattice."""
+    from mgcfd.partition import partition_level, rcb_partition
+    monkeypatch.setenv("MGCFD_TILE_ORDER", tile_order)
+    mg = meshgen.make_mixed_multigrid((60,), "m6wing", seed=2, jitter=0.2, area_noise=0.02, volume_noise=0.02, permute=True)
+    levels = _levels(mg)
+    assert levels[0]["nel"] > 768 * 256
+    report = mgcfd.plan_audit(levels, mg.mesh_variant)
+    assert report == "", report
+    P = partition_level(levels[0], rcb_partition(np.asarray(levels[0]["coords"]), 1))[0]
+    cut = levels[0]["nel"] - 5000                          # (the last 5,000 nodes as ghosts: complete owned tiles only may move)
+    report = mgcfd.plan_audit([P.level], mg.mesh_variant, n_owned=[cut])
+    assert report == "", report
+
+
 def test_partitioned_levels_and_hierarchies_are_in_range():
     from mgcfd.partition import partition_hierarchy, partition_level, rcb_partition
     mg = meshgen.make_multigrid((14, 9), "m6wing", seed=2, cavity_radius=0.1, jitter=0.2, area_noise=0.05, volume_noise=0.05)

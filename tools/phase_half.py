@@ -30,7 +30,7 @@ def run():
     import bench, mgcfd
     variant = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     lattice = int(sys.argv[3]) if len(sys.argv) > 3 else 67
-    mg, levels = bench.build_workload(lattice)
+    mg, levels = bench.build_workload(lattice, mesh=os.environ.get("PH_MESH", "lattice"))       # PH_MESH=mixed: the non-uniform-degree level
     s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
     s.set(0, "variables", bench.perturbed_state(s.nel(0), s.far_field()[:5]))
     s.set_option("flux_variant", variant)

@@ -366,6 +366,16 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             }
             std::vector<int32_t> reordered(order);
             const int64_t q = n_tiles_all >> 3, r = n_tiles_all & 7;
+            if (std::getenv("MGCFD_VERBOSE")) {
+                int64_t f0 = 0;
+                for (int64_t x = 0; x < 8; x++) {
+                    const int64_t l0 = std::min(f0 + q + (x < r ? 1 : 0), n_perm);
+                    int64_t rows_sum = 0, halo_sum = 0;
+                    for (int64_t t = f0; t < l0; t++) { rows_sum += cost[static_cast<size_t>(t)] / 1024; halo_sum += cost[static_cast<size_t>(t)] % 1024; }
+                    std::fprintf(stderr, "[mgcfd] XCD %ld: tiles %ld..%ld, sum of longest rows %ld, sum of halo nodes %ld\n", (long)x, (long)f0, (long)l0, (long)rows_sum, (long)halo_sum);
+                    f0 += q + (x < r ? 1 : 0);
+                }
+            }
             const int64_t n_tail_of_a_range = std::max<int64_t>(0, (n_tiles_all - first_round + 7) / 8);
             int64_t first = 0;
             for (int64_t x = 0; x < 8; x++) {

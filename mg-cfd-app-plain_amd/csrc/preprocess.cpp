@@ -340,9 +340,9 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     // last decides when the launch ends.  So the cheapest tiles of every range — as many as do not fit the first round —
     // go to its end, the costliest of them first; every other tile keeps its place (neighbours in space stay neighbours in
     // time: their halos meet in the XCD's L2).  Cost: the longest row a lane of the tile walks, then the nodes it stages
-    // beside its own.  Measured on the 67^3 levels (flux launch): mixed-element 19.2 -> 18.2 us bit-identical and 14.9 -> 14.2
-    // order-free, lattice order-free 13.9 -> 13.6, the rest unchanged; sorting the WHOLE range by cost (tile_order = 1)
-    // gains the same there and costs the lattice's bit-identical stages 1 %.  Any order gives the same results.
+    // beside its own.  Measured on the 67^3 mixed-element level (flux launch): 19.2 -> 18.2 us bit-identical, 14.9 -> 14.2
+    // order-free; sorting the WHOLE range by cost (tile_order = 1) gains the same there and costs a lattice's bit-identical
+    // stages 1 %.  Any order gives the same results.
     if (opt.ordering == 2 && opt.tile_order != 0) {
         const int64_t n_tiles_all = (nel + kTile - 1) / kTile;
         const int64_t n_perm = n_owned / kTile;                          // complete tiles of owned nodes only
@@ -364,6 +364,13 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                 }
                 cost[static_cast<size_t>(t)] = int64_t(longest) * 1024 + halo;
             }
+            // (tiles that all walk rows of the same length — a lattice — differ by their halos only, and moving those costs
+            //  the later rounds of a large level more in locality than the tail gains: 84^3 and 96^3 lattices 1-2.5 % slower,
+            //  67^3 and 134^3 unchanged; such a level keeps its order)
+            const auto longest_of = [&](int64_t t) { return cost[static_cast<size_t>(t)] / 1024; };
+            int64_t lo = longest_of(0), hi = longest_of(0);
+            for (int64_t t = 1; t < n_perm; t++) { lo = std::min(lo, longest_of(t)); hi = std::max(hi, longest_of(t)); }
+            const bool rows_differ = hi >= lo + 2;
             std::vector<int32_t> reordered(order);
             const int64_t q = n_tiles_all >> 3, r = n_tiles_all & 7;
             if (std::getenv("MGCFD_VERBOSE")) {
@@ -376,7 +383,8 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                     f0 += q + (x < r ? 1 : 0);
                 }
             }
-            const int64_t n_tail_of_a_range = std::max<int64_t>(0, (n_tiles_all - first_round + 7) / 8);
+            // (never more than one round's share: in a launch of several rounds only the last one is the tail)
+            int64_t n_tail_of_a_range = std::min<int64_t>(std::max<int64_t>(0, (n_tiles_all - first_round + 7) / 8), first_round / 8);
             int64_t first = 0;
             for (int64_t x = 0; x < 8; x++) {
                 const int64_t last = std::min(first + q + (x < r ? 1 : 0), n_perm);
@@ -386,7 +394,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                     std::vector<int64_t> by_cost(ids);
                     std::stable_sort(by_cost.begin(), by_cost.end(), [&](int64_t a, int64_t b) { return cost[static_cast<size_t>(a)] > cost[static_cast<size_t>(b)]; });
                     if (opt.tile_order == 1) ids.swap(by_cost);
-                    else {
+                    else if (rows_differ || opt.tile_order == 3) {
                         const int64_t n_tail = std::min<int64_t>(last - first, n_tail_of_a_range);
                         std::vector<char> in_tail(static_cast<size_t>(last - first), 0);
                         for (int64_t k = (last - first) - n_tail; k < last - first; k++) in_tail[static_cast<size_t>(by_cost[static_cast<size_t>(k)] - first)] = 1;

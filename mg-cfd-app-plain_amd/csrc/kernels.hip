@@ -577,25 +577,35 @@ __device__ __forceinline__ void boundary_rows(const NodeQ &me, const FluxC &fm, 
 // TAIL: the level has long rows (TailPlan): the per-node loop stops at the tile's row limit and the workgroup
 // evaluates the remaining entries together (see below).
 // WMODE: 0 = the length factor k recomputed from the row's weights, 1 = k streamed with them, 2 = indexed weights (above).
-template <int MINW, int WMODE, bool FUSE, bool ACC, int ROLE, bool TAIL, bool PUSH = false>
-__global__ void __launch_bounds__(kBlock, MINW)
-k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at wave launch (Makefile:
-            // -amdgpu-kernarg-preload-count): what the first loads of the prologue need comes first
-            const double *__restrict__ q, const int32_t *__restrict__ tile_halo, uint32_t n_tiles, int32_t pad_row,
-            int64_t stride, int64_t nel, const int32_t *__restrict__ slice_row0,
-            const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
-            const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
-            const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
-            double *__restrict__ fluxes, int classes, FusedStep fs, TailPlan tp,
-            const uint16_t *__restrict__ gat16, const int32_t *__restrict__ te_chunk_ptr, const double *__restrict__ te_w3,
-            StagePush push /* PUSH instantiations only: the stage sends its own message (device_plan.hpp) */)
+// The workgroup's LDS: the staged records, the first stage's partial minima per wave, the last stage's per-wave sums
+// (559 records x 96 B + 32 + 64 B = 53,760 B = 42 of the 1,280-byte granules LDS is handed out in: three workgroups per CU).
+struct FluxTileLds {
+    double2 tile[kTileCap * kLdsRecD2];
+    double s_pm[kBlock / 64];
+    double s_next[2][kBlock / 64];
+};
+
+// The kernel's body as a function of the workgroup's position in the launch (`block`): k_flux_tile calls it with blockIdx.x
+// (tools/exp/sweep_flow.patch: a dataflow sweep calls it with the tile a workgroup has claimed).
+template <int WMODE, bool FUSE, bool ACC, int ROLE, bool TAIL, bool PUSH>
+__device__ __forceinline__ void
+flux_tile_body(FluxTileLds &lds, const unsigned block,
+               const double *__restrict__ q, const int32_t *__restrict__ tile_halo, uint32_t n_tiles, int32_t pad_row,
+               int64_t stride, int64_t nel, const int32_t *__restrict__ slice_row0,
+               const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
+               const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
+               const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, const FarField &ff,
+               double *__restrict__ fluxes, int classes, const FusedStep &fs, const TailPlan &tp,
+               const uint16_t *__restrict__ gat16, const int32_t *__restrict__ te_chunk_ptr, const double *__restrict__ te_w3,
+               const StagePush &push /* PUSH instantiations only: the stage sends its own message (device_plan.hpp) */,
+               const bool block_is_tile = false /* `block` IS the tile (tools/exp/sweep_flow.patch) */)
 {
     constexpr bool LOADK = WMODE == 1;
     static_assert(!PUSH || FUSE, "only a fused stage sends its message");
     PH_BEGIN();
     constexpr bool IDXW = WMODE == 2;
     static_assert(!(IDXW && TAIL), "indexed weights: levels without long rows only");
-    __shared__ double2 tile[kTileCap * kLdsRecD2];
+    double2 *const tile = lds.tile;
 
     // FUSE: this launch is a whole Runge-Kutta stage — the node's complete flux never leaves
     // registers; time_step (cfd_loops.cpp:241-268) is applied to it at the end and the new state
@@ -605,17 +615,17 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
     // are not on its dependent chain), the reduction happens after the records are staged and shares the staging
     // barrier, so none of it adds to the prologue's latency chain.
     constexpr int kPartPre = 6;                                           // partials per thread held in registers (1,536 tiles)
-    __shared__ double s_pm[kBlock / 64];
+    double *const s_pm = lds.s_pm;
     double pmv[kPartPre];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    unsigned t = xcd_contiguous_block(blockIdx.x, n_tiles);            // n_tiles == gridDim.x, without the hidden-argument load
+    unsigned t = block_is_tile ? block : xcd_contiguous_block(block, n_tiles);   // n_tiles == gridDim.x, without the hidden-argument load
     if (PUSH) {
         // boundary tiles in dispatch order first (their message leaves while the rest of the launch runs), the interior
         // tiles behind them in XCD-contiguous ranges
         const unsigned nb = unsigned(push.n_boundary);
-        t = blockIdx.x < nb ? blockIdx.x : nb + xcd_contiguous_block(blockIdx.x - nb, n_tiles - nb);
+        t = block < nb ? block : nb + xcd_contiguous_block(block - nb, n_tiles - nb);
     }
     if (FUSE && fs.tile_list) t = unsigned(fs.tile_list[t]);           // a launch over part of the level (uniform branch)
     const int64_t base = int64_t(t) * kTile;
@@ -969,7 +979,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             const Derived d = derive(rho, mx, my, mz, en);
             fs.next_legacy_sf[i] = 0.5 / (sqrt(fs.volumes[i]) * (d.speed + d.c));   // k_step_factor_legacy
         }
-        if (PUSH && blockIdx.x < unsigned(push.n_boundary)) {
+        if (PUSH && block < unsigned(push.n_boundary)) {
             // this node into the ghost slots of the neighbours that hold it
             for (int32_t e = push.send_ptr[i]; e < push.send_ptr[i + 1]; e++) {
                 const int k = push.send_peer[e];
@@ -982,7 +992,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
             }
         }
     }
-    if (PUSH && blockIdx.x < unsigned(push.n_boundary)) {              // (uniform per workgroup)
+    if (PUSH && block < unsigned(push.n_boundary)) {              // (uniform per workgroup)
         // as k_halo_push_flags: the stores acknowledged, the workgroup counted off, the last boundary tile raises the flags
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -999,7 +1009,7 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         }
     }
     if (ROLE == 3 || (ROLE >= 2 && ROLE <= 4 && fs.sumsq_partial)) {  // uniform: every thread of the workgroup takes part
-        __shared__ double s_next[2][kBlock / 64];
+        double (*const s_next)[kBlock / 64] = lds.s_next;
         if (ROLE == 3) sf_next = wave_min(sf_next);
         if (fs.sumsq_partial) ss = wave_sum(ss);
         if ((threadIdx.x & 63) == 0) { s_next[0][threadIdx.x >> 6] = sf_next; s_next[1][threadIdx.x >> 6] = ss; }
@@ -1012,6 +1022,24 @@ k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at 
         }
     }
     PH_MARK(3);
+}
+
+template <int MINW, int WMODE, bool FUSE, bool ACC, int ROLE, bool TAIL, bool PUSH = false>
+__global__ void __launch_bounds__(kBlock, MINW)
+k_flux_tile(// the first 16 dwords of the arguments are preloaded into SGPRs at wave launch (Makefile:
+            // -amdgpu-kernarg-preload-count): what the first loads of the prologue need comes first
+            const double *__restrict__ q, const int32_t *__restrict__ tile_halo, uint32_t n_tiles, int32_t pad_row,
+            int64_t stride, int64_t nel, const int32_t *__restrict__ slice_row0,
+            const int32_t *__restrict__ rows_int, const int32_t *__restrict__ rows_bnd,
+            const uint16_t *__restrict__ nbr16, const double *__restrict__ w,
+            const int32_t *__restrict__ tile_ovf_ptr, const int32_t *__restrict__ tile_ovf, FarField ff,
+            double *__restrict__ fluxes, int classes, FusedStep fs, TailPlan tp,
+            const uint16_t *__restrict__ gat16, const int32_t *__restrict__ te_chunk_ptr, const double *__restrict__ te_w3,
+            StagePush push)
+{
+    __shared__ FluxTileLds lds;
+    flux_tile_body<WMODE, FUSE, ACC, ROLE, TAIL, PUSH>(lds, blockIdx.x, q, tile_halo, n_tiles, pad_row, stride, nel, slice_row0, rows_int, rows_bnd, nbr16, w,
+                                                       tile_ovf_ptr, tile_ovf, ff, fluxes, classes, fs, tp, gat16, te_chunk_ptr, te_w3, push);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -447,6 +447,20 @@ struct mgcfd_solver {
                         const StagePush *push = nullptr)
     {
         DeviceLevel &lv = level(l);
+        const FusedStep fs = fused_step(l, j, out, apply_min, with_residual, old, look_ahead, sumsq, vin_flux, tile_list, n_list, min_list, n_min, lazy_residual);
+        Timed t(this, l, MGCFD_LOOP_FLUX, true);
+        if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv, true), &fs, push);
+        else fast::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv, true), &fs, push);
+        if (count_iters) {                          // (a stage launched in two parts counts once)
+            lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
+            lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
+        }
+    }
+    // the arguments of one fused stage (what op_fused_stage launches; tools/exp/sweep_flow.patch takes three of them for one launch)
+    FusedStep fused_step(int l, int j, double *out, int apply_min, bool with_residual, const double *old, bool look_ahead, bool sumsq,
+                         const double *vin_flux, const int32_t *tile_list, int32_t n_list, const double *min_list, int n_min, bool lazy_residual)
+    {
+        DeviceLevel &lv = level(l);
         settle_residuals(lv);                       // (a sweep that supersedes the residual has dropped the flag: smooth_once)
         FusedStep fs;
         fs.tile_list = tile_list;
@@ -472,13 +486,7 @@ struct mgcfd_solver {
         fs.err = err;
         if (vin_flux) fs.check_vin = next_check();       // the absorbed first stage's check_for_invalid_variables comes first
         fs.check = force_check >= 0 ? force_check : next_check();
-        Timed t(this, l, MGCFD_LOOP_FLUX, true);
-        if (opt_exact) exact::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv, true), &fs, push);
-        else fast::launch_flux(stream, lv.dp, in, ff, lv.fluxes, 7, 0, variant_for(lv, true), &fs, push);
-        if (count_iters) {                          // (a stage launched in two parts counts once)
-            lv.iters[MGCFD_LOOP_FLUX] += lv.info.n_internal;
-            lv.iters[MGCFD_LOOP_TIME_STEP] += lv.info.nel;
-        }
+        return fs;
     }
     void op_indirect_rw(int l)
     {
@@ -1333,10 +1341,10 @@ static void smooth_once(mgcfd_solver *s, int level)
             exact::launch_min_reduce(s->stream, lv.info.nel, lv.partial_min, lv.min_dt);
             apply = 2;
         }
+        const bool sumsq = lv.want_sumsq && lv.n_owned == lv.info.nel;
         mgcfd_solver::Timed group(s, level, MGCFD_LOOP_FLUX, true, s->opt_timing == 2 ? MGCFD_RK : 1);
         s->op_fused_stage(level, 0, start, b1, apply, false, start);
         s->op_fused_stage(level, 1, b1, b2, 0, false, start);
-        const bool sumsq = lv.want_sumsq && lv.n_owned == lv.info.nel;
         // residual (:508) = this stage's result - the sweep's start state.  On a single-level run nothing reads it before
         // the next sweep overwrites it, so the stage leaves the 40 B per node unwritten (its squares still go into the
         // RMS partials) and settle_residuals writes it if anybody asks: both operands stay where they are.

@@ -434,6 +434,49 @@ class leg_guard:
         self.timer.cancel()
 
 
+def two_launches_in_flight(solver, levels, mesh_variant, device, fast: bool):
+    """What the flux kernel does when the chip is kept full: batches of the standalone launch from TWO solvers on the same level at
+    once, each on its own stream from its own host thread — independent launches, which the hardware overlaps (one launch's tail and
+    boundary under the other's rows) — as wall time per launch over both batches.  Never the line's `roofline.frac` (that is ONE
+    launch after the other, as a sweep needs them); it separates what the kernel's code reaches from what the shape of a 1.15-1.5
+    round launch costs (tools/exp/two_streams.py, profiles/r4_dataflow.txt).  Leaves the solver's options as it found them."""
+    import threading
+    import mgcfd
+    out = {"what": "two independent batches of the standalone compute_flux_edge launch in flight at once (two solvers on the level, two streams, "
+                   "two host threads): wall time over both batches / launches of both; frac = 40 E + 80 N per launch against 8 TB/s.  What the "
+                   "kernel reaches when the chip is kept full — mesh copies, several meshes, ranks sharing a device — not a single sweep's figure"}
+    other = None
+    try:
+        other = mgcfd.Solver.from_arrays(levels, mesh_variant, device=device)            # (its own stream)
+        other.set(0, "variables", solver.get(0, "variables"))
+        pair = (solver, other)
+        modes = [("order_free", 0, 65)] if fast else [("bit_identical", 1, 1), ("order_free", 0, 65)]
+        for name, ex, var in modes:
+            if var == 65 and not solver.has_order_free(0):
+                continue
+            for s in pair:
+                s.set_option("exact", ex); s.set_option("flux_variant", var); s.bench_flux(0, ROOFLINE_LAUNCHES // 2)
+            best = None
+            for _ in range(3):
+                th = [threading.Thread(target=s.bench_flux, args=(0, ROOFLINE_LAUNCHES)) for s in pair]
+                t0 = time.perf_counter()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                dt = (time.perf_counter() - t0) / (2 * ROOFLINE_LAUNCHES)
+                best = dt if best is None else min(best, dt)
+            out[name] = {"us_per_launch": round(best * 1e6, 3), "launches": 2 * ROOFLINE_LAUNCHES}
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        if other is not None:
+            other.close()
+        solver.set_option("exact", 0 if fast else 1)
+        solver.set_option("flux_variant", -1)
+    return out
+
+
 def in_process_group_leg(args, world, lattice, level_built, sizes, hierarchy_built, share_device: bool, steps: int, warmup: int, cycles: int = 25):
     """The form `euler3d_gpu_double --gpus N` runs, timed from ONE process: a solver per device as the ranks of an
     in-process group (mgcfd_group_*: a host thread per rank issues that rank's launches, a stage's message is one launch that
@@ -1045,7 +1088,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    flux_only = probe = stream_ceiling = None
+    flux_only = probe = stream_ceiling = two_in_flight = None
     if workload in ("level0", "copies"):
         # the standalone compute_flux_edge kernel (writes fluxes[]), 50 back-to-back launches between one hipEvent pair
         # on the same stream, and the data-movement probe on the same tiles (indirect_rw: same loads and stores, the
@@ -1054,6 +1097,10 @@ def main():
         # MI355X that has been idle takes tens of milliseconds of load before its clocks are up — the first 20 sweeps after an
         # idle period run at 66-72 us each, the same 20 sweeps after 30 ms of load at 61.5 (tools/exp/first_steps.py); the
         # driver's default of 5 warm-up steps is 0.3 ms.  The line says so in "preheat".
+        # (first of all — it builds and frees a second solver, half a second of idle device — what the kernel does with two
+        #  independent launches in flight: roofline.two_launches_in_flight)
+        if workload == "level0" and world == 1 and args.variant == -1 and os.environ.get("MGCFD_BENCH_NO_TWO_IN_FLIGHT") != "1":
+            two_in_flight = two_launches_in_flight(solver, levels, mg.mesh_variant, local_rank, args.fast)
         solver.bench_flux(0, 2 * ROOFLINE_LAUNCHES)             # (untimed: the ramp itself)
         flux_only = solver.bench_flux(0, ROOFLINE_LAUNCHES)
         flux_contracted = flux_free = None
@@ -1196,6 +1243,11 @@ def main():
                                              f"{ROOFLINE_LAUNCHES} back-to-back launches between one hipEvent pair, launch boundary included (mgcfd_bench_stream_ceiling)")
                 roof["practical_ceiling_frac"] = round(bytes_flux / stream_ceiling / 1e9 / HBM_PEAK_GBS, 4)
                 roof["flux_over_practical_ceiling"] = round(flux_only / stream_ceiling, 3)
+            if two_in_flight:
+                for rec in two_in_flight.values():
+                    if isinstance(rec, dict) and rec.get("us_per_launch"):
+                        rec["frac"] = round(bytes_flux / (rec["us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                roof["two_launches_in_flight"] = two_in_flight
             if probe:
                 roof["empirical_ceiling_us"] = round(probe * 1e6, 3)
                 roof["empirical_ceiling"] = "indirect_rw through the same tiles (same loads and stores, the reference's trivial arithmetic; src/Kernels/indirect_rw_loop.cpp:8-10)"

@@ -377,6 +377,12 @@ def test_bench_line_at_the_drivers_arguments():
     assert roof["traffic"] is None or abs(roof["traffic_over_algorithmic"] - roof["traffic"] / roof["algorithmic_bytes_per_launch"]) < 1e-3
     # the practical ceiling: a tile-shaped stream of exactly the algorithmic bytes, faster than the kernel and slower than the chip's peak
     assert 7.45 < roof["practical_ceiling_us"] < roof["avg_kernel_us"] and abs(roof["flux_over_practical_ceiling"] - roof["avg_kernel_us"] / roof["practical_ceiling_us"]) < 2e-3
+    # two independent batches of the launch in flight at once: what the kernel reaches when the chip is kept full — beside the
+    # line's figure (one launch after the other), never as it; faster per launch than one batch alone, and within the peak
+    two = roof["two_launches_in_flight"]
+    assert "error" not in two, two
+    for name in ("bit_identical", "order_free"):
+        assert 7.45 < two[name]["us_per_launch"] < roof["avg_kernel_us"] and abs(two[name]["frac"] - roof["algorithmic_bytes_per_launch"] / (two[name]["us_per_launch"] * 1e-6) / 8e12) < 2e-3, two
     # (FMA contraction allowed: the same launch, a little faster, reported beside the bit-identical figure)
     assert 10.0 < roof["fma_contracted"]["avg_kernel_us"] < 1.05 * roof["avg_kernel_us"] and "1e-12" in roof["fma_contracted"]["numerics"]
     assert 0.0002 < d["vcycle"]["wall_s_per_cycle"] < 0.001

@@ -26,3 +26,23 @@ def both():
     return (time.perf_counter() - t0) / n
 b = min(both() for _ in range(3))
 print(f"{'fast' if fast else 'bit-identical'}: one solver {a * 1e6:.2f} us per sweep; two solvers at once {b * 1e6:.2f} us per pair of sweeps = {b / 2 * 1e6:.2f} us per sweep ({2 * a / b:.3f} x two in a row)")
+# ... and the standalone compute_flux_edge launch (what roofline.frac prices): one solver's batch of launches alone, two solvers'
+# batches at once on two streams; bytes = 40 E + 80 N per launch
+algo = 40 * solvers[0].num_internal_edges(0) + 80 * solvers[0].nel(0)
+for name, ex, var in (("bit-identical", 1, 1), ("order-free", 0, 65)):
+    for s in solvers:
+        s.set_option("exact", ex); s.set_option("flux_variant", var); s.bench_flux(0, 500)
+    one = min(solvers[0].bench_flux(0, 1000) for _ in range(3))
+    out = [0.0, 0.0]
+    def run(k):
+        out[k] = solvers[k].bench_flux(0, 1000)
+    best = 1e9
+    for _ in range(3):
+        th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        best = min(best, (time.perf_counter() - t0) / 2000)
+    print(f"flux launch, {name}: alone {one * 1e6:.2f} us = {algo / one / 8e12:.3f} of 8 TB/s; two batches at once: {best * 1e6:.2f} us per launch (wall / 2,000 launches) = {algo / best / 8e12:.3f}; "
+          f"each batch's own event time {out[0] * 1e6:.2f} / {out[1] * 1e6:.2f} us per launch")
+

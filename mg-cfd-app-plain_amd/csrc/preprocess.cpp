@@ -274,6 +274,24 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
     };
     const int64_t nel = L.nel;
     if (nel <= 0 || nel >= (int64_t(1) << 29)) throw std::runtime_error("level size out of range for 29-bit node ids");
+    // host threads for the parts of the plan that are independent per node or per tile (the result never depends on their number)
+    int plan_threads = opt.threads > 0 ? opt.threads : int(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())));
+    plan_threads = std::max<int>(1, std::min<int64_t>(plan_threads, nel / (64 * kTile)));
+    if (const char *o = std::getenv("MGCFD_PLAN_THREADS")) plan_threads = std::max<int>(1, std::min<int64_t>(std::atoi(o), std::max<int64_t>(1, nel / kTile)));
+    auto over_ranges = [&](int64_t n, int64_t granule, auto &&body) {        // body(begin, end) on [0, n) cut at multiples of `granule`
+        const int64_t units = (n + granule - 1) / granule;
+        const int k_max = static_cast<int>(std::min<int64_t>(plan_threads, std::max<int64_t>(1, units)));
+        std::vector<std::exception_ptr> errors(static_cast<size_t>(k_max));
+        auto guarded = [&](int k) {
+            try { body(std::min(n, units * k / k_max * granule), std::min(n, units * (k + 1) / k_max * granule)); }
+            catch (...) { errors[static_cast<size_t>(k)] = std::current_exception(); }
+        };
+        std::vector<std::thread> workers;
+        for (int k = 1; k < k_max; k++) workers.emplace_back(guarded, k);
+        guarded(0);
+        for (std::thread &w : workers) w.join();
+        for (const std::exception_ptr &e : errors) if (e) std::rethrow_exception(e);
+    };
     for (int64_t e = L.internal_start; e < L.internal_start + L.n_internal; e++)
         if (edges[e].a < 0 || edges[e].a >= nel || edges[e].b < 0 || edges[e].b >= nel)
             throw std::runtime_error("internal edge " + std::to_string(e) + " has an end point outside [0, nel)");
@@ -348,29 +366,35 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         const int64_t n_perm = n_owned / kTile;                          // complete tiles of owned nodes only
         const int64_t first_round = 768;
         if (n_perm > 8 && (opt.tile_order == 1 || n_tiles_all > first_round)) {
-            std::vector<int32_t> tile_of(static_cast<size_t>(nel));
-            for (int64_t n = 0; n < nel; n++) tile_of[static_cast<size_t>(order[static_cast<size_t>(n)])] = static_cast<int32_t>(n / kTile);
             std::vector<int64_t> cost(static_cast<size_t>(n_perm), 0);
-            std::vector<int32_t> seen(static_cast<size_t>(nel), -1);
+            int64_t lo_rows = std::numeric_limits<int64_t>::max(), hi_rows = 0;
             for (int64_t t = 0; t < n_perm; t++) {
-                int32_t longest = 0, halo = 0;
-                for (int64_t n = t * kTile; n < (t + 1) * kTile; n++) {
-                    const int32_t v = order[static_cast<size_t>(n)];
-                    longest = std::max(longest, rows_of(v));
-                    for (int32_t k = g.ptr[static_cast<size_t>(v)]; k < g.ptr[static_cast<size_t>(v) + 1]; k++) {
-                        const int32_t w = g.idx[static_cast<size_t>(k)];
-                        if (tile_of[static_cast<size_t>(w)] != t && seen[static_cast<size_t>(w)] != t) { seen[static_cast<size_t>(w)] = static_cast<int32_t>(t); halo++; }
+                int32_t longest = 0;
+                for (int64_t n = t * kTile; n < (t + 1) * kTile; n++) longest = std::max(longest, rows_of(order[static_cast<size_t>(n)]));
+                cost[static_cast<size_t>(t)] = int64_t(longest) * 1024;
+                lo_rows = std::min<int64_t>(lo_rows, longest); hi_rows = std::max<int64_t>(hi_rows, longest);
+            }
+            // (the halos — a walk over every edge — only where an order will be made of them)
+            if (opt.tile_order == 1 || opt.tile_order == 3 || hi_rows >= lo_rows + 2 || std::getenv("MGCFD_VERBOSE")) {
+                std::vector<int32_t> tile_of(static_cast<size_t>(nel));
+                for (int64_t n = 0; n < nel; n++) tile_of[static_cast<size_t>(order[static_cast<size_t>(n)])] = static_cast<int32_t>(n / kTile);
+                std::vector<int32_t> seen(static_cast<size_t>(nel), -1);
+                for (int64_t t = 0; t < n_perm; t++) {
+                    int32_t halo = 0;
+                    for (int64_t n = t * kTile; n < (t + 1) * kTile; n++) {
+                        const int32_t v = order[static_cast<size_t>(n)];
+                        for (int32_t k = g.ptr[static_cast<size_t>(v)]; k < g.ptr[static_cast<size_t>(v) + 1]; k++) {
+                            const int32_t w = g.idx[static_cast<size_t>(k)];
+                            if (tile_of[static_cast<size_t>(w)] != t && seen[static_cast<size_t>(w)] != t) { seen[static_cast<size_t>(w)] = static_cast<int32_t>(t); halo++; }
+                        }
                     }
+                    cost[static_cast<size_t>(t)] += halo;
                 }
-                cost[static_cast<size_t>(t)] = int64_t(longest) * 1024 + halo;
             }
             // (tiles that all walk rows of the same length — a lattice — differ by their halos only, and moving those costs
             //  the later rounds of a large level more in locality than the tail gains: 84^3 and 96^3 lattices 1-2.5 % slower,
             //  67^3 and 134^3 unchanged; such a level keeps its order)
-            const auto longest_of = [&](int64_t t) { return cost[static_cast<size_t>(t)] / 1024; };
-            int64_t lo = longest_of(0), hi = longest_of(0);
-            for (int64_t t = 1; t < n_perm; t++) { lo = std::min(lo, longest_of(t)); hi = std::max(hi, longest_of(t)); }
-            const bool rows_differ = hi >= lo + 2;
+            const bool rows_differ = hi_rows >= lo_rows + 2;
             std::vector<int32_t> reordered(order);
             const int64_t q = n_tiles_all >> 3, r = n_tiles_all & 7;
             if (std::getenv("MGCFD_VERBOSE")) {
@@ -469,7 +493,8 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                 }
         }
         const int64_t W = kTile;
-        for (int64_t s = 0; s < nel; s += W) {
+        over_ranges(nel, W, [&](int64_t s_begin, int64_t s_end) {
+        for (int64_t s = s_begin; s < s_end; s += W) {
             auto b = order.begin() + s, e = order.begin() + std::min(nel, s + W);
             std::stable_sort(b, e, [&](int32_t x, int32_t y) {
                 if (owned(x) != owned(y)) return owned(x);                    // (the tile where the ghosts begin: owned nodes first)
@@ -480,6 +505,7 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
                 return cut_count[static_cast<size_t>(x)] > cut_count[static_cast<size_t>(y)];
             });
         }
+        });
     }
     lap("degree / facing sort");
     P.old_of_new = order;
@@ -513,28 +539,37 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
         const int32_t s = node_new / kSlice, lane = node_new % kSlice;
         return (static_cast<int64_t>(P.slice_row0[static_cast<size_t>(s)]) + row_in_slice) * kSlice + lane;
     };
-    int64_t useful = 0;
-    for (int64_t e = L.internal_start; e < L.internal_start + L.n_internal; e++) {
-        const mgcfd_edge &E = edges[static_cast<size_t>(e)];
-        const int32_t a = P.new_of_old[static_cast<size_t>(E.a)], b = P.new_of_old[static_cast<size_t>(E.b)];
-        const double ewt = std::sqrt(E.x * E.x + E.y * E.y + E.z * E.z);      // flux_kernel.elemfunc.c:27
-        const double k = -ewt * kSmoothing * 0.5;                              // prefix of :130
-        const double fx = -0.5 * E.x, fy = -0.5 * E.y, fz = -0.5 * E.z;       // :138-140
-        if (owned(E.a)) {
-            int64_t ia = entry_index(a, fill_int[static_cast<size_t>(a)]++);
-            P.nbr[static_cast<size_t>(ia)] = b;                                // this node is 'a'
-            entry_edge[static_cast<size_t>(ia)] = static_cast<int32_t>(e - L.internal_start);
-            P.w[static_cast<size_t>(ia)] = EdgeW{fx, fy, fz, k};
-            useful++;
+    // (every host thread walks ALL edges in order and fills the rows of the nodes in its own range of new ids: a node's entries
+    //  keep the edge order whatever the number of threads, and a thread's writes stay in its own part of the arrays)
+    std::atomic<int64_t> useful_total{0};
+    over_ranges(nel, kTile, [&](int64_t n_begin, int64_t n_end) {
+        int64_t useful_here = 0;
+        for (int64_t e = L.internal_start; e < L.internal_start + L.n_internal; e++) {
+            const mgcfd_edge &E = edges[static_cast<size_t>(e)];
+            const int32_t a = P.new_of_old[static_cast<size_t>(E.a)], b = P.new_of_old[static_cast<size_t>(E.b)];
+            const bool mine_a = a >= n_begin && a < n_end && owned(E.a), mine_b = b >= n_begin && b < n_end && owned(E.b);
+            if (!mine_a && !mine_b) continue;
+            const double ewt = std::sqrt(E.x * E.x + E.y * E.y + E.z * E.z);      // flux_kernel.elemfunc.c:27
+            const double k = -ewt * kSmoothing * 0.5;                              // prefix of :130
+            const double fx = -0.5 * E.x, fy = -0.5 * E.y, fz = -0.5 * E.z;       // :138-140
+            if (mine_a) {
+                int64_t ia = entry_index(a, fill_int[static_cast<size_t>(a)]++);
+                P.nbr[static_cast<size_t>(ia)] = b;                                // this node is 'a'
+                entry_edge[static_cast<size_t>(ia)] = static_cast<int32_t>(e - L.internal_start);
+                P.w[static_cast<size_t>(ia)] = EdgeW{fx, fy, fz, k};
+                useful_here++;
+            }
+            if (mine_b) {
+                int64_t ib = entry_index(b, fill_int[static_cast<size_t>(b)]++);
+                P.nbr[static_cast<size_t>(ib)] = a | kRoleB;                       // this node is 'b'
+                entry_edge[static_cast<size_t>(ib)] = static_cast<int32_t>(e - L.internal_start);
+                P.w[static_cast<size_t>(ib)] = EdgeW{-fx, -fy, -fz, k};            // x - f*y == x + (-f)*y exactly
+                useful_here++;
+            }
         }
-        if (owned(E.b)) {
-            int64_t ib = entry_index(b, fill_int[static_cast<size_t>(b)]++);
-            P.nbr[static_cast<size_t>(ib)] = a | kRoleB;                       // this node is 'b'
-            entry_edge[static_cast<size_t>(ib)] = static_cast<int32_t>(e - L.internal_start);
-            P.w[static_cast<size_t>(ib)] = EdgeW{-fx, -fy, -fz, k};            // x - f*y == x + (-f)*y exactly
-            useful++;
-        }
-    }
+        useful_total += useful_here;
+    });
+    int64_t useful = useful_total.load();
     auto add_face = [&](const mgcfd_edge &E, int32_t code, double scale) {
         if (!owned(E.b)) return;
         const int32_t b = P.new_of_old[static_cast<size_t>(E.b)];

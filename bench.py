@@ -457,13 +457,22 @@ def two_launches_in_flight(solver, levels, mesh_variant, device, fast: bool):
             for s in pair:
                 s.set_option("exact", ex); s.set_option("flux_variant", var); s.bench_flux(0, ROOFLINE_LAUNCHES // 2)
             best = None
+            failed = []
+
+            def batch(s):
+                try:
+                    s.bench_flux(0, ROOFLINE_LAUNCHES)
+                except Exception as e:                           # (a thread's exception would otherwise only be printed)
+                    failed.append(e)
             for _ in range(3):
-                th = [threading.Thread(target=s.bench_flux, args=(0, ROOFLINE_LAUNCHES)) for s in pair]
+                th = [threading.Thread(target=batch, args=(s,)) for s in pair]
                 t0 = time.perf_counter()
                 for t in th:
                     t.start()
                 for t in th:
                     t.join()
+                if failed:
+                    raise failed[0]
                 dt = (time.perf_counter() - t0) / (2 * ROOFLINE_LAUNCHES)
                 best = dt if best is None else min(best, dt)
             out[name] = {"us_per_launch": round(best * 1e6, 3), "launches": 2 * ROOFLINE_LAUNCHES}

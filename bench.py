@@ -66,6 +66,7 @@ HIERARCHY = (67, 55, 48, 43) # 300,763 / 166,375 / 110,592 
 HIERARCHY_8X = (134, 110, 96, 86)   # the same hierarchy tiled 8x (connected): 2,406,104 / 1,331,000 / 884,736 / 636,056 nodes
 TRAFFIC_PROFILE = os.path.join("profiles", "r4_traffic.json")
 ROOFLINE_LAUNCHES = 1000     # back-to-back launches of the standalone flux kernel / of its data-movement probe per measurement
+PREHEAT_SWEEPS = 1000           # untimed sweeps in front of a short timed region (see main)
 
 
 def build_workload(lattice: int, seed: int = 0, mesh: str = "lattice"):
@@ -1098,6 +1099,7 @@ def main():
         torch.cuda.synchronize()
 
     flux_only = probe = stream_ceiling = two_in_flight = None
+    preheat_sweeps = 0
     if workload in ("level0", "copies"):
         # the standalone compute_flux_edge kernel (writes fluxes[]), 50 back-to-back launches between one hipEvent pair
         # on the same stream, and the data-movement probe on the same tiles (indirect_rw: same loads and stores, the
@@ -1133,6 +1135,13 @@ def main():
         # ... and a tile-shaped STREAM of exactly the algorithmic bytes (one workgroup per tile, nothing dependent, nothing computed)
         stream_ceiling = solver.bench_stream_ceiling(0, ROOFLINE_LAUNCHES)
         solver.zero_fluxes(0)                                   # (the sweeps start from zero fluxes, as after any time_step)
+        # A short timed region (the driver's 20 steps are 1.1 ms) would otherwise run before the device has settled under THIS
+        # kernel: after the flux launches above the first few hundred sweeps still take 57.6-60 us against 55.2 in the steady state
+        # (same box, --steps 20 ... 400 against 2,000).  So, when fewer than 1,000 steps are timed, 1,000 sweeps of the workload itself
+        # (55 ms) run untimed in front of the W warm-up steps; the timed steps are the same operations on a later state.
+        if workload == "level0" and world == 1 and args.steps < 1000 and os.environ.get("MGCFD_BENCH_NO_PREHEAT_SWEEPS") != "1":
+            solver.smooth(0, PREHEAT_SWEEPS)
+            preheat_sweeps = PREHEAT_SWEEPS
     while True:
         for _ in range(args.warmup):
             step()
@@ -1242,7 +1251,9 @@ def main():
                     "algorithmic_bytes": "40 B per internal edge + 80 B per node (SURVEY.md §8d)",
                     "medges_per_s": round(n_int / flux_only / 1e6, 1) if flux_only > 0 else None}
             roof["preheat"] = (f"the {(3 if args.fast else (7 if flux_free else 5)) * ROOFLINE_LAUNCHES} flux + {ROOFLINE_LAUNCHES} probe launches above ({2 if args.fast else (4 if flux_free else 3)} x {ROOFLINE_LAUNCHES} of them untimed) ran BEFORE the warm-up and timed steps "
-                               "(an idle MI355X needs ~30 ms of load before its clocks are up: tools/exp/first_steps.py)")
+                               "(an idle MI355X needs ~30 ms of load before its clocks are up: tools/exp/first_steps.py)"
+                               + (f"; then {preheat_sweeps} untimed sweeps of the workload itself in front of the {args.warmup} warm-up steps "
+                                  "(fewer than 1,000 timed steps: the device settles under the stage kernel over tens of milliseconds)" if preheat_sweeps else ""))
             if roof["traffic"]:
                 roof["traffic_over_algorithmic"] = round(roof["traffic"] / bytes_flux, 3)
             if stream_ceiling:

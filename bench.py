@@ -477,6 +477,35 @@ def two_launches_in_flight(solver, levels, mesh_variant, device, fast: bool):
                 dt = (time.perf_counter() - t0) / (2 * ROOFLINE_LAUNCHES)
                 best = dt if best is None else min(best, dt)
             out[name] = {"us_per_launch": round(best * 1e6, 3), "launches": 2 * ROOFLINE_LAUNCHES}
+        # ... and whole sweeps (three fused stage launches each) of the mode the line is quoted in: one solver alone, both at once
+        n_sw = 500
+        for s in pair:
+            s.set_option("exact", 0 if fast else 1); s.set_option("flux_variant", -1)
+            s.zero_fluxes(0); s.smooth(0, 100); s.synchronize()
+        t0 = time.perf_counter(); solver.smooth(0, n_sw); solver.synchronize(); alone = (time.perf_counter() - t0) / n_sw
+
+        def sweeps(s):
+            try:
+                s.smooth(0, n_sw); s.synchronize()
+            except Exception as e:
+                failed.append(e)
+        failed = []
+        best = None
+        for _ in range(2):
+            th = [threading.Thread(target=sweeps, args=(s,)) for s in pair]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if failed:
+                raise failed[0]
+            dt = (time.perf_counter() - t0) / (2 * n_sw)
+            best = dt if best is None else min(best, dt)
+        out["sweeps"] = {"us_per_sweep_one_solver": round(alone * 1e6, 3), "us_per_sweep_two_at_once": round(best * 1e6, 3),
+                         "gain": round(alone / best, 3), "sweeps": 2 * n_sw,
+                         "what": "two solvers sweeping the level at once (wall over both / sweeps of both) against one alone: what independent "
+                                 "sweeps — mesh copies, several meshes — gain from filling each other's launch boundaries and tails"}
     except Exception as e:
         out["error"] = f"{type(e).__name__}: {e}"
     finally:

@@ -381,6 +381,7 @@ def test_bench_line_at_the_drivers_arguments():
     # line's figure (one launch after the other), never as it; faster per launch than one batch alone, and within the peak
     two = roof["two_launches_in_flight"]
     assert "error" not in two, two
+    assert two["sweeps"]["us_per_sweep_two_at_once"] < two["sweeps"]["us_per_sweep_one_solver"] and two["sweeps"]["gain"] > 1.05, two["sweeps"]
     for name in ("bit_identical", "order_free"):
         assert 7.45 < two[name]["us_per_launch"] < roof["avg_kernel_us"] and abs(two[name]["frac"] - roof["algorithmic_bytes_per_launch"] / (two[name]["us_per_launch"] * 1e-6) / 8e12) < 2e-3, two
     # (FMA contraction allowed: the same launch, a little faster, reported beside the bit-identical figure)

@@ -386,10 +386,16 @@ __device__ __forceinline__ EdgeRow load_row(const uint16_t *__restrict__ nbr, co
                                             int64_t row, int lane)
 {
     EdgeRow e;
-    e.code = nbr[(row << 6) + lane];
     const double *wr = w + (row << 8) + lane;
+#ifdef MGCFD_EXP_ROW_LD_NT          // (experiment: the rows are read once — streamed past the L2 so that the state stays in it)
+    e.code = __builtin_nontemporal_load(nbr + (row << 6) + lane);
+    e.fx = __builtin_nontemporal_load(wr); e.fy = __builtin_nontemporal_load(wr + 64); e.fz = __builtin_nontemporal_load(wr + 128);
+    e.k = LOADK ? __builtin_nontemporal_load(wr + 192) : 0.0;
+#else
+    e.code = nbr[(row << 6) + lane];
     e.fx = wr[0]; e.fy = wr[64]; e.fz = wr[128];
     e.k = LOADK ? wr[192] : 0.0;
+#endif
     return e;
 }
 

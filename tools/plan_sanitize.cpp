@@ -50,6 +50,7 @@ int main(int argc, char **argv)
     LevelPlan PF, PC; PlanOptions opt;
     for (int order = 0; order < 4; order++) {
         opt.tile_order = order;
+        opt.tile_curve = order % 3;                      // (as clustered, Morton, Hilbert)
         PF = LevelPlan(); PC = LevelPlan();
         build_level_plan(F.d, F.edges, opt, PF);
         build_level_plan(C.d, C.edges, opt, PC);

@@ -761,6 +761,21 @@ static std::unique_ptr<mgcfd_solver> build_solver(const mgcfd_level_desc *levels
             std::fprintf(stderr, "[mgcfd] level %d: half rows %s: %ld evaluations (%.2f per node), %ld in another node's lane, %ld padding slots (%.1f%%)\n", l, lv.plan.half ? "yes" : "no",
                          (long)lv.plan.hr_entries, double(lv.plan.hr_entries) / double(d.nel), (long)lv.plan.hr_foreign, (long)lv.plan.hr_padding,
                          lv.plan.hr_entries ? 100.0 * double(lv.plan.hr_padding) / double(lv.plan.hr_entries) : 0.0);
+        if (std::getenv("MGCFD_VERBOSE")) {
+            // how many staged halo nodes belong to a tile of ANOTHER XCD's range (their state cannot meet its owner's in an L2)
+            const int64_t nt = lv.plan.n_tiles, q8 = nt >> 3, r8 = nt & 7;
+            auto xcd_of = [&](int64_t t) { return t < r8 * (q8 + 1) ? t / (q8 + 1) : r8 + (t - r8 * (q8 + 1)) / std::max<int64_t>(q8, 1); };
+            int64_t total = 0, foreign = 0, near_ = 0;
+            for (int64_t t = 0; t < nt; t++)
+                for (int32_t k = lv.plan.tile_halo_ptr[static_cast<size_t>(t)]; k < lv.plan.tile_halo_ptr[static_cast<size_t>(t) + 1]; k++) {
+                    const int64_t o = lv.plan.tile_halo[static_cast<size_t>(k)] / kTile;
+                    total++;
+                    if (xcd_of(o) != xcd_of(t)) foreign++;
+                    else if (std::llabs(o - t) <= 48) near_++;
+                }
+            std::fprintf(stderr, "[mgcfd] level %d: staged halo nodes %ld: %.1f%% owned by a tile of another XCD's range, %.1f%% by a tile within 48 of the reader in its own range\n",
+                         l, (long)total, total ? 100.0 * foreign / total : 0.0, total ? 100.0 * near_ / total : 0.0);
+        }
         if (std::getenv("MGCFD_VERBOSE") && lv.plan.has_tail) {
             int64_t rows_full = 0, rows_cut = 0;
             for (size_t q = 0; q < lv.plan.rows_int.size(); q++) { rows_full += lv.plan.rows_int[q]; rows_cut += lv.plan.rows_main[q]; }

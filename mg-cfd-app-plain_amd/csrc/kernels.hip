@@ -391,6 +391,12 @@ __device__ __forceinline__ EdgeRow load_row(const uint16_t *__restrict__ nbr, co
     e.code = __builtin_nontemporal_load(nbr + (row << 6) + lane);
     e.fx = __builtin_nontemporal_load(wr); e.fy = __builtin_nontemporal_load(wr + 64); e.fz = __builtin_nontemporal_load(wr + 128);
     e.k = LOADK ? __builtin_nontemporal_load(wr + 192) : 0.0;
+#elif defined(MGCFD_EXP_ROW_LD_SC1)  // (experiment: agent-scope loads of the weights — past the XCD's L2, from the memory-side cache)
+    e.code = nbr[(row << 6) + lane];
+    e.fx = __hip_atomic_load(wr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    e.fy = __hip_atomic_load(wr + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    e.fz = __hip_atomic_load(wr + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    e.k = LOADK ? __hip_atomic_load(wr + 192, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #else
     e.code = nbr[(row << 6) + lane];
     e.fx = wr[0]; e.fy = wr[64]; e.fz = wr[128];

@@ -384,7 +384,9 @@ void build_level_plan(const mgcfd_level_desc &L, const std::vector<mgcfd_edge> &
             for (int64_t t = 0; t < n_perm; t++) {
                 uint32_t X[3];
                 for (int d = 0; d < 3; d++) {
-                    const double f = hi[d] > lo[d] ? (c[static_cast<size_t>(t) * 3 + d] - lo[d]) / (hi[d] - lo[d]) : 0.0;
+                    double f = hi[d] > lo[d] ? (c[static_cast<size_t>(t) * 3 + d] - lo[d]) / (hi[d] - lo[d]) : 0.0;
+                    if (!(f >= 0.0)) f = 0.0;                             // (a coordinate that is not a number: any place on the curve will do)
+                    if (f > 1.0) f = 1.0;
                     X[d] = static_cast<uint32_t>(f * 65535.0);
                 }
                 if (hilbert) {

@@ -76,7 +76,9 @@ def main():
                                                   levels[l]["nel"], mg.mesh_variant) == -1 for l in range(len(levels)))
         else:
             ok = all(np.array_equal(s.get(l, "variables").view(np.int64), want[l].view(np.int64)) for l in range(len(levels)))
-        ok = ok and np.allclose(rms, want_rms, rtol=1e-12, atol=1e-300)
+        # (the RMS history: 1e-12 where the state is bit-identical — a tree sum against the reference's loop —, north_star's 1e-10 in the
+        #  fast mode, whose state is a few 1e-12 away after three cycles: seed 41093 reads 2.6e-12 with every tile order)
+        ok = ok and np.allclose(rms, want_rms, rtol=1e-10 if args.fast else 1e-12, atol=1e-300)
         t = s.tiling(0)
         s.close()
         print(f"seed {seed}: {kind} {name} {[l.nel for l in mg.levels]} {opts} list={t['list_entries']} overflow={t['overflow_refs']}: {'ok' if ok else 'MISMATCH'}", flush=True)

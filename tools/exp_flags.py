@@ -13,7 +13,7 @@ procs, objs = [], []
 for ns, contract in (("exact", "off"), ("fast", "fast")):
     o = os.path.join(OUT, f"k_{name}_{ns}.o")
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wno-unused-result",
-                                   "-mllvm", "-amdgpu-kernarg-preload-count=16", f"-ffp-contract={contract}", f"-DMGCFD_KERNEL_NS={ns}"]
+                                   "-mllvm", "-amdgpu-kernarg-preload-count=" + os.environ.get("MGCFD_EXP_PRELOAD", "16"), f"-ffp-contract={contract}", f"-DMGCFD_KERNEL_NS={ns}"]
                                   + (["-DMGCFD_ORDER_FREE=1"] if ns == "fast" else []) + flags
                                   + [f"-I{ROOT}/include", f"-I{CSRC}", "-c", src, "-o", o]))
     objs.append(o)

@@ -698,6 +698,9 @@ def main():
                          "figure counts only if its final state equals the torch path's after the same sweeps — it has been rehearsed on one GPU only")
     ap.add_argument("--rank-graphs", action="store_true",
                     help="partitioned workload, library exchange: replay every rank's sweep from a captured hipGraph (MGCFD_OPT_GRAPH)")
+    ap.add_argument("--no-two-in-flight", action="store_true",
+                    help="skip roofline.two_launches_in_flight (two solvers' batches overlapped on purpose: under rocprofv3 --stats their launches "
+                         "would raise the per-kernel means the summary is read for)")
     ap.add_argument("--no-rank-graphs", action="store_true", help="N > 1: skip the leg that times the RCCL form's sweeps replayed from hipGraphs (`rank_graphs` in the line)")
     ap.add_argument("--no-group", action="store_true", help="N > 1: skip the in-process group leg (one process sweeping all N devices: `in_process_group` in the line)")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle leg (a rocprofv3 summary of the command then holds only the timed workload's launches)")
@@ -1139,7 +1142,7 @@ def main():
         # driver's default of 5 warm-up steps is 0.3 ms.  The line says so in "preheat".
         # (first of all — it builds and frees a second solver, half a second of idle device — what the kernel does with two
         #  independent launches in flight: roofline.two_launches_in_flight)
-        if workload == "level0" and world == 1 and args.variant == -1 and os.environ.get("MGCFD_BENCH_NO_TWO_IN_FLIGHT") != "1":
+        if workload == "level0" and world == 1 and args.variant == -1 and not args.no_two_in_flight and os.environ.get("MGCFD_BENCH_NO_TWO_IN_FLIGHT") != "1":
             two_in_flight = two_launches_in_flight(solver, levels, mg.mesh_variant, local_rank, args.fast)
         solver.bench_flux(0, 2 * ROOFLINE_LAUNCHES)             # (untimed: the ramp itself)
         flux_only = solver.bench_flux(0, ROOFLINE_LAUNCHES)

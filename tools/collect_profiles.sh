@@ -1,6 +1,7 @@
 #!/usr/bin/env bash
 # Per-round evidence, collected on the GPU box into gpurun_out/<tag>/ (copy what is to be judged into profiles/):
-#   kernel-trace summaries of the default bench command and of the V-cycle bench, the un-profiled bench line,
+#   kernel-trace summaries of the default bench command (without its two-in-flight leg: two solvers' launches overlapped on purpose would
+#   raise the per-kernel means) and of the V-cycle bench, the un-profiled bench line,
 #   FETCH_SIZE / WRITE_SIZE passes over the bench command (separate --pmc passes; no trace domain beside --kernel-trace).
 # Usage (GPU box): bash tools/collect_profiles.sh <tag>
 set -u
@@ -10,16 +11,16 @@ mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp && cd "$OLDPWD"
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_bench -- python3 bench.py --no-vcycle --cpu-seconds 0 > $out/bench_default_under_rocprof.json 2> $out/kt_bench.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_bench -- python3 bench.py --no-vcycle --cpu-seconds 0 --no-two-in-flight > $out/bench_default_under_rocprof.json 2> $out/kt_bench.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_vcycle -- python3 tools/vcycle_bench.py --cycles 50 --repeats 2 > $out/vcycle_under_rocprof.json 2> $out/kt_vcycle.log
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 40 --warmup 5 --no-vcycle --cpu-seconds 0 > $out/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 40 --warmup 5 --no-vcycle --cpu-seconds 0 --no-two-in-flight > $out/pmc_$c.log 2>&1
 done
 # the fast mode (MGCFD_OPT_EXACT = 0: order-free stages): its line, its kernel summary, its traffic
 python3 bench.py --fast --steps 2000 --warmup 200 --cpu-seconds 0 > $out/bench_fast.json 2> $out/bench_fast.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_bench_fast -- python3 bench.py --fast --no-vcycle --cpu-seconds 0 > $out/bench_fast_under_rocprof.json 2> $out/kt_bench_fast.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_bench_fast -- python3 bench.py --fast --no-vcycle --cpu-seconds 0 --no-two-in-flight > $out/bench_fast_under_rocprof.json 2> $out/kt_bench_fast.log
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmcfast_$c -- python3 bench.py --fast --steps 40 --warmup 5 --no-vcycle --cpu-seconds 0 > $out/pmcfast_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmcfast_$c -- python3 bench.py --fast --steps 40 --warmup 5 --no-vcycle --cpu-seconds 0 --no-two-in-flight > $out/pmcfast_$c.log 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, os, sys, collections
